@@ -1,0 +1,153 @@
+/* ranslice.h -- C ABI of libranslice.so, the MI355X-native batched RAN-slice simulator.
+ *
+ * The reference (jjalcaraz-upct/network-slicing) has no FFI: its boundary for this path is
+ * the Python class surface gym_ran_slice.RanSlice.reset()/step() (reference
+ * gym-ran_slice/gym_ran_slice/ran_slice.py:30-54) over NodeB.reset()/step()
+ * (reference node_b.py:17-22, 59-91).  The entry points below are what a ctypes binding of
+ * that surface needs; each cites the reference method it stands in for.  All pointers are
+ * plain host pointers unless the name ends in _device; no torch types appear.
+ *
+ * Every function returns RS_OK (0) or a negative error code; rs_last_error() gives text.
+ * A handle is bound to one HIP device and one stream and is not thread-safe.
+ */
+#ifndef RANSLICE_H
+#define RANSLICE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RS_OK 0
+#define RS_EINVAL (-1)    /* bad argument / action shape or sum (reference Q9: silently mis-slices) */
+#define RS_EOVERFLOW (-2) /* a fixed capacity (UEs per slice, bursts per UE, mMTC queue) was exceeded */
+#define RS_EHIP (-3)      /* HIP runtime error */
+#define RS_ESTATE (-4)    /* call order error (e.g. step before reset / fading not loaded) */
+
+#define RS_N_EMBB_VARS 10 /* reference scenario_creator.py:80-82 */
+#define RS_N_MMTC_VARS 3  /* reference scenario_creator.py:92 */
+#define RS_MAX_MCS 32
+#define RS_MAX_SET 8
+#define RS_N_TRACES 3 /* reference channel_models.py:29-33 */
+
+/* Immutable description of one scenario.  Field values come from the reference's
+ * module-level constants (scenario_creator.py:26-96,115-134; channel_models.py:21-27,
+ * 268-270; schedulers.py:13; datasets/mcs_codeset.csv); the Python host fills it. */
+typedef struct rs_config {
+    int32_t n_envs;         /* independent env replicas simulated by this handle */
+    int32_t n_prbs;         /* scenario_creator.py:26-50 */
+    int32_t n_embb;         /* eMBB slices come first, then mMTC (scenario_creator.py:158-166) */
+    int32_t n_mmtc;
+    int32_t slots_per_step; /* scenario_creator.py:100 (50) */
+    int32_t max_ue;         /* capacity: UEs per eMBB slice (0 -> 32) */
+    int32_t max_bursts;     /* capacity: active VBR bursts per UE (0 -> 8) */
+    int32_t max_mtc_queue;  /* capacity: backlogged mMTC devices per slice (0 -> 1024) */
+    double slot_length;     /* 1e-3 s */
+    double penalty;         /* ran_slice.py:19 */
+    /* eMBB traffic (scenario_creator.py:55-69) */
+    double cbr_lambda, cbr_t_mean, cbr_bit_rate;
+    double vbr_lambda, vbr_t_mean, vbr_p_size, vbr_b_size, vbr_b_rate;
+    /* eMBB SLA (scenario_creator.py:71-78): cbr_th, cbr_prb, cbr_queue, vbr_th, vbr_prb, vbr_queue */
+    double sla_embb[6];
+    /* normalisation of the 10 eMBB state variables, in state order (scenario_creator.py:115-126) */
+    double norm_embb[RS_N_EMBB_VARS];
+    /* mMTC (scenario_creator.py:86-96,130-134) */
+    int32_t mtc_n_devices;
+    int32_t mtc_n_rep, mtc_n_period;
+    int32_t mtc_rep_set[RS_MAX_SET];
+    int32_t mtc_period_set[RS_MAX_SET];
+    double sla_mtc_delay;
+    double norm_mmtc[RS_N_MMTC_VARS]; /* devices, avg_rep, delay */
+    /* propagation (channel_models.py:84-97,121-124): L = A + B log10(R) */
+    double prop_A, prop_B;
+    /* proportional-fair scheduler (schedulers.py:13) */
+    int32_t pf_granularity, pf_window, sym_per_prb;
+    /* MCS table (datasets/mcs_codeset.csv; channel_models.py:260-270) */
+    int32_t n_mcs;
+    double mcs_rate[RS_MAX_MCS];
+    double mcs_snr[RS_MAX_MCS];
+    int32_t mcs_order[RS_MAX_MCS];
+    int32_t mcs_mod[RS_MAX_MCS]; /* 0 qpsk, 1 16qam, 2 64qam */
+    double mi_x0[3], mi_k[3];    /* mutual-information sigmoid parameters per modulation */
+} rs_config;
+
+typedef struct rs_handle rs_handle;
+
+/* per-slot, per-UE record for bit-exact allocation checks (debug / parity only) */
+typedef struct rs_alloc_rec {
+    int32_t serial; /* arrival serial of the UE inside its slice, >= 1; 0 = empty entry */
+    int32_t type;   /* 0 CBR, 1 VBR */
+    int32_t e_snr;  /* UE.e_snr after the slot (slice_ran.py:45) */
+    int32_t prbs;   /* UE.prbs after the slot (schedulers.py:68) */
+    int64_t bits;   /* UE.bits after transmission_step (slice_ran.py:51-55) */
+    double queue;   /* UE.queue after the slot */
+    double th;      /* UE.th after the slot */
+    double p;       /* UE.p, reception probability of this slot's allocation (0 if none) */
+} rs_alloc_rec;
+
+/* Build the simulator for cfg->n_envs replicas on HIP device `device`.
+ * Stands in for scenario_creator.create_env (scenario_creator.py:100-183) minus file I/O. */
+int rs_create(const rs_config* cfg, int device, rs_handle** out);
+
+/* Upload fading trace `trace_id` (0..2), given in the reference's CSV layout: row-major
+ * [rows = PRB][cols = time], dB, NaN allowed.  Rows are wrapped up to n_prbs as in
+ * SINRSelectiveFading.__init__ (channel_models.py:141-150).  Data is copied. */
+int rs_load_fading(rs_handle* h, int trace_id, const double* data, int rows, int cols);
+
+/* RanSlice.reset()/NodeB.reset() (ran_slice.py:30-36, node_b.py:17-22) for every replica.
+ * seeds[n_envs]: one 64-bit stream seed per replica (Evaluator.evaluate's default_rng(seed=i),
+ * experiments_kbrl.py:46).  obs (may be NULL) receives zeros [n_envs][n_vars]. */
+int rs_reset(rs_handle* h, const uint64_t* seeds, float* obs);
+
+/* RanSlice.step(action) for every replica (ran_slice.py:38-54, node_b.py:59-91).
+ * actions [n_envs][n_slices] PRBs per slice; must be >= 0 with row sums <= n_prbs.
+ * Outputs (any may be NULL): obs f32 [n_envs][n_vars]; reward f64 [n_envs];
+ * labels i32 [n_envs][n_slices] (+1/-1, node_b.py:51-57); violations i32 [n_envs][n_slices]. */
+int rs_step(rs_handle* h, const int32_t* actions, float* obs, double* reward, int32_t* labels,
+            int32_t* violations);
+
+/* Same step, but actions are already resident in the handle's device action buffer
+ * (filled by rs_random_actions) and nothing is copied back: the timed path of bench.py. */
+int rs_step_resident(rs_handle* h);
+
+/* Fill the device action buffer with i.i.d. multinomial(n_prbs; 1/(S+1) per slice and one
+ * "unused" bin) draws per replica, from Philox stream (seed, step_index).  Used by bench.py
+ *  and reproduced by the oracle for the CPU baseline. */
+int rs_random_actions(rs_handle* h, uint64_t seed, uint64_t step_index);
+
+/* Copy the results of the last step (resident or not) to host buffers (any may be NULL). */
+int rs_fetch(rs_handle* h, int32_t* actions, float* obs, double* reward, int32_t* labels,
+             int32_t* violations);
+
+/* info['l1_info'] accumulators of the last step (node_b.py:46-49): f64 [n_envs][n_slices][10]
+ * (eMBB: cbr_traffic, cbr_th, cbr_prb, cbr_queue, cbr_snr, vbr_...; mMTC: delay, avg_rep,
+ * devices, rest 0). */
+int rs_get_info(rs_handle* h, double* info);
+
+/* Enable (capacity > 0) or disable per-slot allocation tracing.  When enabled every step
+ * records [n_envs][n_embb][slots_per_step][max_ue] rs_alloc_rec entries. */
+int rs_set_alloc_trace(rs_handle* h, int enable);
+int rs_get_alloc_trace(rs_handle* h, rs_alloc_rec* out);
+
+/* Counters maintained by the step kernels since the last rs_reset: [0] = sum over replicas,
+ * slots, eMBB slices of n_ue * n_prbs (fading samples read; SURVEY.md §8d algorithmic bytes),
+ * [1] = env-steps executed, [2] = PF loop iterations, [3] = UE-slots. */
+int rs_get_counters(rs_handle* h, uint64_t counters[4]);
+
+/* Average device time of the dominant step kernel over the launches since the last call,
+ * measured with HIP events on the handle's stream (bench.py roofline leg). */
+int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches);
+int rs_set_kernel_timing(rs_handle* h, int enable);
+
+int rs_synchronize(rs_handle* h);
+int rs_n_vars(const rs_handle* h);
+int rs_n_slices(const rs_handle* h);
+const char* rs_last_error(const rs_handle* h);
+void rs_destroy(rs_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RANSLICE_H */

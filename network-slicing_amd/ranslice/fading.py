@@ -1,0 +1,54 @@
+"""Synthetic frequency-selective fading traces.
+
+The reference reads three ns-3 style traces, `datasets/fading_trace_{EPA_3kmph,
+ETU_3kmph,EVA_60kmph}.csv` (reference channel_models.py:29-33, 141-150): headerless CSV,
+100 rows (PRBs) x T columns (time samples), values in dB, NaNs tolerated.  Those files
+are absent from the reference checkout (.MISSING_LARGE_BLOBS), so this build ships a
+seeded generator with the same layout.  Real traces can be loaded with `load_csv`.
+
+Layout returned here is the reference's: float64 [rows=PRB][cols=time].  The C-ABI
+(`rs_load_fading`) transposes to [time][PRB] for the device.
+"""
+import numpy as np
+
+TRACE_NAMES = ("EPA_3kmph", "ETU_3kmph", "EVA_60kmph")
+# (number of multipath taps, time-domain rate per sample, delay spread in PRB^-1 units)
+_PROFILE = ((7, 0.004, 0.010), (9, 0.004, 0.045), (9, 0.080, 0.025))
+
+
+def synth_fading(trace_id, n_cols, seed=20240, n_rows=100, nan_cols=()):
+    """Sum-of-sinusoids Rayleigh-like gain in dB, quantised to 1e-4 dB."""
+    taps, ft, fd = _PROFILE[trace_id]
+    rng = np.random.default_rng([int(seed), int(trace_id)])
+    t = np.arange(n_cols, dtype=np.float64)[None, :]
+    f = np.arange(n_rows, dtype=np.float64)[:, None]
+    re = np.zeros((n_rows, n_cols))
+    im = np.zeros((n_rows, n_cols))
+    for _ in range(taps):
+        amp = rng.exponential(1.0)
+        w_t = ft * rng.uniform(-1.0, 1.0)
+        w_f = fd * rng.uniform(0.0, 1.0)
+        ph = rng.uniform(0.0, 2.0 * np.pi)
+        arg = 2.0 * np.pi * (w_t * t + w_f * f) + ph
+        re += amp * np.cos(arg)
+        im += amp * np.sin(arg)
+    power = (re * re + im * im) / taps
+    db = 10.0 * np.log10(np.maximum(power, 1e-6)) + 0.25 * rng.standard_normal((n_rows, n_cols))
+    db = np.round(db, 4)
+    for c in nan_cols:
+        db[int(rng.integers(n_rows)), int(c)] = np.nan
+    return np.ascontiguousarray(db)
+
+
+def extend_rows(table, n_prbs):
+    """Row extension used when the cell has more than 100 PRBs: wrap the first rows
+    (reference channel_models.py:144-148)."""
+    rows = table.shape[0]
+    if n_prbs > rows:
+        table = np.vstack((table, table[0:n_prbs - rows, :]))
+    return np.ascontiguousarray(table)
+
+
+def load_csv(path):
+    """Load a real trace in the reference's CSV layout (headerless, rows=PRB)."""
+    return np.ascontiguousarray(np.genfromtxt(path, delimiter=",", dtype=np.float64))
