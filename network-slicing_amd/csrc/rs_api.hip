@@ -1,0 +1,671 @@
+// rs_api.hip -- host side of libranslice.so: the C ABI declared in include/ranslice.h.
+// Owns device memory, the stream and the launches.  No torch, no CPU fallback: without a HIP
+// device rs_create fails with RS_EHIP.
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rs_embb.hip"
+#include "rs_mmtc.hip"
+
+using namespace rs;
+
+struct rs_handle {
+    rs_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    RsDev hdev;            // host copy of the device constants
+    RsDev* ddev = nullptr;
+    RsState st;
+    MtcState mst;
+    std::vector<void*> allocs;
+    double* fad = nullptr;
+    uint8_t* fad_valid = nullptr;
+    bool fad_loaded[RS_N_TRACES] = {false, false, false};
+    std::vector<double> fad_host[RS_N_TRACES];
+    std::vector<uint8_t> valid_host[RS_N_TRACES];
+    int32_t* d_actions = nullptr;
+    float* d_obs = nullptr;
+    double* d_reward = nullptr;
+    int32_t* d_labels = nullptr;
+    int32_t* d_viol = nullptr;
+    double* d_info = nullptr;
+    uint64_t* d_counters = nullptr;   // [n_tasks][4]
+    uint64_t* d_counter_sum = nullptr;  // [4]
+    rs_alloc_rec* d_trace = nullptr;
+    bool trace_on = false;
+    int n_slices = 0, n_vars = 0, n_tasks = 0;
+    int32_t clock = 0;     // slots since reset
+    uint64_t steps = 0;
+    bool is_reset = false;
+    // kernel timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t ev_used = 0;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) {                                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                            \
+            return RS_EHIP;                                                                          \
+        }                                                                                            \
+    } while (0)
+
+template <class T>
+static int dalloc(rs_handle* h, T** p, size_t n) {
+    void* q = nullptr;
+    size_t bytes = sizeof(T) * (n ? n : 1);
+    HIPCHK(h, hipMalloc(&q, bytes));
+    HIPCHK(h, hipMemsetAsync(q, 0, bytes, h->stream));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return RS_OK;
+}
+
+// ------------------------------------------------------------------ mMTC host helpers
+
+static int mtc_alloc(rs_handle* h, rs::MtcState* m, size_t n_tasks, const RsDev& d) {
+    memset(m, 0, sizeof *m);
+    m->n_tasks = n_tasks;
+    m->cap = d.mtc_cap;
+    if (n_tasks == 0) return RS_OK;
+    if (d.mtc_n_dev > MTC_DEV_MAX || d.mtc_cap > MTC_CAP_MAX || d.mtc_n_rep <= 0 || d.mtc_n_rep > 8 ||
+        d.mtc_n_period <= 0 || d.mtc_n_period > 8) {
+        h->err = "rs_create: mMTC configuration out of range (<=1024 devices, queue capacity <=2048)";
+        return RS_EINVAL;
+    }
+    for (int i = 0; i < d.mtc_n_period; ++i)
+        if (d.mtc_period_set[i] < d.slots) {
+            h->err = "rs_create: mMTC periods shorter than one observation period are not supported";
+            return RS_EINVAL;
+        }
+    int rc;
+    if ((rc = dalloc(h, &m->n_users, n_tasks)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->s_start, n_tasks)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->s_rep, n_tasks)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->dev_next, n_tasks * MTC_DEV_MAX)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->dev_period, n_tasks * MTC_DEV_MAX)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->dev_rep, n_tasks * MTC_DEV_MAX)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->q_rep, n_tasks * (size_t)m->cap)) != RS_OK) return rc;
+    if ((rc = dalloc(h, &m->q_start, n_tasks * (size_t)m->cap)) != RS_OK) return rc;
+    return RS_OK;
+}
+
+static int mtc_reset(rs_handle* h, rs::MtcState* m) {
+    if (m->n_tasks == 0) return RS_OK;
+    hipLaunchKernelGGL(rs::mtc_reset_kernel, dim3((unsigned)m->n_tasks), dim3(256), 0, h->stream, h->ddev, *m,
+                       h->st.seeds);
+    return RS_OK;
+}
+
+static int mtc_step(rs_handle* h, rs::MtcState* m) {
+    if (m->n_tasks == 0) return RS_OK;
+    rs::MtcArgs a;
+    a.D = h->ddev;
+    a.M = *m;
+    a.actions = h->d_actions;
+    a.clock0 = h->clock;
+    a.obs = h->d_obs;
+    a.labels = h->d_labels;
+    a.violations = h->d_viol;
+    a.info = h->d_info;
+    a.err = h->st.err;
+    size_t lds = (size_t)4 * 2 * m->cap * sizeof(int32_t);
+    hipLaunchKernelGGL(rs::mtc_step_kernel, dim3((unsigned)((m->n_tasks + 3) / 4)), dim3(256), lds, h->stream, a);
+    return RS_OK;
+}
+
+// ------------------------------------------------------------------ small kernels
+
+namespace rs {
+
+__global__ void reset_kernel(const RsDev* D, RsState S, const uint64_t* seeds_in) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int n_tasks = D->n_envs * D->n_embb;
+    if (i < n_tasks) {
+        S.t_n_ue[i] = 0;
+        S.t_cbr_at[i] = 1;  // cbr_steps_next_arrival = 0 (slice_ran.py:185): fires in the first slot
+        S.t_vbr_at[i] = 1;
+        S.t_ctr[i] = 0;
+        S.t_serial[i] = 1;
+    }
+    if (i < D->n_envs) {
+        S.seeds[i] = seeds_in[i];
+        S.err[i] = 0;
+    }
+}
+
+// reward of RanSlice.step (ran_slice.py:45-52)
+__global__ void finalize_kernel(const RsDev* D, const int32_t* actions, const int32_t* viol, double* reward) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= D->n_envs) return;
+    int S = D->n_slices;
+    long tv = 0, ta = 0;
+    for (int s = 0; s < S; ++s) {
+        tv += viol[r * S + s];
+        ta += actions[r * S + s];
+    }
+    double rew;
+    if (tv > 0)
+        rew = -1 * D->penalty * (double)tv;
+    else
+        rew = (double)(D->n_prbs - ta > 0 ? D->n_prbs - ta : 0);
+    reward[r] = rew;
+}
+
+// bench action script: one wave per replica, one categorical draw
+// per PRB over S slices + "unused"; identical to rso_random_actions.
+__global__ __launch_bounds__(256) void random_actions_kernel(const RsDev* D, int32_t* actions, uint64_t seed,
+                                                           uint64_t step) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= D->n_envs) return;
+    const int S = D->n_slices;
+    int my_bin[8];
+    int cnt = 0;
+    for (int p = lane; p < D->n_prbs; p += 64) {
+        uint32_t a, b;
+        rs_philox4x32_10((uint32_t)p, (uint32_t)r, (uint32_t)step,
+                         (uint32_t)(step >> 32) ^ (uint32_t)((uint64_t)r >> 32) ^ 0x5bd1e995u, (uint32_t)seed,
+                         (uint32_t)(seed >> 32), &a, &b);
+        my_bin[cnt++ & 7] = (int)(((uint64_t)a * (uint64_t)(S + 1)) >> 32);
+    }
+    for (int s = 0; s < S; ++s) {
+        int c = 0;
+        for (int k = 0; k < cnt; ++k) c += my_bin[k] == s ? 1 : 0;
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+        if (lane == 0) actions[r * S + s] = c;
+    }
+}
+
+__global__ void counter_sum_kernel(const uint64_t* per_task, int n_tasks, uint64_t* out) {
+    __shared__ unsigned long long acc[4];
+    if (threadIdx.x < 4) acc[threadIdx.x] = 0ull;
+    __syncthreads();
+    unsigned long long loc[4] = {0ull, 0ull, 0ull, 0ull};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_tasks; i += gridDim.x * blockDim.x)
+        for (int k = 0; k < 4; ++k) loc[k] += per_task[(size_t)i * 4 + k];
+    for (int k = 0; k < 4; ++k) atomicAdd(&acc[k], loc[k]);
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd((unsigned long long*)&out[threadIdx.x], acc[threadIdx.x]);
+}
+
+}  // namespace rs
+
+// ------------------------------------------------------------------ create / destroy
+
+static void mcs_factors(double* A, double* B) {  // MCSCodeset.compute_factors (channel_models.py:272-279)
+    double Delta = 0.1;
+    double a = 1.0 / Delta;
+    double s01 = rs_sigmoid(0.1, 0.0, 1.0), s09 = rs_sigmoid(0.9, 0.0, 1.0);
+    a = a * (rs_log(1.0 / s01 - 1.0) - rs_log(1.0 / s09 - 1.0));
+    *A = a;
+    *B = -rs_log(1.0 / s09 - 1.0);
+}
+
+// mcs_rate_vs_error (channel_models.py:288-295) + int truncation of the rate (schedulers.py:44)
+static void mcs_lookup(const rs_config* c, double A, double B, int e_snr, int* mcs_out, int* rate_out) {
+    double rx_prob = 1.0 - 0.1;
+    int mcs;
+    for (mcs = 0; mcs < c->n_mcs; ++mcs) {
+        double x = A * ((double)e_snr - c->mcs_snr[mcs]) - B;
+        if (rs_sigmoid(x, 0.0, 1.0) < rx_prob) {
+            *mcs_out = mcs - 1 > 0 ? mcs - 1 : 0;
+            *rate_out = (int)((double)c->sym_per_prb * (c->mcs_rate[mcs] * (double)c->mcs_order[mcs]));
+            return;
+        }
+    }
+    mcs = c->n_mcs - 1;
+    *mcs_out = mcs;
+    *rate_out = (int)((double)c->sym_per_prb * (c->mcs_rate[mcs] * (double)c->mcs_order[mcs]));
+}
+
+extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
+    if (!cfg || !out) return RS_EINVAL;
+    *out = nullptr;
+    rs_handle* h = new rs_handle();
+    *out = h;  // returned even on failure so that rs_last_error works; caller destroys it
+    h->cfg = *cfg;
+    h->device = device;
+    if (cfg->n_envs <= 0 || cfg->n_prbs <= 0 || cfg->n_prbs > RS_MAX_PRBS || cfg->n_embb < 0 || cfg->n_mmtc < 0 ||
+        cfg->n_embb + cfg->n_mmtc <= 0 || cfg->slots_per_step <= 0 || cfg->n_mcs <= 0 || cfg->n_mcs > 32 ||
+        cfg->pf_granularity <= 0 || (cfg->max_ue != 0 && cfg->max_ue != RS_GROUP) ||
+        (cfg->max_bursts != 0 && cfg->max_bursts != RS_BURSTS)) {
+        h->err = "rs_create: unsupported configuration (n_prbs <= 256, max_ue in {0,32}, max_bursts in {0,8})";
+        return RS_EINVAL;
+    }
+    int ndev = 0;
+    HIPCHK(h, hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) {
+        h->err = "rs_create: no such HIP device";
+        return RS_EHIP;
+    }
+    HIPCHK(h, hipSetDevice(device));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->n_slices = cfg->n_embb + cfg->n_mmtc;
+    h->n_vars = cfg->n_embb * RS_N_EMBB_VARS + cfg->n_mmtc * RS_N_MMTC_VARS;
+    h->n_tasks = cfg->n_envs * cfg->n_embb;
+
+    RsDev& d = h->hdev;
+    memset(&d, 0, sizeof d);
+    d.n_envs = cfg->n_envs;
+    d.n_prbs = cfg->n_prbs;
+    d.n_embb = cfg->n_embb;
+    d.n_mmtc = cfg->n_mmtc;
+    d.n_slices = h->n_slices;
+    d.slots = cfg->slots_per_step;
+    d.n_vars = h->n_vars;
+    d.slot_length = cfg->slot_length;
+    d.cbr_bits = cfg->cbr_bit_rate * 1e-3;
+    d.cbr_ia_scale = 1.0 / cfg->cbr_lambda;
+    d.cbr_hold_scale = cfg->cbr_t_mean;
+    d.vbr_ia_scale = 1.0 / cfg->vbr_lambda;
+    d.vbr_hold_scale = cfg->vbr_t_mean;
+    d.vbr_p_size = cfg->vbr_p_size;
+    d.vbr_b_size = cfg->vbr_b_size;
+    d.vbr_inter = (1 / cfg->vbr_b_rate) / cfg->slot_length;
+    for (int i = 0; i < 6; ++i) d.sla[i] = cfg->sla_embb[i];
+    for (int i = 0; i < 10; ++i) d.norm[i] = cfg->norm_embb[i];
+    d.prop_A = cfg->prop_A;
+    d.prop_B = cfg->prop_B;
+    mcs_factors(&d.mcsA, &d.mcsB);
+    d.pf_b = 1.0 / cfg->pf_window;
+    d.pf_a = 1 - d.pf_b;
+    d.gran = cfg->pf_granularity;
+    d.penalty = cfg->penalty;
+    // e_snr -> (mcs, rate): outside [lo, hi] the answer is constant (first / no failing MCS)
+    {
+        int lo = (int)std::floor(cfg->mcs_snr[0]) - 4, hi = (int)std::ceil(cfg->mcs_snr[cfg->n_mcs - 1]) + 4;
+        if (hi - lo + 1 > RS_LUT_MAX) {
+            h->err = "rs_create: MCS table spans too many dB for the lookup";
+            return RS_EINVAL;
+        }
+        d.lut_lo = lo;
+        d.lut_n = hi - lo + 1;
+        for (int e = lo; e <= hi; ++e) mcs_lookup(cfg, d.mcsA, d.mcsB, e, &d.lut_mcs[e - lo], &d.lut_rate[e - lo]);
+        int m, r;
+        mcs_lookup(cfg, d.mcsA, d.mcsB, lo - 50, &m, &r);
+        bool ok = m == d.lut_mcs[0] && r == d.lut_rate[0];
+        mcs_lookup(cfg, d.mcsA, d.mcsB, hi + 50, &m, &r);
+        ok = ok && m == d.lut_mcs[d.lut_n - 1] && r == d.lut_rate[d.lut_n - 1];
+        if (!ok) {
+            h->err = "rs_create: MCS lookup is not constant outside the tabulated range";
+            return RS_EINVAL;
+        }
+    }
+    for (int m = 0; m < cfg->n_mcs; ++m) {
+        d.mcs_ref[m] = cfg->mcs_snr[m];
+        d.mcs_x0[m] = cfg->mi_x0[cfg->mcs_mod[m]];
+        d.mcs_k[m] = cfg->mi_k[cfg->mcs_mod[m]];
+    }
+    d.mtc_n_dev = cfg->mtc_n_devices;
+    d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
+    d.mtc_n_rep = cfg->mtc_n_rep;
+    d.mtc_n_period = cfg->mtc_n_period;
+    for (int i = 0; i < 8; ++i) {
+        d.mtc_rep_set[i] = cfg->mtc_rep_set[i];
+        d.mtc_period_set[i] = cfg->mtc_period_set[i];
+    }
+    d.sla_mtc_delay = cfg->sla_mtc_delay;
+    for (int i = 0; i < 3; ++i) d.norm_mmtc[i] = cfg->norm_mmtc[i];
+
+    int rc;
+    const size_t T = (size_t)h->n_tasks, U = T * RS_GROUP, N = (size_t)cfg->n_envs;
+    RsState& s = h->st;
+#define DA(p, n)                                   \
+    if ((rc = dalloc(h, &(p), (n))) != RS_OK) return rc
+    DA(h->ddev, 1);
+    DA(s.t_n_ue, T); DA(s.t_cbr_at, T); DA(s.t_vbr_at, T); DA(s.t_ctr, T); DA(s.t_serial, T);
+    DA(s.u_queue, U); DA(s.u_th, U); DA(s.u_nominal, U);
+    DA(s.u_hold_at, U); DA(s.u_e_snr, U); DA(s.u_findex, U); DA(s.u_bits, U); DA(s.u_prbs, U);
+    DA(s.u_vbr_at, U); DA(s.u_ctr, U); DA(s.u_serial, U); DA(s.u_flags, U);
+    DA(s.u_burst, U * RS_BURSTS);
+    DA(s.seeds, N); DA(s.err, N);
+    DA(h->d_actions, N * h->n_slices);
+    DA(h->d_obs, N * h->n_vars);
+    DA(h->d_reward, N);
+    DA(h->d_labels, N * h->n_slices);
+    DA(h->d_viol, N * h->n_slices);
+    DA(h->d_info, N * h->n_slices * 10);
+    DA(h->d_counters, (T ? T : 1) * 4);
+    DA(h->d_counter_sum, 4);
+    if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
+#undef DA
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+extern "C" void rs_destroy(rs_handle* h) {
+    if (!h) return;
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->fad) (void)hipFree(h->fad);
+    if (h->fad_valid) (void)hipFree(h->fad_valid);
+    if (h->d_trace) (void)hipFree(h->d_trace);
+    for (auto& e : h->ev) {
+        (void)hipEventDestroy(e.first);
+        (void)hipEventDestroy(e.second);
+    }
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+extern "C" const char* rs_last_error(const rs_handle* h) { return h ? h->err.c_str() : "null handle"; }
+extern "C" int rs_n_vars(const rs_handle* h) { return h ? h->n_vars : RS_EINVAL; }
+extern "C" int rs_n_slices(const rs_handle* h) { return h ? h->n_slices : RS_EINVAL; }
+
+// ------------------------------------------------------------------ fading tables
+
+static int upload_fading(rs_handle* h) {
+    RsDev& d = h->hdev;
+    size_t elems = 0, vbytes = 0;
+    d.has_nan = 0;
+    for (int f = 0; f < RS_N_TRACES; ++f) {
+        d.fad_off[f] = (int64_t)elems;
+        d.valid_off[f] = (int64_t)vbytes;
+        elems += h->fad_host[f].size();
+        vbytes += h->valid_host[f].size();
+        bool any_valid = false;
+        for (uint8_t v : h->valid_host[f]) {
+            if (!v) d.has_nan = 1;
+            any_valid = any_valid || v;
+        }
+        if (!any_valid) {
+            h->err = "rs_load_fading: a trace has no NaN-free column";
+            return RS_EINVAL;
+        }
+    }
+    if (elems + (size_t)RS_MAX_PRBS >= (size_t)1 << 31) {
+        h->err = "rs_load_fading: tables exceed 2^31 samples";
+        return RS_EINVAL;
+    }
+    if (h->fad) (void)hipFree(h->fad);
+    if (h->fad_valid) (void)hipFree(h->fad_valid);
+    // tail padding so that a subgroup's strided reads never leave the allocation
+    HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
+    HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
+    for (int f = 0; f < RS_N_TRACES; ++f) {
+        HIPCHK(h, hipMemcpyAsync(h->fad + d.fad_off[f], h->fad_host[f].data(), sizeof(double) * h->fad_host[f].size(),
+                                 hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipMemcpyAsync(h->fad_valid + d.valid_off[f], h->valid_host[f].data(), h->valid_host[f].size(),
+                                 hipMemcpyHostToDevice, h->stream));
+    }
+    HIPCHK(h, hipMemcpyAsync(h->ddev, &d, sizeof d, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (int f = 0; f < RS_N_TRACES; ++f) {
+        std::vector<double>().swap(h->fad_host[f]);
+        std::vector<uint8_t>().swap(h->valid_host[f]);
+    }
+    return RS_OK;
+}
+
+extern "C" int rs_load_fading(rs_handle* h, int trace_id, const double* data, int rows, int cols) {
+    if (!h) return RS_EINVAL;
+    if (trace_id < 0 || trace_id >= RS_N_TRACES || !data || rows <= 0 || cols <= 0 || h->cfg.n_prbs > 2 * rows) {
+        h->err = "rs_load_fading: bad arguments";
+        return RS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    const int P = h->cfg.n_prbs > rows ? h->cfg.n_prbs : rows;
+    if (h->hdev.P != 0 && h->hdev.P != P) {
+        h->err = "rs_load_fading: all traces must have the same number of rows";
+        return RS_EINVAL;
+    }
+    h->hdev.P = P;
+    h->hdev.T[trace_id] = cols;
+    // transpose to [time][PRB] with the reference's row wrap (channel_models.py:144-148); a column
+    // is invalid if np.isnan(np.sum(column)) over all rows (channel_models.py:188-189)
+    std::vector<double>& tab = h->fad_host[trace_id];
+    std::vector<uint8_t>& val = h->valid_host[trace_id];
+    tab.assign((size_t)P * cols, 0.0);
+    val.assign((size_t)cols, 1);
+    for (int t = 0; t < cols; ++t) {
+        bool bad = false;
+        for (int p = 0; p < P; ++p) {
+            double v = data[(size_t)(p % rows) * cols + t];
+            tab[(size_t)t * P + p] = v;
+            bad = bad || (v != v);
+        }
+        val[t] = bad ? 0 : 1;
+    }
+    h->fad_loaded[trace_id] = true;
+    if (h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]) return upload_fading(h);
+    return RS_OK;
+}
+
+// ------------------------------------------------------------------ reset / step
+
+static bool fading_ready(const rs_handle* h) {
+    return h->cfg.n_embb == 0 || (h->fad != nullptr && h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]);
+}
+
+extern "C" int rs_reset(rs_handle* h, const uint64_t* seeds, float* obs) {
+    if (!h || !seeds) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!fading_ready(h)) {
+        h->err = "rs_reset: fading traces not loaded";
+        return RS_ESTATE;
+    }
+    const int N = h->cfg.n_envs;
+    if (h->cfg.n_embb == 0) HIPCHK(h, hipMemcpyAsync(h->ddev, &h->hdev, sizeof(RsDev), hipMemcpyHostToDevice, h->stream));
+    uint64_t* tmp = nullptr;
+    HIPCHK(h, hipMalloc((void**)&tmp, sizeof(uint64_t) * N));
+    HIPCHK(h, hipMemcpyAsync(tmp, seeds, sizeof(uint64_t) * N, hipMemcpyHostToDevice, h->stream));
+    int n = h->n_tasks > N ? h->n_tasks : N;
+    hipLaunchKernelGGL(reset_kernel, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->ddev, h->st, tmp);
+    if (h->cfg.n_mmtc > 0) mtc_reset(h, &h->mst);
+    HIPCHK(h, hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * 4 * (h->n_tasks ? h->n_tasks : 1), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_obs, 0, sizeof(float) * N * h->n_vars, h->stream));
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+    h->clock = 0;
+    h->steps = 0;
+    h->is_reset = true;
+    if (obs) memset(obs, 0, sizeof(float) * (size_t)N * h->n_vars);
+    return RS_OK;
+}
+
+static int launch_step(rs_handle* h) {
+    if (!h->is_reset) {
+        h->err = "rs_step: call rs_reset first";
+        return RS_ESTATE;
+    }
+    if (h->clock > 2000000000 - h->cfg.slots_per_step) {
+        h->err = "rs_step: slot clock would overflow; reset the environment";
+        return RS_ESTATE;
+    }
+    if (h->n_tasks > 0) {
+        StepArgs a;
+        a.D = h->ddev;
+        a.S = h->st;
+        a.fad = h->fad;
+        a.fad_valid = h->fad_valid;
+        a.actions = h->d_actions;
+        a.clock0 = h->clock;
+        a.obs = h->d_obs;
+        a.labels = h->d_labels;
+        a.violations = h->d_viol;
+        a.info = h->d_info;
+        a.counters = h->d_counters;
+        a.trace = h->d_trace;
+        const int per_block = 256 / RS_GROUP;
+        dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (h->timing) {
+            if (h->ev_used == h->ev.size()) {
+                hipEvent_t a0, a1;
+                HIPCHK(h, hipEventCreate(&a0));
+                HIPCHK(h, hipEventCreate(&a1));
+                h->ev.emplace_back(a0, a1);
+            }
+            e0 = h->ev[h->ev_used].first;
+            e1 = h->ev[h->ev_used].second;
+            h->ev_used++;
+            HIPCHK(h, hipEventRecord(e0, h->stream));
+        }
+        if (h->trace_on)
+            hipLaunchKernelGGL(embb_step_kernel<true>, grid, block, 0, h->stream, a);
+        else
+            hipLaunchKernelGGL(embb_step_kernel<false>, grid, block, 0, h->stream, a);
+        if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
+    }
+    if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
+    hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,
+                       h->d_actions, h->d_viol, h->d_reward);
+    HIPCHK(h, hipGetLastError());
+    h->clock += h->cfg.slots_per_step;
+    h->steps += 1;
+    return RS_OK;
+}
+
+static int check_errors(rs_handle* h) {
+    std::vector<int32_t> e((size_t)h->cfg.n_envs);
+    HIPCHK(h, hipMemcpyAsync(e.data(), h->st.err, sizeof(int32_t) * e.size(), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    for (size_t i = 0; i < e.size(); ++i)
+        if (e[i]) {
+            h->err = "capacity exceeded (UEs per slice, bursts per UE or mMTC queue) in replica " + std::to_string(i);
+            return RS_EOVERFLOW;
+        }
+    return RS_OK;
+}
+
+extern "C" int rs_fetch(rs_handle* h, int32_t* actions, float* obs, double* reward, int32_t* labels,
+                        int32_t* violations) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.n_envs, S = (size_t)h->n_slices;
+    if (actions) HIPCHK(h, hipMemcpyAsync(actions, h->d_actions, sizeof(int32_t) * N * S, hipMemcpyDeviceToHost, h->stream));
+    if (obs) HIPCHK(h, hipMemcpyAsync(obs, h->d_obs, sizeof(float) * N * h->n_vars, hipMemcpyDeviceToHost, h->stream));
+    if (reward) HIPCHK(h, hipMemcpyAsync(reward, h->d_reward, sizeof(double) * N, hipMemcpyDeviceToHost, h->stream));
+    if (labels) HIPCHK(h, hipMemcpyAsync(labels, h->d_labels, sizeof(int32_t) * N * S, hipMemcpyDeviceToHost, h->stream));
+    if (violations) HIPCHK(h, hipMemcpyAsync(violations, h->d_viol, sizeof(int32_t) * N * S, hipMemcpyDeviceToHost, h->stream));
+    return check_errors(h);
+}
+
+extern "C" int rs_step(rs_handle* h, const int32_t* actions, float* obs, double* reward, int32_t* labels,
+                       int32_t* violations) {
+    if (!h || !actions) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t N = (size_t)h->cfg.n_envs, S = (size_t)h->n_slices;
+    for (size_t r = 0; r < N; ++r) {  // Q9: the reference silently mis-slices; the build rejects
+        long tot = 0;
+        for (size_t s = 0; s < S; ++s) {
+            if (actions[r * S + s] < 0) {
+                h->err = "rs_step: negative action";
+                return RS_EINVAL;
+            }
+            tot += actions[r * S + s];
+        }
+        if (tot > h->cfg.n_prbs) {
+            h->err = "rs_step: sum(action) > n_prbs in replica " + std::to_string(r);
+            return RS_EINVAL;
+        }
+    }
+    HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, sizeof(int32_t) * N * S, hipMemcpyHostToDevice, h->stream));
+    int rc = launch_step(h);
+    if (rc != RS_OK) return rc;
+    return rs_fetch(h, nullptr, obs, reward, labels, violations);
+}
+
+extern "C" int rs_step_resident(rs_handle* h) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    return launch_step(h);
+}
+
+extern "C" int rs_random_actions(rs_handle* h, uint64_t seed, uint64_t step_index) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->n_slices > 8) {
+        h->err = "rs_random_actions: at most 8 slices";
+        return RS_EINVAL;
+    }
+    if (h->cfg.n_prbs > 512) return RS_EINVAL;
+    hipLaunchKernelGGL(random_actions_kernel, dim3((h->cfg.n_envs + 3) / 4), dim3(256), 0, h->stream, h->ddev,
+                       h->d_actions, seed, step_index);
+    HIPCHK(h, hipGetLastError());
+    return RS_OK;
+}
+
+extern "C" int rs_get_info(rs_handle* h, double* info) {
+    if (!h || !info) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof(double) * (size_t)h->cfg.n_envs * h->n_slices * 10,
+                             hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_set_alloc_trace(rs_handle* h, int enable) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (enable && !h->d_trace) {
+        size_t n = (size_t)h->n_tasks * h->cfg.slots_per_step * RS_GROUP;
+        HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(rs_alloc_rec) * (n ? n : 1)));
+    }
+    h->trace_on = enable != 0;
+    return RS_OK;
+}
+
+extern "C" int rs_get_alloc_trace(rs_handle* h, rs_alloc_rec* out) {
+    if (!h || !out || !h->d_trace) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    size_t n = (size_t)h->n_tasks * h->cfg.slots_per_step * RS_GROUP;
+    HIPCHK(h, hipMemcpyAsync(out, h->d_trace, sizeof(rs_alloc_rec) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
+    if (!h || !counters) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_counter_sum, 0, sizeof(uint64_t) * 4, h->stream));
+    if (h->n_tasks > 0)
+        hipLaunchKernelGGL(counter_sum_kernel, dim3(64), dim3(256), 0, h->stream, h->d_counters, h->n_tasks,
+                           h->d_counter_sum);
+    HIPCHK(h, hipMemcpyAsync(counters, h->d_counter_sum, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    counters[1] = h->steps * (uint64_t)h->cfg.n_envs;
+    return RS_OK;
+}
+
+extern "C" int rs_set_kernel_timing(rs_handle* h, int enable) {
+    if (!h) return RS_EINVAL;
+    h->timing = enable != 0;
+    h->ev_used = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches) {
+    if (!h || !avg_ms) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    double tot = 0.0;
+    for (size_t i = 0; i < h->ev_used; ++i) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
+        tot += ms;
+    }
+    *avg_ms = h->ev_used ? tot / (double)h->ev_used : 0.0;
+    if (launches) *launches = (int64_t)h->ev_used;
+    h->ev_used = 0;
+    return RS_OK;
+}
+
+extern "C" int rs_synchronize(rs_handle* h) {
+    if (!h) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}

@@ -1,0 +1,72 @@
+// rs_device.h -- device-side data layout of the batched RAN-slice simulator (gfx950).
+//
+// One "task" is one eMBB slice of one env replica.  A task is advanced by a 32-lane half
+// wavefront: lane u of the group owns UE u of the slice (UE list order = arrival order,
+// reference slice_l1.py:183-191), so every per-UE quantity lives in a register and the
+// per-slot reductions the reference does with Python loops (argmax of the PF metric,
+// RB prefix sums, per-class sums) are cross-lane operations.  Persistent state is kept in HBM
+// as structure-of-arrays with the UE index fastest, so a group's load of one field is one
+// contiguous 128/256-byte segment.
+#pragma once
+#include <stdint.h>
+
+#define RS_GROUP 32          // lanes per task == UE capacity per slice
+#define RS_BURSTS 8          // VBR burst slots per UE
+#define RS_LUT_MAX 64
+#define RS_NEVER 0x7fffffff  // absolute slot time that never arrives (reference quirk Q5)
+#define RS_MAX_PRBS 256
+
+// Immutable parameters, one copy in HBM, read through scalar loads.
+struct RsDev {
+    int32_t n_envs, n_prbs, n_embb, n_mmtc, n_slices, slots, n_vars;
+    int32_t P;              // row length of the fading tables (PRBs after row extension)
+    int32_t T[3];           // time samples per trace
+    int32_t has_nan;        // any trace column flagged invalid
+    int64_t fad_off[3];     // element offset of trace f inside the table buffer
+    int64_t valid_off[3];   // byte offset of trace f inside the column-valid buffer
+    double slot_length;
+    double cbr_bits;        // CbrSource packet size = bit_rate * 1e-3 (traffic_generators.py:56-59)
+    double cbr_ia_scale, cbr_hold_scale;   // 1/lambda, t_mean (slice_ran.py:208,220)
+    double vbr_ia_scale, vbr_hold_scale;   // slice_ran.py:243,238
+    double vbr_p_size, vbr_b_size, vbr_inter;  // traffic_generators.py:62-66
+    double sla[6], norm[10];
+    double prop_A, prop_B;
+    double mcsA, mcsB;      // MCSCodeset.compute_factors (channel_models.py:272-279)
+    double pf_a, pf_b;      // 1 - 1/window, 1/window (schedulers.py:16-17, slice_ran.py:30-31)
+    int32_t gran;           // PF granularity
+    int32_t lut_lo, lut_n;  // e_snr -> (mcs, rate) lookup, clamped outside [lut_lo, lut_lo+lut_n)
+    int32_t lut_mcs[RS_LUT_MAX], lut_rate[RS_LUT_MAX];
+    double mcs_ref[32], mcs_x0[32], mcs_k[32];
+    double penalty;
+    // mMTC
+    int32_t mtc_n_dev, mtc_cap, mtc_n_rep, mtc_n_period;
+    int32_t mtc_rep_set[8], mtc_period_set[8];
+    double sla_mtc_delay, norm_mmtc[3];
+};
+
+// Persistent per-task / per-UE state (device pointers).
+struct RsState {
+    // per task [n_envs * n_embb]
+    int32_t* t_n_ue;
+    int32_t* t_cbr_at;      // absolute slot at which the next CBR arrival check fires
+    int32_t* t_vbr_at;
+    uint32_t* t_ctr;        // slice-level Philox draw counter
+    uint32_t* t_serial;     // next UE serial
+    // per UE [task][RS_GROUP]
+    double* u_queue;
+    double* u_th;
+    double* u_nominal;
+    int32_t* u_hold_at;     // absolute slot at which the UE departs
+    int32_t* u_e_snr;
+    int32_t* u_findex;
+    int32_t* u_bits;        // last slot's UE.bits (kept for Q2)
+    int32_t* u_prbs;
+    int32_t* u_vbr_at;      // absolute slot of the source's next burst arrival
+    uint32_t* u_ctr;
+    uint32_t* u_serial;
+    int32_t* u_flags;       // bit0 type (0 CBR, 1 VBR), bits1-2 fading trace, bit3 step sign (+1 if set)
+    int32_t* u_burst;       // [task][RS_BURSTS][RS_GROUP] absolute end slots, 0 = free
+    // per replica
+    uint64_t* seeds;
+    int32_t* err;           // [n_envs] sticky error flags (RS_EOVERFLOW ...)
+};

@@ -1,0 +1,624 @@
+// rs_embb.hip -- one observation period (slots_per_step slots) of every eMBB slice of every
+// replica, on gfx950.
+//
+// What it computes (reference call tree):
+//   NodeB.step                 node_b.py:59-91      (set_prbs + the slot loop for eMBB slices)
+//   SliceL1eMBB.slot           slice_l1.py:193-228
+//   SliceRANeMBB.slot/...      slice_ran.py:195-325 (arrivals, CAC, departures, update_info, SLA)
+//   UE.*                       slice_ran.py:20-58
+//   ProportionalFair.allocate  schedulers.py:21-76
+//   SINRSelectiveFading / MCSCodeset / macro_cell   channel_models.py
+//   CbrSource / VbrSource      traffic_generators.py
+//
+// Mapping to the machine: a 32-lane half-wave owns one (replica, slice) task for the whole
+// step, lane u = UE u; state sits in VGPRs for all 50 slots and touches HBM once in, once out.
+// The only HBM traffic inside the loop is the fading table: a UE's per-slot column
+// [time][PRB] is contiguous, and is summed by an 8-lane subgroup in numpy's pairwise order
+// (8 strided accumulators == 8 lanes), four UEs per group at a time.  The PF loop is the
+// serial part: one argmax per RB pair, done as a cross-lane f64 max + ballot; it exits in
+// closed form once every queue is drained (reference quirk Q4 gives the rest to UE 0).
+// Compiled with -ffp-contract=off: all f64 arithmetic is IEEE and in the oracle's order.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rs_device.h"
+#include "../../include/rs_philox.h"
+#include "../../include/ranslice.h"
+
+namespace rs {
+
+__device__ __forceinline__ int bperm(int v, int src_lane) {
+    return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
+}
+__device__ __forceinline__ unsigned bperm(unsigned v, int src_lane) {
+    return (unsigned)__builtin_amdgcn_ds_bpermute(src_lane << 2, (int)v);
+}
+__device__ __forceinline__ double bperm(double v, int src_lane) {
+    uint64_t u = rs_d2u(v);
+    int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)u);
+    int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, (int)(uint32_t)(u >> 32));
+    return rs_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+__device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
+
+// ballot restricted to this lane's 32-lane group
+__device__ __forceinline__ unsigned group_ballot(bool c, int gshift) {
+    return (unsigned)(__builtin_amdgcn_ballot_w64(c) >> gshift);
+}
+
+template <class T>
+__device__ __forceinline__ T group_sum(T v, int lane) {
+#pragma unroll
+    for (int d = 1; d < RS_GROUP; d <<= 1) v += bperm(v, lane ^ d);
+    return v;
+}
+
+__device__ __forceinline__ double group_max(double v, int lane) {
+#pragma unroll
+    for (int d = 1; d < RS_GROUP; d <<= 1) {
+        double o = bperm(v, lane ^ d);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int group_excl_scan(int v, int lane, int gl) {
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < RS_GROUP; d <<= 1) {
+        int o = bperm(inc, lane - d);
+        if (gl >= d) inc += o;
+    }
+    return inc - v;
+}
+
+// index of the k-th (0-based) set bit of m, or 0 if there is none
+__device__ __forceinline__ int kth_set_bit(unsigned m, int k) {
+    for (int z = 0; z < k; ++z) m &= m - 1u;
+    return m ? __ffs((int)m) - 1 : 0;
+}
+
+// numpy pairwise sum of f(0..n-1) evaluated cooperatively by the 8 lanes of a subgroup
+// (lane j == strided accumulator j of numpy's unrolled loop).  Every lane of the subgroup
+// must call it with the same n; all return the same value.  n <= 256.
+template <class F>
+__device__ __forceinline__ double sub8_block(int off, int n, int j, int lane, F f) {
+    double res = 0.0;
+    int i0 = 0;
+    if (n >= 8) {
+        int lim = n - (n & 7);
+        double r = f(off + j);
+        for (int i = 8; i < lim; i += 8) r += f(off + i + j);
+        r += bperm(r, lane ^ 1);
+        r += bperm(r, lane ^ 2);
+        r += bperm(r, lane ^ 4);
+        res = r;
+        i0 = lim;
+    }
+    int rem = n - i0;
+    double v = j < rem ? f(off + i0 + j) : 0.0;
+    int base = lane & ~7;
+    for (int k = 0; k < rem; ++k) res += bperm(v, base + k);
+    return res;
+}
+
+template <class F>
+__device__ __forceinline__ double sub8_pairwise(int n, int j, int lane, F f) {
+    if (n <= 128) return sub8_block(0, n, j, lane, f);
+    int n2 = n >> 1;
+    n2 -= n2 & 7;
+    double a = sub8_block(0, n2, j, lane, f);
+    double b = sub8_block(n2, n - n2, j, lane, f);
+    return a + b;
+}
+
+// macro_cell (channel_models.py:84-97) on the UE's own stream
+__device__ __noinline__ double macro_cell_draw(const RsDev* D, rs_stream* st) {
+    double x, y;
+    for (;;) {
+        x = rs_stream_uniform(st);
+        y = rs_stream_uniform(st);
+        // generate_xy / find_y_value (channel_models.py:44-76), evaluated literally
+        double m, b;
+        m = (0.0 - 0.5) / (0.25 - 0.0); b = -m * 0.0 + 0.5;   bool c1 = y > m * x + b;
+        m = (0.5 - 0.0) / (1.0 - 0.75); b = -m * 0.75 + 0.0;  bool c2 = y > m * x + b;
+        m = (1.0 - 0.5) / (0.25 - 0.0); b = -m * 0.0 + 0.5;   bool c3 = y < m * x + b;
+        m = (0.5 - 1.0) / (1.0 - 0.75); b = -m * 0.75 + 1.0;  bool c4 = y < m * x + b;
+        if (c1 && c2 && c3 && c4) break;
+    }
+    double LogF = rs_stream_normal(st, 0.0, 10.0);
+    double x_t = x - 0.5 / 2;
+    double distance = RS_SQRT(x_t * x_t + y * y);
+    double cos_theta = x_t / distance;
+    double theta = rs_acos(cos_theta);
+    theta = theta * RS_RAD2DEG - 60;
+    double R = distance * 2 > 0.1 ? distance * 2 : 0.1;
+    double t65 = theta / 65;
+    double att = 12 * (t65 * t65);
+    double G = 15 + (-1 * (att < 20 ? att : 20));
+    double lr = rs_log10(R);
+    double L = D->prop_A + D->prop_B * lr;
+    double gamma = 2.6;
+    double FSPL = 20 * rs_log10(2.0) + 92.45 + gamma * 10 * lr;
+    L = L > FSPL ? L : FSPL;
+    double loss = L + LogF - G;
+    double Rx_pw = 30 - (loss > 70 ? loss : 70);
+    return Rx_pw - (-110) - 9;
+}
+
+__device__ __forceinline__ int rint_slots(double seconds_or_slots, double slot_length) {
+    // np.rint(x / slot_length) as a non-negative slot count, saturated far below RS_NEVER
+    double v = RS_RINT(seconds_or_slots / slot_length);
+    return v < 1.0e9 ? (int)v : 1000000000;
+}
+
+struct StepArgs {
+    const RsDev* D;
+    RsState S;
+    const double* fad;        // [trace][time][P]
+    const uint8_t* fad_valid; // [trace][time]
+    const int32_t* actions;   // [n_envs][n_slices]
+    int32_t clock0;           // slots elapsed since reset before this step
+    float* obs;               // [n_envs][n_vars]
+    int32_t* labels;          // [n_envs][n_slices]
+    int32_t* violations;      // [n_envs][n_slices]
+    double* info;             // [n_envs][n_slices][10]
+    uint64_t* counters;       // [n_tasks][4]
+    rs_alloc_rec* trace;      // [n_tasks][slots][RS_GROUP] or null
+};
+
+template <bool TRACE>
+__global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
+    const RsDev* __restrict__ D = A.D;
+    const RsState& S = A.S;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int gl = lane & 31;       // UE index owned by this lane
+    const int gbase = lane & 32;    // first lane of my group inside the wave
+    const int gshift = gbase;
+    const int sub = gl >> 3;        // 8-lane subgroup inside the group
+    const int j8 = gl & 7;
+    const int n_tasks = D->n_envs * D->n_embb;
+    int task = (int)blockIdx.x * (256 / RS_GROUP) + (int)(threadIdx.x >> 5);
+    const bool valid = task < n_tasks;
+    if (!valid) task = n_tasks - 1;
+    const int rep = task / D->n_embb;
+    const int sl = task - rep * D->n_embb;
+    const int n_slices = D->n_slices;
+    const int P = D->P;
+    const double slot_len = D->slot_length;
+    const double pf_a = D->pf_a, pf_b = D->pf_b;
+    const int gran = D->gran;
+
+    // set_prbs (node_b.py:71-74): contiguous ranges in slice order
+    int prb_lo = 0;
+    for (int q = 0; q < sl; ++q) prb_lo += A.actions[rep * n_slices + q];
+    int n_prb = A.actions[rep * n_slices + sl];
+    if (!valid) n_prb = 0;
+
+    // ---- load persistent state
+    int n_ue = valid ? S.t_n_ue[task] : 0;
+    int cbr_at = S.t_cbr_at[task];
+    int vbr_at = S.t_vbr_at[task];
+    uint32_t sl_ctr = S.t_ctr[task];
+    uint32_t next_serial = S.t_serial[task];
+    const uint64_t seed = S.seeds[rep];
+    const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+    int err = 0;
+
+    const int ui = task * RS_GROUP + gl;
+    bool active = gl < n_ue;
+    double queue = 0.0, th = 0.0, nominal = 0.0;
+    int hold_at = RS_NEVER, e_snr = 0, findex = 0, ue_bits = 0, ue_prbs = 0, uvbr_at = RS_NEVER, flags = 0;
+    uint32_t uctr = 0, userial = 0;
+    int burst[RS_BURSTS];
+#pragma unroll
+    for (int k = 0; k < RS_BURSTS; ++k) burst[k] = 0;
+    if (active) {
+        queue = S.u_queue[ui];
+        th = S.u_th[ui];
+        nominal = S.u_nominal[ui];
+        hold_at = S.u_hold_at[ui];
+        e_snr = S.u_e_snr[ui];
+        findex = S.u_findex[ui];
+        ue_bits = S.u_bits[ui];
+        ue_prbs = S.u_prbs[ui];
+        uvbr_at = S.u_vbr_at[ui];
+        uctr = S.u_ctr[ui];
+        userial = S.u_serial[ui];
+        flags = S.u_flags[ui];
+#pragma unroll
+        for (int k = 0; k < RS_BURSTS; ++k) burst[k] = S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl];
+    }
+
+    // per-step accumulators: lane k (<10) holds info[k] of this slice (slice_ran.py:270-273)
+    double infok = 0.0;
+    // per-UE running sums flushed into info[] by class: traffic, th(bits), prb
+    double acc_traffic = 0.0;
+    int acc_bits = 0, acc_prbs = 0;
+    uint64_t cnt_samples = 0, cnt_pf = 0, cnt_ue = 0;
+
+    auto flush = [&]() {
+        // SliceRANeMBB.update_info's three integer-valued sums (slice_ran.py:282-285,296-299):
+        // exact in f64 whatever the order, so they are accumulated per UE and folded here.
+        const bool is_vbr = (flags & 1) != 0;
+        double t_c = group_sum((active && !is_vbr) ? acc_traffic : 0.0, lane);
+        double t_v = group_sum((active && is_vbr) ? acc_traffic : 0.0, lane);
+        int b_c = group_sum((active && !is_vbr) ? acc_bits : 0, lane);
+        int b_v = group_sum((active && is_vbr) ? acc_bits : 0, lane);
+        int p_c = group_sum((active && !is_vbr) ? acc_prbs : 0, lane);
+        int p_v = group_sum((active && is_vbr) ? acc_prbs : 0, lane);
+        double add = 0.0;
+        add = gl == 0 ? t_c : add;
+        add = gl == 1 ? (double)b_c : add;
+        add = gl == 2 ? (double)p_c : add;
+        add = gl == 5 ? t_v : add;
+        add = gl == 6 ? (double)b_v : add;
+        add = gl == 7 ? (double)p_v : add;
+        infok += add;
+        acc_traffic = 0.0;
+        acc_bits = 0;
+        acc_prbs = 0;
+    };
+
+    const int slots = D->slots;
+    for (int t = 0; t < slots; ++t) {
+        const int now = A.clock0 + t + 1;
+        const int slot_counter = t + 1;
+
+        // ================= SliceRANeMBB.slot: arrivals (slice_ran.py:205-249)
+        const bool cbr_fire = valid && cbr_at == now;
+        const bool vbr_fire = valid && vbr_at == now;
+        if (wave_any(cbr_fire || vbr_fire)) {
+            int n_pend = 0;
+            int pend_type0 = 0, pend_type1 = 0;
+            if (wave_any(cbr_fire)) flush();  // cbr_cac reads this step's running sums
+            double i1 = bperm(infok, gbase + 1), i2 = bperm(infok, gbase + 2);
+            if (cbr_fire) {
+                rs_stream st = {key0, key1, (uint32_t)sl, 0u, sl_ctr};
+                double ia = rs_stream_exponential(&st, D->cbr_ia_scale);
+                sl_ctr = st.ctr;
+                cbr_at = now + 1 + rint_slots(ia, slot_len);
+                // cbr_cac (slice_ran.py:195-203)
+                int cslots = slot_counter > 1 ? slot_counter : 1;
+                double time = cslots * slot_len;
+                double c_prb = i2 / cslots;
+                double c_th = i1 / time;
+                if (!(c_prb >= D->sla[1] || c_th >= D->sla[0])) {
+                    pend_type0 = 0;
+                    n_pend = 1;
+                }
+            }
+            if (vbr_fire) {
+                rs_stream st = {key0, key1, (uint32_t)sl, 0u, sl_ctr};
+                double ia = rs_stream_exponential(&st, D->vbr_ia_scale);
+                sl_ctr = st.ctr;
+                vbr_at = now + 1 + rint_slots(ia, slot_len);
+                if (n_pend == 0) pend_type0 = 1; else pend_type1 = 1;
+                n_pend += 1;
+            }
+            if (n_ue + n_pend > RS_GROUP) {
+                err |= 1;  // RS_EOVERFLOW: UE capacity
+                n_pend = RS_GROUP - n_ue;
+            }
+            const bool is_new = gl >= n_ue && gl < n_ue + n_pend;
+            if (is_new) {
+                const int k = gl - n_ue;
+                const int type = k == 0 ? pend_type0 : pend_type1;
+                userial = next_serial + (uint32_t)k;
+                rs_stream st = {key0, key1, (uint32_t)sl, userial, 0u};
+                queue = 0.0; th = 0.0; e_snr = 0; ue_bits = 0; ue_prbs = 0;
+                acc_traffic = 0.0; acc_bits = 0; acc_prbs = 0;
+#pragma unroll
+                for (int q = 0; q < RS_BURSTS; ++q) burst[q] = 0;
+                uvbr_at = RS_NEVER;
+                if (type == 1) {  // VbrSource.__init__ (traffic_generators.py:62-68)
+                    int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
+                    uvbr_at = v >= 1 ? now + v - 1 : RS_NEVER;  // Q5: 0 never fires
+                }
+                double hold = rs_stream_exponential(&st, type == 0 ? D->cbr_hold_scale : D->vbr_hold_scale);
+                int hv = rint_slots(hold, slot_len);
+                hold_at = hv >= 1 ? now + hv - 1 : RS_NEVER;    // Q5
+                int ftype = 0, fstep = 1;
+                if (hold_at != now) {  // Q13: a one-slot holding time never joins the slice
+                    // SINRSelectiveFading.insert_user (channel_models.py:163-169)
+                    ftype = (int)rs_stream_integers(&st, RS_N_TRACES);
+                    findex = (int)rs_stream_integers(&st, D->T[ftype]);
+                    fstep = rs_stream_pm1(&st);
+                    nominal = macro_cell_draw(D, &st);
+                }
+                uctr = st.ctr;
+                flags = type | (ftype << 1) | ((fstep > 0 ? 1 : 0) << 3);
+                active = true;
+            }
+            n_ue += n_pend;
+            next_serial += (uint32_t)n_pend;
+        }
+
+        // ================= departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191)
+        const bool depart = active && hold_at == now;
+        if (wave_any(depart)) {
+            flush();
+            const unsigned keep = group_ballot(active && !depart, gshift);
+            const int n_new = __popc(keep);
+            const int src = gbase + kth_set_bit(keep, gl);
+            queue = bperm(queue, src);
+            th = bperm(th, src);
+            nominal = bperm(nominal, src);
+            hold_at = bperm(hold_at, src);
+            e_snr = bperm(e_snr, src);
+            findex = bperm(findex, src);
+            ue_bits = bperm(ue_bits, src);
+            ue_prbs = bperm(ue_prbs, src);
+            uvbr_at = bperm(uvbr_at, src);
+            uctr = bperm(uctr, src);
+            userial = bperm(userial, src);
+            flags = bperm(flags, src);
+#pragma unroll
+            for (int k = 0; k < RS_BURSTS; ++k) burst[k] = bperm(burst[k], src);
+            n_ue = n_new;
+            active = gl < n_ue;
+            if (!active) { hold_at = RS_NEVER; uvbr_at = RS_NEVER; userial = 0; }
+        }
+
+        const bool is_vbr = (flags & 1) != 0;
+
+        // ================= UE.traffic_step (slice_ran.py:47-49)
+        double new_bits = 0.0;
+        if (active) {
+            if (!is_vbr) {
+                new_bits = D->cbr_bits;
+            } else {
+                // VbrSource.step (traffic_generators.py:70-99) on absolute end times
+                int n_act = 0;
+#pragma unroll
+                for (int k = 0; k < RS_BURSTS; ++k) n_act += burst[k] > now ? 1 : 0;
+                new_bits = (double)n_act * D->vbr_p_size;
+                if (uvbr_at == now) {
+                    rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
+                    int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
+                    int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
+                    uctr = st.ctr;
+                    int endt = d >= 1 ? now + d : RS_NEVER;  // Q5: immortal burst
+                    bool placed = false;
+#pragma unroll
+                    for (int k = 0; k < RS_BURSTS; ++k) {
+                        if (!placed && burst[k] <= now) { burst[k] = endt; placed = true; }
+                    }
+                    if (!placed) err |= 2;  // RS_EOVERFLOW: burst capacity
+                    uvbr_at = v >= 1 ? now + v : RS_NEVER;
+                }
+            }
+            queue += new_bits;
+            acc_traffic += new_bits;
+        }
+        const bool any_queue = group_ballot(active && queue > 0.0, gshift) != 0u;
+
+        // ================= channel: get_snr + estimate_snr (channel_models.py:171-191, slice_ran.py:43-45)
+        int col = 0;  // element offset of this UE's fading column
+        if (n_prb > 0) {
+            if (active) {
+                const int ftype = (flags >> 1) & 3;
+                int fstep = (flags & 8) ? 1 : -1;
+                const int Tn = D->T[ftype];
+                for (;;) {
+                    findex += fstep;
+                    if (findex >= Tn || findex < 0) {
+                        rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
+                        findex = (int)rs_stream_integers(&st, Tn);
+                        fstep = rs_stream_pm1(&st);
+                        uctr = st.ctr;
+                    }
+                    if (!D->has_nan || A.fad_valid[D->valid_off[ftype] + findex]) break;  // Q10
+                }
+                flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
+                col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
+            }
+            // four UEs per group at a time, one per 8-lane subgroup
+            for (int rho = 0; wave_any(rho * 4 < n_ue); ++rho) {
+                const int k = rho * 4 + sub;
+                const bool have = k < n_ue;
+                const int srcl = gbase + (have ? k : 0);
+                const int c_col = bperm(col, srcl);
+                const double c_nom = bperm(nominal, srcl);
+                int es = 0;
+                if (have) {
+                    const double* __restrict__ base = A.fad + c_col + prb_lo;
+                    double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return base[i] + c_nom; });
+                    es = (int)RS_RINT(sum / (double)n_prb);  // round(np.mean(...)): half-to-even (Q7)
+                }
+                const int got = bperm(es, gbase + ((gl & 3) << 3));
+                if (active && (gl >> 2) == rho) e_snr = got;
+            }
+            cnt_samples += (uint64_t)n_ue * (uint64_t)n_prb;
+        }
+        cnt_ue += (uint64_t)n_ue;
+
+        // ================= scheduling (slice_l1.py:215-224)
+        const bool sched = valid && any_queue && n_prb > 0;
+        double p_rx = 0.0;
+        if (wave_any(sched)) {
+            // ---- ProportionalFair.allocate (schedulers.py:21-76)
+            int li = e_snr - D->lut_lo;
+            li = li < 0 ? 0 : (li >= D->lut_n ? D->lut_n - 1 : li);
+            const int mcs = D->lut_mcs[li];
+            const int rate = D->lut_rate[li];
+            const double rate_d = (double)rate;
+            int q = active ? (int)(queue < 1073741824.0 ? queue : 1073741824.0) : 0;
+            double thl = th > 1.0 ? th : 1.0;
+            int rbs = 0, bits = 0;
+            double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
+            int r = 0;
+            for (;;) {
+                const bool more = sched && r < n_prb;
+                if (!wave_any(more)) break;
+                const double mx = group_max(m, lane);
+                const unsigned eq = group_ballot(m == mx, gshift);
+                const int idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                if (more) {
+                    if (mx == 0.0) {
+                        // every queue is empty: argmax of an all-zero metric is UE 0 for all the
+                        // remaining RB pairs (Q4); its local th is discarded afterwards
+                        if (gl == 0) rbs += n_prb - r;
+                        r = n_prb;
+                    } else {
+                        const int prbs = n_prb - r < gran ? n_prb - r : gran;
+                        if (gl == idx) {
+                            rbs += prbs;
+                            int tx = prbs * rate < q ? prbs * rate : q;
+                            q -= tx;
+                            bits += tx;
+                            thl = pf_a * thl + pf_b * (double)bits / slot_len;
+                            m = (q > 0 ? rate_d : 0.0) / thl;
+                        }
+                        r += gran;
+                    }
+                }
+            }
+            // RBs are laid out contiguously in UE order (schedulers.py:66-76)
+            const int prb_i = group_excl_scan(rbs, lane, gl);
+            const unsigned smask = group_ballot(sched && active && rbs > 0, gshift);
+            const int nsched = __popc(smask);
+            const int my_rank = __popc(smask & ((1u << gl) - 1u));
+            // ---- MCSCodeset.response (channel_models.py:297-313), one scheduled UE per subgroup
+            for (int rho = 0; wave_any(rho * 4 < nsched); ++rho) {
+                const int k = rho * 4 + sub;
+                const bool have = k < nsched;
+                const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
+                const int c_rbs = bperm(rbs, srcl);
+                const int c_off = bperm(col + prb_i, srcl);
+                const int c_mcs = bperm(mcs, srcl);
+                const double c_nom = bperm(nominal, srcl);
+                double pv = 0.0;
+                if (have) {
+                    const double* __restrict__ base = A.fad + c_off + prb_lo;
+                    const double x0 = D->mcs_x0[c_mcs], kk = D->mcs_k[c_mcs];
+                    double s;
+                    if (c_rbs > 1) {
+                        double sum = sub8_pairwise(c_rbs, j8, lane,
+                                                   [&](int i) { return rs_sigmoid(base[i] + c_nom, x0, kk); });
+                        double avg = sum / (double)c_rbs;
+                        s = rs_inv_sigmoid(avg, x0, kk);
+                    } else {
+                        s = base[0] + c_nom;
+                    }
+                    double x = D->mcsA * (s - D->mcs_ref[c_mcs]) - D->mcsB;
+                    pv = rs_sigmoid(x, 0.0, 1.0);
+                }
+                const double got = bperm(pv, gbase + ((my_rank & 3) << 3));
+                if (sched && active && rbs > 0 && (my_rank >> 2) == rho) p_rx = got;
+            }
+            // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
+            if (sched && active) {
+                bool received = false;
+                if (rbs > 0) {
+                    rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
+                    received = rs_stream_uniform(&st) < p_rx;
+                    uctr = st.ctr;
+                }
+                if (!received) bits = 0;
+                double nq = queue - (double)bits;
+                queue = nq > 0.0 ? nq : 0.0;
+                th = pf_a * th + pf_b * (double)bits / slot_len;
+                ue_bits = bits;
+                ue_prbs = rbs;
+            }
+            if (sched) cnt_pf += (uint64_t)((n_prb + gran - 1) / gran);
+        }
+
+        // ================= SliceRANeMBB.update_info (slice_ran.py:278-305); Q2: stale bits/prbs count
+        if (active) {
+            acc_bits += ue_bits;
+            acc_prbs += ue_prbs;
+        }
+        {
+            const unsigned m_c = group_ballot(active && !is_vbr, gshift);
+            const unsigned m_v = group_ballot(active && is_vbr, gshift);
+            int n_c = __popc(m_c), n_v = __popc(m_v);
+            n_c = n_c > 1 ? n_c : 1;
+            n_v = n_v > 1 ? n_v : 1;
+            double q_c = 0.0, q_v = 0.0;
+            if (wave_any(active && queue != 0.0)) {
+                q_c = group_sum((active && !is_vbr) ? queue : 0.0, lane);
+                q_v = group_sum((active && is_vbr) ? queue : 0.0, lane);
+            }
+            // both e_snr sums in one integer reduction: |sum| < 2^15 per class
+            int packed = active ? (is_vbr ? e_snr * 65536 : e_snr) : 0;
+            packed = group_sum(packed, lane);
+            int s_c = (int)(int16_t)(packed & 0xffff);
+            int s_v = (packed - s_c) >> 16;
+            double add = 0.0;
+            add = gl == 3 ? q_c / n_c : add;
+            add = gl == 4 ? (double)s_c / n_c : add;
+            add = gl == 8 ? q_v / n_v : add;
+            add = gl == 9 ? (double)s_v / n_v : add;
+            infok += add;
+        }
+
+        if (TRACE) {
+            if (valid) {
+                rs_alloc_rec rec;
+                rec.serial = active ? (int32_t)userial : 0;
+                rec.type = active ? (flags & 1) : 0;
+                rec.e_snr = active ? e_snr : 0;
+                rec.prbs = active ? ue_prbs : 0;
+                rec.bits = active ? (int64_t)ue_bits : 0;
+                rec.queue = active ? queue : 0.0;
+                rec.th = active ? th : 0.0;
+                rec.p = (active && sched) ? p_rx : 0.0;
+                A.trace[((size_t)task * slots + t) * RS_GROUP + gl] = rec;
+            }
+        }
+    }
+    flush();
+
+    // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)
+    const double i1 = bperm(infok, gbase + 1), i2 = bperm(infok, gbase + 2), i3 = bperm(infok, gbase + 3);
+    const double i6 = bperm(infok, gbase + 6), i7 = bperm(infok, gbase + 7), i8 = bperm(infok, gbase + 8);
+    if (valid) {
+        if (gl < RS_N_EMBB_VARS) {
+            A.obs[(size_t)rep * D->n_vars + sl * RS_N_EMBB_VARS + gl] = (float)(infok / D->norm[gl]);
+            A.info[((size_t)rep * n_slices + sl) * 10 + gl] = infok;
+        }
+        if (gl == 0) {
+            const double obs_time = slots * slot_len;
+            bool cbr_ok = (i1 / obs_time > D->sla[0]) || (i2 / slots > D->sla[1]) || (i3 / slots < D->sla[2]);
+            bool vbr_ok = (i6 / obs_time > D->sla[3]) || (i7 / slots > D->sla[4]) || (i8 / slots < D->sla[5]);
+            int viol = !(cbr_ok && vbr_ok);
+            A.violations[rep * n_slices + sl] = viol;
+            A.labels[rep * n_slices + sl] = viol == 0 ? 1 : -1;
+            S.t_n_ue[task] = n_ue;
+            S.t_cbr_at[task] = cbr_at;
+            S.t_vbr_at[task] = vbr_at;
+            S.t_ctr[task] = sl_ctr;
+            S.t_serial[task] = next_serial;
+            uint64_t* c = A.counters + (size_t)task * 4;
+            c[0] += cnt_samples;
+            c[2] += cnt_pf;
+            c[3] += cnt_ue;
+        }
+        const unsigned e = group_ballot(err != 0, gshift);
+        if (gl == 0 && (e != 0u || err != 0)) atomicOr(&S.err[rep], 1);
+        if (active) {
+            S.u_queue[ui] = queue;
+            S.u_th[ui] = th;
+            S.u_nominal[ui] = nominal;
+            S.u_hold_at[ui] = hold_at;
+            S.u_e_snr[ui] = e_snr;
+            S.u_findex[ui] = findex;
+            S.u_bits[ui] = ue_bits;
+            S.u_prbs[ui] = ue_prbs;
+            S.u_vbr_at[ui] = uvbr_at;
+            S.u_ctr[ui] = uctr;
+            S.u_serial[ui] = userial;
+            S.u_flags[ui] = flags;
+#pragma unroll
+            for (int k = 0; k < RS_BURSTS; ++k) S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = burst[k];
+        }
+    } else {
+        (void)group_ballot(err != 0, gshift);
+    }
+}
+
+}  // namespace rs

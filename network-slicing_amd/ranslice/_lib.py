@@ -1,0 +1,64 @@
+"""ctypes binding of libranslice.so (include/ranslice.h).  Fails loudly when the HIP library is
+missing or no GPU is usable: there is NO CPU fallback in the product path."""
+import ctypes as C
+import os
+
+from .config import RsConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libranslice.so')
+
+RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
+
+EXPORTS = (
+    'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
+    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_kernel_time_ms',
+    'rs_set_kernel_timing', 'rs_synchronize', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
+)
+
+
+class RanSliceError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__('libranslice error %d: %s' % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libranslice.so; raises if it has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError('libranslice.so not found at %s: build it with `make -C network-slicing_amd/csrc` '
+                          '(hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+    L.rs_create.argtypes = [C.POINTER(RsConfig), C.c_int, C.POINTER(vp)]
+    L.rs_load_fading.argtypes = [vp, C.c_int, dp, C.c_int, C.c_int]
+    L.rs_reset.argtypes = [vp, up, fp]
+    L.rs_step.argtypes = [vp, ip, fp, dp, ip, ip]
+    L.rs_step_resident.argtypes = [vp]
+    L.rs_random_actions.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.rs_fetch.argtypes = [vp, ip, fp, dp, ip, ip]
+    L.rs_get_info.argtypes = [vp, dp]
+    L.rs_set_alloc_trace.argtypes = [vp, C.c_int]
+    L.rs_get_alloc_trace.argtypes = [vp, vp]
+    L.rs_get_counters.argtypes = [vp, up]
+    L.rs_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.rs_set_kernel_timing.argtypes = [vp, C.c_int]
+    L.rs_synchronize.argtypes = [vp]
+    L.rs_n_vars.argtypes = [vp]
+    L.rs_n_slices.argtypes = [vp]
+    L.rs_last_error.argtypes = [vp]
+    L.rs_last_error.restype = C.c_char_p
+    L.rs_destroy.argtypes = [vp]
+    L.rs_destroy.restype = None
+    for name in EXPORTS:
+        if name not in ('rs_last_error', 'rs_destroy'):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L

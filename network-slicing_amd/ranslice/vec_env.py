@@ -1,0 +1,132 @@
+"""VecRanSlice: N independent RanSlice environments advanced together on one MI355X.
+
+This is the batched form of the reference's gym surface (reference
+gym-ran_slice/gym_ran_slice/ran_slice.py:15-54): `reset()` and `step(actions)` with a leading
+replica axis.  `gym_ran_slice.RanSlice` is its N=1 view.  All simulation runs in the HIP kernels
+behind libranslice.so; this module only moves numpy buffers across the C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import RsAllocRec, make_config, n_vars
+from .fading import synth_fading
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint64)
+
+
+def default_fading(n_cols=10000, seed=20240):
+    """The build's seeded stand-in for the three absent ns-3 traces."""
+    return [synth_fading(t, n_cols, seed=seed) for t in range(3)]
+
+
+class VecRanSlice:
+    def __init__(self, n_envs=1, scenario=0, seed=0, device=0, fading=None, cfg=None, **cfg_kw):
+        self.L = _lib.load()
+        self.cfg = cfg if cfg is not None else make_config(scenario, n_envs=n_envs, **cfg_kw)
+        self.cfg.n_envs = n_envs
+        self.n_envs = n_envs
+        self.n_slices = self.cfg.n_embb + self.cfg.n_mmtc
+        self.n_variables = n_vars(self.cfg)
+        self.n_prbs = self.cfg.n_prbs
+        self.penalty = self.cfg.penalty
+        self.h = C.c_void_p()
+        rc = self.L.rs_create(C.byref(self.cfg), int(device), C.byref(self.h))
+        self._check(rc)
+        if self.cfg.n_embb > 0:
+            if fading is None:
+                fading = default_fading()
+            for t, tab in enumerate(fading):
+                tab = np.ascontiguousarray(tab, dtype=np.float64)
+                self._check(self.L.rs_load_fading(self.h, t, tab.ctypes.data_as(_dp), tab.shape[0], tab.shape[1]))
+        self.base_seed = int(seed)
+        self._obs = np.zeros((n_envs, self.n_variables), dtype=np.float32)
+        self._reward = np.zeros(n_envs, dtype=np.float64)
+        self._labels = np.zeros((n_envs, self.n_slices), dtype=np.int32)
+        self._viol = np.zeros((n_envs, self.n_slices), dtype=np.int32)
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.rs_last_error(self.h).decode() if self.h else 'rs_create failed'
+            raise _lib.RanSliceError(rc, msg)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.rs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- gym-like surface -------------------------------------------------------------
+    def reset(self, seeds=None):
+        """seeds: per-replica 64-bit stream seeds; default base_seed + replica index
+        (the reference seeds run i with default_rng(seed=i), experiments_kbrl.py:46)."""
+        if seeds is None:
+            seeds = self.base_seed + np.arange(self.n_envs, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        assert seeds.shape == (self.n_envs,)
+        self._check(self.L.rs_reset(self.h, seeds.ctypes.data_as(_up), self._obs.ctypes.data_as(_fp)))
+        return self._obs.copy()
+
+    def step(self, actions):
+        actions = np.ascontiguousarray(actions, dtype=np.int32).reshape(self.n_envs, self.n_slices)
+        self._check(self.L.rs_step(self.h, actions.ctypes.data_as(_ip), self._obs.ctypes.data_as(_fp),
+                                   self._reward.ctypes.data_as(_dp), self._labels.ctypes.data_as(_ip),
+                                   self._viol.ctypes.data_as(_ip)))
+        info = {'SLA_labels': self._labels.copy(), 'violations': self._viol.copy(),
+                'total_violations': self._viol.sum(axis=1), 'n_prbs': actions.copy()}
+        return self._obs.copy(), self._reward.copy(), np.zeros(self.n_envs, dtype=bool), info
+
+    # ---- device-resident path (bench) --------------------------------------------------
+    def random_actions(self, seed, step_index):
+        self._check(self.L.rs_random_actions(self.h, int(seed), int(step_index)))
+
+    def step_resident(self):
+        self._check(self.L.rs_step_resident(self.h))
+
+    def fetch(self):
+        actions = np.zeros((self.n_envs, self.n_slices), dtype=np.int32)
+        self._check(self.L.rs_fetch(self.h, actions.ctypes.data_as(_ip), self._obs.ctypes.data_as(_fp),
+                                    self._reward.ctypes.data_as(_dp), self._labels.ctypes.data_as(_ip),
+                                    self._viol.ctypes.data_as(_ip)))
+        return dict(actions=actions, obs=self._obs.copy(), reward=self._reward.copy(),
+                    labels=self._labels.copy(), violations=self._viol.copy())
+
+    def synchronize(self):
+        self._check(self.L.rs_synchronize(self.h))
+
+    # ---- introspection ------------------------------------------------------------------
+    def l1_info(self):
+        info = np.zeros((self.n_envs, self.n_slices, 10), dtype=np.float64)
+        self._check(self.L.rs_get_info(self.h, info.ctypes.data_as(_dp)))
+        return info
+
+    def set_alloc_trace(self, enable=True):
+        self._check(self.L.rs_set_alloc_trace(self.h, int(bool(enable))))
+
+    def alloc_trace(self):
+        tr = np.zeros((self.n_envs, self.cfg.n_embb, self.cfg.slots_per_step, 32), dtype=np.dtype(RsAllocRec))
+        self._check(self.L.rs_get_alloc_trace(self.h, tr.ctypes.data_as(C.c_void_p)))
+        return tr
+
+    def counters(self):
+        c = (C.c_uint64 * 4)()
+        self._check(self.L.rs_get_counters(self.h, c))
+        return [int(x) for x in c]
+
+    def set_kernel_timing(self, enable=True):
+        self._check(self.L.rs_set_kernel_timing(self.h, int(bool(enable))))
+
+    def kernel_time_ms(self):
+        ms = C.c_double()
+        n = C.c_int64()
+        self._check(self.L.rs_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value

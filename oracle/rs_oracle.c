@@ -608,7 +608,8 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
     }
 
     /* ---- scheduling and transmission (slice_l1.py:215-224); Q2: skipped -> stale bits/prbs */
-    if (queued_data > 0 && e->n_prbs > 0) {
+    int scheduled = queued_data > 0 && e->n_prbs > 0;
+    if (scheduled) {
         pf_allocate(o, c, o->mcsA, o->mcsB, e->n_ue, ptr, col, e->prb_lo, e->n_prbs);
         double b = 1.0 / c->pf_window, a = 1 - b; /* UE.__init__: b = 1/window, a = 1-b */
         for (int i = 0; i < e->n_ue; ++i) {
@@ -656,7 +657,7 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
             r->bits = u->bits;
             r->queue = u->queue;
             r->th = u->th;
-            r->p = u->p;
+            r->p = scheduled ? u->p : 0.0; /* this slot's allocation only */
         }
     }
 }

@@ -1,0 +1,158 @@
+"""GPU parity: the HIP simulator (through the C ABI, via VecRanSlice) against the CPU oracle on the
+same Philox streams.  Everything is compared bit-for-bit: observations (f32 bits), rewards, SLA
+labels, violation counts, the ten info accumulators per slice (f64 bits) and -- with allocation
+tracing on -- every UE's e_snr / RBs / bits / queue / throughput / reception probability in every
+slot.  No tolerance anywhere: both sides use include/rs_detmath.h and IEEE arithmetic in the
+same order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from ranslice.config import make_config
+from ranslice.fading import synth_fading
+
+pytestmark = pytest.mark.gpu
+
+
+def _small_fading(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    return [g['t0'], g['t1'], g['t2']]
+
+
+def _churn(cfg):
+    cfg.cbr_lambda, cfg.cbr_t_mean = 2.0 / 1.2, 0.6
+    cfg.vbr_lambda, cfg.vbr_t_mean = 5.0 / 1.2, 0.6
+    cfg.vbr_b_size, cfg.vbr_b_rate = 40, 12
+    return cfg
+
+
+def _actions(rng, n_envs, n_slices, n_prbs, step):
+    mode = step % 6
+    if mode == 0:
+        a = rng.multinomial(n_prbs, [1.0 / n_slices] * n_slices, size=n_envs)
+    elif mode == 2:
+        a = rng.multinomial(n_prbs // 2, [1.0 / n_slices] * n_slices, size=n_envs)
+        a[np.arange(n_envs), rng.integers(n_slices, size=n_envs)] = 0
+    elif mode == 4:
+        a = rng.integers(0, 4, size=(n_envs, n_slices))
+    else:
+        a = rng.multinomial(n_prbs, [1.0 / (n_slices + 1)] * (n_slices + 1), size=n_envs)[:, :n_slices]
+    return a.astype(np.int32)
+
+
+def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None):
+    from ranslice.vec_env import VecRanSlice
+    cfg = make_config(scenario, n_envs=n_envs)
+    if churn:
+        _churn(cfg)
+    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, seed=seed0)
+    if check_trace:
+        env.set_alloc_trace(True)
+    obs0 = env.reset()
+    assert not obs0.any()
+    reps = list(range(n_envs)) if sample is None else list(sample)
+    ocfg = make_config(scenario, n_envs=1)
+    if churn:
+        _churn(ocfg)
+    oracles = []
+    for r in reps:
+        o = po.OracleEnv(ocfg, fading)
+        o.set_seed(seed0 + r)
+        o.reset()
+        oracles.append(o)
+    rng = np.random.default_rng(99 + scenario)
+    n_slices = cfg.n_embb + cfg.n_mmtc
+    for i in range(steps):
+        acts = _actions(rng, n_envs, n_slices, cfg.n_prbs, i)
+        obs, rew, done, info = env.step(acts)
+        l1 = env.l1_info()
+        tr = env.alloc_trace() if check_trace else None
+        for k, r in enumerate(reps):
+            out = oracles[k].step(acts[r], trace=check_trace)
+            assert obs[r].tobytes() == out['obs'].tobytes(), 'obs bits differ: step %d replica %d' % (i, r)
+            assert rew[r] == out['reward']
+            assert (info['SLA_labels'][r] == out['labels']).all()
+            assert (info['violations'][r] == out['violations']).all()
+            assert l1[r].tobytes() == out['info'].tobytes(), 'info differs: step %d replica %d' % (i, r)
+            if check_trace and cfg.n_embb:
+                a, b = tr[r], out['trace']
+                for f in ('serial', 'type', 'e_snr', 'prbs', 'bits'):
+                    assert (a[f] == b[f]).all(), '%s differs: step %d replica %d' % (f, i, r)
+                for f in ('queue', 'th', 'p'):
+                    assert a[f].tobytes() == b[f].tobytes(), '%s bits differ: step %d replica %d' % (f, i, r)
+    c = env.counters()
+    if sample is None:
+        tot = np.sum([o.counters() for o in oracles], axis=0)
+        assert c[0] == tot[0] and c[2] == tot[2] and c[3] == tot[3], (c, tot)
+    env.close()
+
+
+def test_scenario0_small_trace(golden_dir):
+    _compare(0, n_envs=24, steps=8, fading=_small_fading(golden_dir), churn=False, seed0=1)
+
+
+def test_scenario0_churn(golden_dir):
+    """arrivals, admission control, departures, compaction, VBR bursts all fire within a few steps"""
+    _compare(0, n_envs=40, steps=30, fading=_small_fading(golden_dir), churn=True, seed0=1000)
+
+
+@pytest.mark.parametrize('scenario', [1, 2, 3])
+def test_mixed_scenarios(golden_dir, scenario):
+    _compare(scenario, n_envs=16, steps=25, fading=_small_fading(golden_dir), churn=True, seed0=5)
+
+
+def test_ragged_batch(golden_dir):
+    """n_envs not a multiple of the 8 tasks per block, single replica"""
+    _compare(0, n_envs=1, steps=4, fading=_small_fading(golden_dir), churn=True, seed0=77)
+    _compare(1, n_envs=3, steps=4, fading=_small_fading(golden_dir), churn=True, seed0=78)
+
+
+def test_full_size_sampled():
+    """BASELINE config 2 shape: 4096 replicas, 10,000-sample traces; oracle follows a sample."""
+    fading = [synth_fading(t, 10000) for t in range(3)]
+    sample = [0, 1, 7, 8, 63, 64, 1000, 2047, 2048, 4095]
+    _compare(0, n_envs=4096, steps=12, fading=fading, churn=False, seed0=0, check_trace=False, sample=sample)
+
+
+def test_determinism_and_independence(golden_dir):
+    """same seeds -> identical results; a replica's trajectory does not depend on its batch"""
+    from ranslice.vec_env import VecRanSlice
+    fading = _small_fading(golden_dir)
+    rng = np.random.default_rng(3)
+    acts = [_actions(rng, 64, 5, 200, i) for i in range(6)]
+
+    def run(n_envs, seeds, rows):
+        env = VecRanSlice(n_envs=n_envs, cfg=_churn(make_config(0, n_envs=n_envs)), fading=fading)
+        env.reset(seeds=seeds)
+        outs = []
+        for a in acts:
+            o, r, _, inf = env.step(a[rows])
+            outs.append((o.copy(), r.copy(), inf['violations'].copy()))
+        env.close()
+        return outs
+    seeds = np.arange(64, dtype=np.uint64) + 10
+    a = run(64, seeds, np.arange(64))
+    b = run(64, seeds, np.arange(64))
+    rows = np.array([5, 17, 63])
+    c = run(3, seeds[rows], rows)
+    for (o1, r1, v1), (o2, r2, v2), (o3, r3, v3) in zip(a, b, c):
+        assert o1.tobytes() == o2.tobytes() and (r1 == r2).all() and (v1 == v2).all()
+        assert o1[rows].tobytes() == o3.tobytes() and (r1[rows] == r3).all() and (v1[rows] == v3).all()
+
+
+def test_action_validation(golden_dir):
+    from ranslice import _lib
+    from ranslice.vec_env import VecRanSlice
+    env = VecRanSlice(n_envs=2, scenario=0, fading=_small_fading(golden_dir))
+    env.reset()
+    bad = np.full((2, 5), 50, dtype=np.int32)  # sums to 250 > 200 (reference Q9)
+    with pytest.raises(_lib.RanSliceError):
+        env.step(bad)
+    neg = np.zeros((2, 5), dtype=np.int32)
+    neg[0, 0] = -1
+    with pytest.raises(_lib.RanSliceError):
+        env.step(neg)
+    env.close()
