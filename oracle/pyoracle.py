@@ -54,6 +54,8 @@ def lib():
         L.rso_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.rso_max_ue.argtypes = [C.c_void_p]
         L.rso_random_actions.argtypes = [C.POINTER(RsConfig), C.c_uint64, C.c_uint64, C.c_int64, _ip]
+        L.rso_bench_run.restype = C.c_double
+        L.rso_bench_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int64]
         L.rso_mcs_factors.argtypes = [_dp, _dp]
         L.rso_mcs_lookup.argtypes = [C.POINTER(RsConfig), C.c_int, _ip, _ip]
         L.rso_response.restype = C.c_double
@@ -141,6 +143,9 @@ class OracleEnv:
         if trace:
             out['trace'] = tr
         return out
+
+    def bench_run(self, action_seed, replica, step0, n_steps):
+        return self.L.rso_bench_run(self.h, int(action_seed), int(replica), int(step0), int(n_steps))
 
     def counters(self):
         c = (C.c_uint64 * 4)()

@@ -927,6 +927,21 @@ void rso_random_actions(const rs_config* cfg, uint64_t seed, uint64_t step_index
     }
 }
 
+/* cpu_baseline leg of bench.py: n_steps of the bench workload (random action script) for one
+ * replica, entirely in C.  Returns the sum of rewards as a checksum. */
+double rso_bench_run(rs_oracle* o, uint64_t action_seed, int64_t replica, uint64_t step0, int64_t n_steps) {
+    int32_t action[64];
+    float obs[1024];
+    int32_t labels[64], viol[64];
+    double reward = 0, acc = 0;
+    for (int64_t i = 0; i < n_steps; ++i) {
+        rso_random_actions(&o->cfg, action_seed, step0 + (uint64_t)i, replica, action);
+        if (rso_step(o, action, obs, &reward, labels, viol, NULL, NULL) != 0) return NAN;
+        acc += reward;
+    }
+    return acc;
+}
+
 double rso_exp(double x) { return rs_exp(x); }
 double rso_log(double x) { return rs_log(x); }
 double rso_acos(double x) { return rs_acos(x); }

@@ -53,6 +53,8 @@ int rso_max_ue(const rs_oracle* o);
 void rso_random_actions(const rs_config* cfg, uint64_t seed, uint64_t step_index, int64_t replica,
                         int32_t* action);
 
+double rso_bench_run(rs_oracle* o, uint64_t action_seed, int64_t replica, uint64_t step0, int64_t n_steps);
+
 /* ---- unit entry points used to pin individual pieces (fixtures G1-G6) ---- */
 void rso_mcs_factors(double* A, double* B);
 void rso_mcs_lookup(const rs_config* cfg, int e_snr, int* mcs, int* rate);

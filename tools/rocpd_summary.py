@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 rocpd SQLite database (kernel trace, optionally PMC counters) as text.
+usage: python tools/rocpd_summary.py <results.db> [> profiles/<name>.txt]"""
+import sqlite3
+import sys
+
+
+def main(path):
+    c = sqlite3.connect(path)
+    cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+    rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
+                     "from kernels group by name order by 3 desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    print('# kernel trace summary of %s' % path)
+    print('%-60s %8s %14s %12s %12s %12s %7s' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'pct'))
+    for n, k, t, a, mn, mx in rows:
+        print('%-60s %8d %14d %12.0f %12d %12d %6.2f%%' % (n[:60], k, t, a, mn, mx, 100.0 * t / tot))
+    extra = [x for x in ('vgpr_count', 'accum_vgpr_count', 'sgpr_count', 'lds_size', 'scratch_size', 'workgroup_size', 'grid_size') if x in cols]
+    if extra:
+        print('\n# per-kernel resources (%s)' % ', '.join(extra))
+        for r in c.execute("select distinct name, %s from kernels" % ', '.join(extra)):
+            print('  ', r)
+    try:
+        pm = c.execute("select k.name, p.counter_name, avg(p.value), sum(p.value), count(*) from pmc_events p "
+                       "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+    except sqlite3.Error as e:
+        pm = []
+        print('\n# no PMC data (%s)' % e)
+    if pm:
+        print('\n# PMC counters: kernel, counter, mean per dispatch, sum, dispatches')
+        for r in pm:
+            print('   %-48s %-28s %16.1f %18.1f %6d' % (r[0][:48], r[1], r[2], r[3], r[4]))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1])
