@@ -208,3 +208,138 @@ def macro_cell(cfg, uv, normal):
     used = C.c_int32()
     v = lib().rso_macro_cell(C.byref(cfg), _p(uv, _dp), len(uv), float(normal), C.byref(used))
     return v, used.value
+
+
+# ----------------------------------------------------------------------------- KBRL oracle
+def _kb_lib():
+    L = lib()
+    if not getattr(L, '_kb_ready', False):
+        L.kbo_create.restype = C.c_void_p
+        L.kbo_create.argtypes = [C.c_int, _ip, C.c_int, C.c_double, C.c_double, C.c_double, _ip, _ip, C.c_double,
+                                 C.c_double, C.c_int]
+        L.kbo_destroy.argtypes = [C.c_void_p]
+        L.kbo_set_tape.argtypes = [C.c_void_p, _dp, C.c_int64]
+        L.kbo_set_seed.argtypes = [C.c_void_p, C.c_uint64]
+        L.kbo_tape_pos.restype = C.c_int64
+        L.kbo_tape_pos.argtypes = [C.c_void_p]
+        L.kbo_predict.argtypes = [C.c_void_p, C.c_int, _dp, _dp]
+        L.kbo_update.argtypes = [C.c_void_p, C.c_int, _dp, C.c_int, _dp]
+        L.kbo_set_size.argtypes = [C.c_void_p, C.c_int]
+        L.kbo_m.argtypes = [C.c_void_p, C.c_int]
+        for f in ('kbo_coeff', 'kbo_landmarks'):
+            getattr(L, f).restype = _dp
+            getattr(L, f).argtypes = [C.c_void_p, C.c_int]
+        L.kbo_kinv.restype = _dp
+        L.kbo_kinv.argtypes = [C.c_void_p, C.c_int, _ip]
+        L.kbo_select_action.argtypes = [C.c_void_p, C.POINTER(C.c_float), _ip]
+        L.kbo_update_control.argtypes = [C.c_void_p, C.POINTER(C.c_float), _ip, _ip, C.c_int, _ip]
+        L.kbo_margins.restype = _ip
+        L.kbo_margins.argtypes = [C.c_void_p]
+        L.kbo_security_factors.restype = _ip
+        L.kbo_security_factors.argtypes = [C.c_void_p]
+        L.kbo_accuracies.restype = _dp
+        L.kbo_accuracies.argtypes = [C.c_void_p]
+        L.kbo_n_predict.restype = C.c_int64
+        L.kbo_n_predict.argtypes = [C.c_void_p]
+        L.kbo_n_mistakes.restype = C.c_int64
+        L.kbo_n_mistakes.argtypes = [C.c_void_p]
+        L.kbo_error.argtypes = [C.c_void_p]
+        L._kb_ready = True
+    return L
+
+
+class OracleKBRL:
+    """The reference's KBRL_Control (one agent) restated in C."""
+
+    def __init__(self, dims, n_prbs, initial_action, security_factor, alfa=0.05, accuracy_range=(0.99, 0.999),
+                 gamma=1.0, eta=0.1, capacity=1024):
+        self.L = _kb_lib()
+        self.dims = np.ascontiguousarray(dims, dtype=np.int32)
+        self.S = len(self.dims)
+        self.n_prbs = n_prbs
+        ia = np.ascontiguousarray(initial_action, dtype=np.int32)
+        sf = np.ascontiguousarray(security_factor, dtype=np.int32)
+        self.cap = capacity
+        self.h = self.L.kbo_create(self.S, _p(self.dims, _ip), n_prbs, alfa, accuracy_range[0], accuracy_range[1],
+                                   _p(ia, _ip), _p(sf, _ip), gamma, eta, capacity)
+        self.action = ia.copy()
+        self.adjusted = 0
+        self._keep = None
+
+    def __del__(self):
+        if getattr(self, 'h', None):
+            self.L.kbo_destroy(self.h)
+            self.h = None
+
+    def set_tape(self, val):
+        val = np.ascontiguousarray(val, dtype=np.float64)
+        self._keep = val
+        self.L.kbo_set_tape(self.h, _p(val, _dp), len(val))
+
+    def set_seed(self, seed):
+        self.L.kbo_set_seed(self.h, int(seed))
+
+    def predict(self, s, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        f = C.c_double()
+        y = self.L.kbo_predict(self.h, s, _p(x, _dp), C.byref(f))
+        return y, f.value
+
+    def update(self, s, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        d = C.c_double(float('nan'))
+        br = self.L.kbo_update(self.h, s, _p(x, _dp), int(y), C.byref(d))
+        return br, d.value
+
+    def m(self, s):
+        return self.L.kbo_m(self.h, s)
+
+    def set_size(self, s):
+        return self.L.kbo_set_size(self.h, s)
+
+    def coeff(self, s):
+        return np.ctypeslib.as_array(self.L.kbo_coeff(self.h, s), shape=(self.cap,))[:self.m(s)].copy()
+
+    def landmarks(self, s):
+        d = int(self.dims[s]) + 1
+        return np.ctypeslib.as_array(self.L.kbo_landmarks(self.h, s), shape=(self.cap, d))[:self.m(s)].copy()
+
+    def kinv(self, s):
+        ld = C.c_int32()
+        p = self.L.kbo_kinv(self.h, s, C.byref(ld))
+        m = self.m(s)
+        return np.ctypeslib.as_array(p, shape=(ld.value, ld.value))[:m, :m].copy()
+
+    def select_action(self, state):
+        state = np.ascontiguousarray(state, dtype=np.float32)
+        act = np.zeros(self.S, dtype=np.int32)
+        adj = self.L.kbo_select_action(self.h, _p(state, C.POINTER(C.c_float)), _p(act, _ip))
+        self.action = act
+        return act, adj
+
+    def update_control(self, state, action, labels):
+        state = np.ascontiguousarray(state, dtype=np.float32)
+        action = np.ascontiguousarray(action, dtype=np.int32)
+        labels = np.ascontiguousarray(labels, dtype=np.int32)
+        hits = np.zeros(self.S, dtype=np.int32)
+        self.L.kbo_update_control(self.h, _p(state, C.POINTER(C.c_float)), _p(action, _ip), _p(labels, _ip),
+                                  int(self.adjusted), _p(hits, _ip))
+        return hits
+
+    @property
+    def margins(self):
+        return np.ctypeslib.as_array(self.L.kbo_margins(self.h), shape=(self.S,)).copy()
+
+    @property
+    def security_factors(self):
+        return np.ctypeslib.as_array(self.L.kbo_security_factors(self.h), shape=(self.S,)).copy()
+
+    @property
+    def accuracies(self):
+        return np.ctypeslib.as_array(self.L.kbo_accuracies(self.h), shape=(self.S, self.n_prbs)).copy()
+
+    def stats(self):
+        return self.L.kbo_n_predict(self.h), self.L.kbo_n_mistakes(self.h)
+
+    def error(self):
+        return self.L.kbo_error(self.h)

@@ -1,0 +1,121 @@
+"""Pin the KBRL oracle (oracle/kb_oracle.c) against teacher-forced sequences recorded from the
+reference (fixtures G9, G10).  numpy evaluates k@coeff and Kinv@k through BLAS, whose summation
+order is not reproducible, so kernel values are compared with a tolerance (1e-9 relative to the
+scale of the terms, as SURVEY.md §8c G9 states) and every DECISION (predicted sign, branch of
+Projectron.update, selected action, hit, security factor) must agree exactly -- the fixtures
+contain no decision closer than that tolerance to its threshold, which the tests assert.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from ranslice.config import make_config
+
+TOL = 1e-9
+ETA = 0.1
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+@pytest.mark.parametrize('tag,d', [('d11', 11), ('d4', 4)])
+def test_g9_projectron_teacher_forced(golden_dir, tag, d):
+    g = _load(golden_dir, 'g9_projectron')
+    ag = po.OracleKBRL([d - 1], 200, [10], [3], capacity=1024)
+    ag.set_tape(g[tag + '_ties'])
+    xs, ys = g[tag + '_x'], g[tag + '_y']
+    n_tie = 0
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, xs[i])
+        fr = g[tag + '_f'][i]
+        assert f == pytest.approx(fr, rel=TOL, abs=TOL)
+        if fr == 0.0 and g[tag + '_m'][i - 1 if i else 0] > 0 and i > 0:
+            n_tie += 1
+        if abs(fr) > TOL or fr == 0.0:
+            assert yp == g[tag + '_ypred'][i], i
+        br, dl = ag.update(0, xs[i], int(ys[i]))
+        assert br == g[tag + '_branch'][i], i
+        if br:
+            assert dl == pytest.approx(g[tag + '_delta'][i], rel=TOL, abs=TOL)
+            assert abs(g[tag + '_delta'][i] - ETA) > TOL  # the fixture has no borderline projection test
+        assert ag.m(0) == g[tag + '_m'][i]
+    assert n_tie >= 1, 'fixture should exercise the f == 0 tie-break (Q11)'
+    assert ag.set_size(0) == int(g[tag + '_set_size'])
+    np.testing.assert_array_equal(ag.landmarks(0), g[tag + '_landmarks'])
+    np.testing.assert_allclose(ag.coeff(0), g[tag + '_coeff'], rtol=1e-8, atol=1e-9)
+    kinv = g[tag + '_kinv']
+    np.testing.assert_allclose(ag.kinv(0), kinv, rtol=1e-7, atol=1e-7 * np.abs(kinv).max())
+    assert ag.error() == 0
+
+
+def _dims(scenario):
+    cfg = make_config(scenario)
+    return [10] * cfg.n_embb + [3] * cfg.n_mmtc, cfg.n_prbs
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_g10_kbrl_control_teacher_forced(golden_dir, scenario):
+    g = _load(golden_dir, 'g10_kbrl_s%d' % scenario)
+    dims, n_prbs = _dims(scenario)
+    ag = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']))
+    ties = g['tape_val'][g['tape_kind'] == 6]
+    ag.set_tape(ties)
+    steps = len(g['state'])
+    acc_i = 0
+    for i in range(steps):
+        hits = ag.update_control(g['state'][i], g['action_in'][i], g['labels'][i])
+        assert (hits == g['hits'][i]).all(), i
+        nxt = g['state'][i + 1] if i + 1 < steps else g['final_state']
+        act, adj = ag.select_action(nxt)
+        ag.adjusted = adj
+        assert (act == g['action_out'][i]).all(), i
+        assert adj == g['adjusted'][i]
+        assert (ag.margins == g['margins'][i]).all()
+        assert (ag.security_factors == g['security'][i]).all()
+        sizes = [ag.set_size(s) if ag.m(s) else 0 for s in range(len(dims))]
+        assert sizes == list(g['set_size'][i]), i
+        if i % 10 == 9 or i == steps - 1:
+            np.testing.assert_allclose(ag.accuracies, g['acc'][acc_i], rtol=0, atol=0)
+            acc_i += 1
+    for s in range(len(dims)):
+        np.testing.assert_array_equal(ag.landmarks(s), g['landmarks%d' % s])
+        np.testing.assert_allclose(ag.coeff(s), g['coeff%d' % s], rtol=1e-8, atol=1e-9)
+    n_pred, n_mist = ag.stats()
+    assert n_pred > 100 * steps // 10 and ag.error() == 0
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_g10_closed_loop_env_plus_agent(golden_dir, scenario):
+    """BASELINE config 1 (plumbing): oracle env on the reference's tape driven by the oracle agent
+    reproduces the reference's closed-loop run (actions, rewards, violations) step for step."""
+    g = _load(golden_dir, 'g10_kbrl_s%d' % scenario)
+    fad = _load(golden_dir, 'fading_small')
+    dims, n_prbs = _dims(scenario)
+    kind, val = g['tape_kind'], g['tape_val']
+    env = po.OracleEnv(make_config(scenario), [fad['t0'], fad['t1'], fad['t2']])
+    env.set_tape(kind[kind != 6], val[kind != 6])
+    ag = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']))
+    ag.set_tape(val[kind == 6])
+    state = env.reset()
+    action = g['init_action'].copy()
+    for i in range(len(g['state'])):
+        out = env.step(action)
+        assert out['reward'] == g['reward'][i] and int(out['violations'].sum()) == g['violation'][i], i
+        ag.update_control(state, action, out['labels'])
+        action, ag.adjusted = ag.select_action(out['obs'])
+        state = out['obs']
+        assert (action == g['action_out'][i]).all(), i
+    assert env.tape_pos() == int((kind != 6).sum())
+
+
+def test_g11_results_schema(golden_dir):
+    """keys / dtypes / shapes of KBRL_Control.run's result dict (kbrl_control.py:148-155)"""
+    g = _load(golden_dir, 'g11_results_schema')
+    want = {'reward': ('float64', 1), 'resources': ('int16', 1), 'hits': ('int16', 2), 'adjusted': ('int16', 1),
+            'SLA': ('int16', 1), 'violation': ('int16', 1)}
+    assert sorted(k[4:] for k in g.files) == sorted(want)
+    for k, (dt, nd) in want.items():
+        assert str(g['key_' + k].dtype) == dt and g['key_' + k].ndim == nd

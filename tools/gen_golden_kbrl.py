@@ -1,0 +1,115 @@
+"""G9-G11: golden sequences for the KBRL agent, recorded from the reference (see gen_golden.py)."""
+import numpy as np
+
+
+def _g9(rh, tape, save):
+    from algorithms.kernel import GaussianKernel
+    from algorithms.projectron import SVvariable, Projectron
+    out = {}
+    for tag, d, n in (('d11', 11, 1500), ('d4', 4, 1200)):
+        rng = np.random.default_rng(90 + d)
+        np.random.seed(9)
+        tape.clear()
+        alg = Projectron(GaussianKernel(SVvariable(), 1))
+        xs, ys, fs, ypred, branch, delta, ms = [], [], [], [], [], [], []
+        for i in range(n):
+            x = np.append(rng.random(d - 1).astype(np.float32), rng.integers(0, 201) / 200)
+            score = x[:-1].mean() * 0.8 + 0.35 - x[-1]
+            y = -1 if score + rng.normal(0, 0.05) > 0 else 1
+            if i in (3, 4):  # exercise f == 0 ties: a far-away point whose kernel values underflow in f32
+                x = x + (30.0 if i == 3 else 60.0)
+            yp = alg.predict(x)
+            f = float(alg.f)
+            m0 = alg.counter
+            dl = np.nan
+            if alg.f * y <= 0:  # the expression of projectron.py:41-44, evaluated on the reference's arrays
+                d_star = alg.Kinv @ alg.K_f
+                if np.ndim(d_star) == 0:
+                    d_star = np.array([d_star], dtype=np.float32)
+                dl = float(max(alg.kernel.k_eval(x, x) - d_star @ alg.K_f, 0))
+            alg.update(x, y)
+            br = 0 if not (f * y <= 0) else (2 if alg.counter > m0 else 1)
+            xs.append(x); ys.append(y); fs.append(f); ypred.append(int(yp)); branch.append(br)
+            delta.append(dl); ms.append(alg.counter)
+        kind, val = tape.arrays()
+        out.update({tag + '_x': np.asarray(xs), tag + '_y': np.asarray(ys, dtype=np.int32),
+                    tag + '_f': np.asarray(fs), tag + '_ypred': np.asarray(ypred, dtype=np.int32),
+                    tag + '_branch': np.asarray(branch, dtype=np.int32), tag + '_delta': np.asarray(delta),
+                    tag + '_m': np.asarray(ms, dtype=np.int32), tag + '_ties': val,
+                    tag + '_landmarks': np.atleast_2d(alg.sv.landmarks), tag + '_coeff': np.asarray(alg.sv.coeff, dtype=np.float64),
+                    tag + '_kinv': np.atleast_2d(np.asarray(alg.Kinv, dtype=np.float64)),
+                    tag + '_set_size': np.int32(alg.get_set_size())})
+    save('g9_projectron', **out)
+
+
+def _run_agent(rh, tape, scenario, seed, steps, a_range):
+    import scenario_creator as sc
+    np.random.seed(2000 + seed)
+    rng = rh.TapeRNG(np.random.default_rng(seed), tape)
+    env = sc.create_env(rng, scenario)
+    tape.on = False
+    agent = sc.create_kbrl_agent(rng, scenario, accuracy_range=a_range)
+    tape.on = True
+    init_action = agent.action.copy()
+    init_sec = agent.security_factors.copy()
+    rec = dict(state=[], action_in=[], labels=[], hits=[], action_out=[], adjusted=[], margins=[], security=[],
+               acc=[], set_size=[], reward=[], violation=[])
+    tape.clear()
+    action = agent.action
+    state = env.reset()
+    for i in range(steps):
+        new_state, reward, _, info = env.step(action)
+        labels = info['SLA_labels']
+        rec['state'].append(np.array(state, dtype=np.float32)); rec['action_in'].append(np.array(action, dtype=np.int32))
+        rec['labels'].append(np.array(labels, dtype=np.int32))
+        hits = agent.update_control(state, action, labels)
+        action, agent.adjusted = agent.select_action(new_state)
+        state = new_state
+        rec['hits'].append(np.array(hits, dtype=np.int32)); rec['action_out'].append(np.array(action, dtype=np.int32))
+        rec['adjusted'].append(int(agent.adjusted)); rec['margins'].append(np.array(agent.margins, dtype=np.int32))
+        rec['security'].append(np.array(agent.security_factors, dtype=np.int32))
+        rec['set_size'].append([h.algorithm.get_set_size() if h.algorithm.counter else 0 for h in agent.learners])
+        rec['reward'].append(reward); rec['violation'].append(int(info['total_violations']))
+        if i % 10 == 9 or i == steps - 1:
+            rec['acc'].append(agent.accuracies.copy())
+    rec['final_state'] = np.array(state, dtype=np.float32)
+    kind, val = tape.arrays()
+    out = {k: np.asarray(v) for k, v in rec.items()}
+    out.update(tape_kind=kind, tape_val=val, init_action=np.asarray(init_action, dtype=np.int32),
+               init_sec=np.asarray(init_sec, dtype=np.int32), scenario=np.int32(scenario), seed=np.int64(seed),
+               a_range=np.asarray(a_range))
+    for s, h in enumerate(agent.learners):
+        out['coeff%d' % s] = np.asarray(h.algorithm.sv.coeff, dtype=np.float64)
+        out['landmarks%d' % s] = np.atleast_2d(h.algorithm.sv.landmarks)
+    return out
+
+
+def _g10(rh, tape, save):
+    for scenario, steps in ((0, 120), (2, 150)):
+        out = _run_agent(rh, tape, scenario, seed=3, steps=steps, a_range=[0.99, 0.999])
+        save('g10_kbrl_s%d' % scenario, **out)
+
+
+def _g11(rh, tape, save):
+    """experiments_kbrl.Evaluator.evaluate plumbing (experiments_kbrl.py:45-55): result dict schema"""
+    import scenario_creator as sc
+    np.random.seed(11)
+    tape.on = False
+    rng = np.random.default_rng(0)
+    env = sc.create_env(rng, 0)
+    agent = sc.create_kbrl_agent(rng, 0, accuracy_range=[0.97, 0.99])
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        res = agent.run(env, 60)
+    tape.on = True
+    out = {}
+    for k, v in res.items():
+        out['key_' + k] = np.asarray(v)
+    save('g11_results_schema', **out)
+
+
+def generate(rh, tape, save):
+    _g9(rh, tape, save)
+    _g10(rh, tape, save)
+    _g11(rh, tape, save)
