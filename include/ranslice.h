@@ -146,6 +146,57 @@ int rs_n_slices(const rs_handle* h);
 const char* rs_last_error(const rs_handle* h);
 void rs_destroy(rs_handle* h);
 
+
+/* ------------------------------------------------------------------------------------------
+ * KBRL agent (hot path B).  Stands in for kbrl_control.KBRL_Control over
+ * algorithms.projectron.Projectron(GaussianKernel(SVvariable)) (reference kbrl_control.py:23-114,
+ * algorithms/projectron.py:23-64, algorithms/kernel.py:3-34), one independent agent per replica.
+ * ------------------------------------------------------------------------------------------ */
+#define KB_MAX_SLICES 8
+
+typedef struct kb_config {
+    int32_t n_envs;               /* agents (one per env replica) */
+    int32_t n_slices;             /* learners per agent */
+    int32_t n_prbs;
+    int32_t capacity;             /* landmarks per learner (<= 1024) */
+    int32_t dims[KB_MAX_SLICES];  /* state variables of learner s: 10 eMBB / 3 mMTC (scenario_creator.py:209-235) */
+    double alfa;                  /* scenario_creator.py:187 */
+    double acc_lo, acc_hi;        /* accuracy_range */
+    double gamma, eta;            /* scenario_creator.py:218, projectron.py:25 */
+} kb_config;
+
+typedef struct kb_handle kb_handle;
+
+int kb_create(const kb_config* cfg, int device, kb_handle** out);
+void kb_destroy(kb_handle* k);
+const char* kb_last_error(const kb_handle* k);
+/* KBRL_Control.__init__ state (kbrl_control.py:28-39): initial_action / security_factor [n_envs][S];
+ * seeds[n_envs] feed the tie-break stream of GaussianKernel.predict (kernel.py:26-27). */
+int kb_reset(kb_handle* k, const int32_t* initial_action, const int32_t* security_factor, const uint64_t* seeds);
+/* KBRL_Control.update_control(state, action, labels) -> hits (kbrl_control.py:80-114), all agents */
+int kb_update_control(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t* hits);
+/* KBRL_Control.select_action(state) -> (action, adjusted) (kbrl_control.py:41-78), all agents */
+int kb_select_action(kb_handle* k, const float* state, int32_t* action, int32_t* adjusted);
+/* One closed-loop agent step entirely on the device (KBRL_Control.run body, kbrl_control.py:129-134):
+ * update_control(previous obs, the action just executed by `env`, its SLA labels) followed by
+ * select_action(new obs); the selected action is written into env's device action buffer. */
+int kb_step_resident(kb_handle* k, rs_handle* env);
+/* Projectron.predict(x) / update(x, y) on learner `s` of agent `e` (projectron.py:32-60).
+ * branch: 0 none, 1 projection, 2 dictionary grew. */
+int kb_predict(kb_handle* k, int e, int s, const double* x, int32_t* y_pred, double* f);
+int kb_update(kb_handle* k, int e, int s, const double* x, int32_t y, int32_t* branch, double* delta);
+/* Dictionary of learner (e, s): m landmarks [m][dims+1], coeff [m], Kinv [m][m] (any may be NULL) */
+int kb_get_learner(kb_handle* k, int e, int s, int32_t* m, double* landmarks, double* coeff, double* kinv);
+/* margins / security_factors / current action [n_envs][S], adjusted [n_envs], accuracies [n_envs][S][n_prbs] */
+int kb_get_control(kb_handle* k, int32_t* margins, int32_t* security, int32_t* action, int32_t* adjusted,
+                   double* accuracies);
+int kb_set_adjusted(kb_handle* k, const int32_t* adjusted);
+/* sums over learners since kb_reset: [0] predicts, [1] mistakes, [2] insertions, [3] kernel evaluations */
+int kb_get_stats(kb_handle* k, uint64_t stats[4]);
+int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
+int kb_set_kernel_timing(kb_handle* k, int enable);
+int kb_synchronize(kb_handle* k);
+
 #ifdef __cplusplus
 }
 #endif

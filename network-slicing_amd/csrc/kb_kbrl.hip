@@ -1,0 +1,614 @@
+// kb_kbrl.hip -- the KBRL agent's kernel machinery on gfx950, batched over env replicas.
+//
+// What it computes (reference call tree):
+//   GaussianKernel.k / predict       algorithms/kernel.py:8-28
+//   Projectron.predict / update      algorithms/projectron.py:32-60
+//   KBRL_Control.select_action / adjust_action / update_control   kbrl_control.py:41-114
+//
+// One workgroup (4 waves) owns one learner = (replica, slice).  Both hot loops of the agent --
+// the augmentation loop of update_control and the linear scan of select_action -- evaluate the
+// classifier on candidates x_c = (state, c / n_prbs) that differ only in the last coordinate.
+// For landmark l_j:  ||l_j - x_c||^2 = D0_j + (lam_j - t_c)^2 = [D0_j + lam_j^2, -2 lam_j, 1] . [1, t_c, t_c^2]
+// so the [landmarks x candidates] distance block is a K=4 dense contraction: exactly one
+// v_mfma_f64_16x16x4_f64 per 16x16 tile.  exp() of the tile and the contraction with the
+// coefficient vector follow on the VALU (4 exps per lane per tile: this, not the MFMA, bounds
+// the kernel; DESIGN.md gives the flop model).  The reference's sequentially dependent loop
+// (predict, update, predict, ...) is reproduced exactly in order: score the whole remaining
+// range, find the first mistake, apply that one Projectron update, rescore what follows (H4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rs_philox.h"
+
+namespace kb {
+
+#define KB_DMAX 16      // max len(x)
+#define KB_CAND_MAX 272 // n_prbs + 1 rounded up to 16 (n_prbs <= 256)
+
+typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
+
+struct KbDev {
+    int32_t n_envs, S, n_prbs, cap, nv;
+    int32_t dims[8];  // state variables per learner (len(x) = dims+1)
+    int32_t off[8];   // first state variable of learner s
+    double alfa, lo, hi, gamma, eta;
+};
+
+struct KbState {
+    int32_t* m;        // [T] landmarks per learner (T = n_envs * S)
+    double* L;         // [T][KB_DMAX][cap] landmarks, coordinate-major
+    double* coeff;     // [T][cap]
+    double* Kinv;      // [T][cap][cap]
+    double* kf;        // [T][cap]  K_f cached by the last predict (projectron.py:34)
+    double* f_last;    // [T]
+    uint32_t* tie_ctr; // [T] Philox counter of the tie-break stream (kernel.py:26-27)
+    uint64_t* seeds;   // [n_envs]
+    int32_t* action;   // [n_envs][S]
+    int32_t* security; // [n_envs][S]
+    int32_t* margins;  // [n_envs][S]
+    int32_t* adjusted; // [n_envs]
+    double* acc;       // [n_envs][S][n_prbs]
+    int32_t* err;      // [n_envs]
+    uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
+};
+
+__device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int s) {
+    uint64_t seed = K.seeds[env];
+    rs_stream st = {(uint32_t)seed, (uint32_t)(seed >> 32), (uint32_t)s, 0xFFFFFFFFu, K.tie_ctr[task]};
+    int v = rs_stream_pm1(&st);
+    K.tie_ctr[task] = st.ctr;
+    return v;
+}
+
+// Shared-memory working set of one learner
+struct Lds {
+    double bq[1024];   // D0_j + lam_j^2
+    double bl[1024];   // -2 lam_j
+    double lam[1024];  // lam_j (last coordinate of the landmark)
+    double d0[1024];   // D0_j
+    double co[1024];   // coeff_j
+    double kf[1024];   // kernel column of the candidate being updated
+    double ds[1024];   // d* = Kinv k_f
+    double f[KB_CAND_MAX];
+    double x[KB_DMAX];
+    double red[8];
+    int ired[8];
+};
+
+__device__ __forceinline__ double block_sum(double v, Lds& sm) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm.red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm.red[w];
+    return t;
+}
+
+// D0_j, lam_j and the MFMA operands for the current state (first d-1 coordinates in sm.x)
+__device__ void prepare_operands(const KbDev& D, const KbState& K, int task, int m, int d, Lds& sm) {
+    const int cap = D.cap;
+    const double* L = K.L + (size_t)task * KB_DMAX * cap;
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+        double d0 = 0.0, lam = 0.0, co = 0.0;
+        if (j < m) {
+            for (int q = 0; q < d - 1; ++q) {
+                double t = L[(size_t)q * cap + j] - sm.x[q];
+                d0 += t * t;
+            }
+            lam = L[(size_t)(d - 1) * cap + j];
+            co = K.coeff[(size_t)task * cap + j];
+        }
+        sm.d0[j] = d0;
+        sm.lam[j] = lam;
+        sm.bq[j] = d0 + lam * lam;
+        sm.bl[j] = -2.0 * lam;
+        sm.co[j] = co;
+    }
+    __syncthreads();
+}
+
+// f(c) for c in [c_lo, c_hi] -> sm.f[c]; one wave per 16-candidate strip, MFMA distance tiles
+__device__ void score_range(const KbDev& D, int m, int c_lo, int c_hi, Lds& sm) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double inv_n = 1.0;  // t_c = c / n_prbs computed below with a true division
+    (void)inv_n;
+    if (m == 0) {
+        for (int c = c_lo + (int)threadIdx.x; c <= c_hi; c += blockDim.x) sm.f[c] = 0.0;
+        __syncthreads();
+        return;
+    }
+    if (m == 1) {
+        // single landmark: numpy keeps k and coeff in float32 (kernel.py:16, projectron.py:9)
+        for (int c = c_lo + (int)threadIdx.x; c <= c_hi; c += blockDim.x) {
+            double t = (double)c / (double)D.n_prbs;
+            double dl = sm.lam[0] - t;
+            double k = rs_exp(-D.gamma * (sm.d0[0] + dl * dl));
+            sm.f[c] = (double)(float)((float)k * (float)sm.co[0]);
+        }
+        __syncthreads();
+        return;
+    }
+    const int n_strips = (c_hi - c_lo) / 16 + 1;
+    const int mt = (m + 15) / 16;
+    const int kq = lane >> 4, li = lane & 15;
+    for (int strip = wave; strip < n_strips; strip += nw) {
+        const int c = c_lo + strip * 16 + li;
+        const double t = (double)c / (double)D.n_prbs;
+        // B[k][cand]: (1, t, t^2, 0)
+        const double bval = kq == 0 ? 1.0 : (kq == 1 ? t : (kq == 2 ? t * t : 0.0));
+        double part = 0.0;
+        for (int jt = 0; jt < mt; ++jt) {
+            const int j = jt * 16 + li;
+            // A[landmark][k]: (D0 + lam^2, -2 lam, 1, 0)
+            const double aval = kq == 0 ? sm.bq[j] : (kq == 1 ? sm.bl[j] : (kq == 2 ? 1.0 : 0.0));
+            kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
+            // lane holds dist[landmark = kq + 4 r][cand = li]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int jj = jt * 16 + kq + 4 * r;
+                double dist = acc[r] > 0.0 ? acc[r] : 0.0;
+                part += rs_exp(-D.gamma * dist) * sm.co[jj];
+            }
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        if (kq == 0 && c <= c_hi) sm.f[c] = part;
+    }
+    __syncthreads();
+}
+
+// kernel column of candidate c against the dictionary -> sm.kf (exact (lam - t)^2 form)
+__device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
+    const double t = (double)c / (double)D.n_prbs;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        double dl = sm.lam[j] - t;
+        double k = rs_exp(-D.gamma * (sm.d0[j] + dl * dl));
+        sm.kf[j] = m == 1 ? (double)(float)k : k;
+    }
+    __syncthreads();
+}
+
+// Projectron.update (projectron.py:39-60) for x = (state, c/n), given sm.kf.  Returns the new m.
+// branch: 1 = projection onto the dictionary, 2 = dictionary grew.
+__device__ int apply_update(const KbDev& D, const KbState& K, int task, int m, int d, int c, int y, Lds& sm,
+                            int* branch, double* delta_out) {
+    const int cap = D.cap;
+    double* Kinv = K.Kinv + (size_t)task * cap * cap;
+    double* coeffg = K.coeff + (size_t)task * cap;
+    double dot;
+    if (m <= 1) {
+        float kinv = m == 0 ? 0.0f : 1.0f;
+        float ds = kinv * (float)(m == 0 ? 0.0 : sm.kf[0]);
+        if (threadIdx.x == 0) sm.ds[0] = (double)ds;
+        dot = (double)(float)(ds * (float)(m == 0 ? 0.0 : sm.kf[0]));
+        __syncthreads();
+    } else {
+        // d* = Kinv k_f: one row per wave-strided lane group (rows are contiguous -> coalesced)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        for (int i = wave; i < m; i += nw) {
+            double a = 0.0;
+            for (int j = lane; j < m; j += 64) a += Kinv[(size_t)i * cap + j] * sm.kf[j];
+            for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
+            if (lane == 0) sm.ds[i] = a;
+        }
+        __syncthreads();
+        double p = 0.0;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) p += sm.ds[j] * sm.kf[j];
+        dot = block_sum(p, sm);
+    }
+    double delta = 1.0 - dot;  // Kii = k(x, x) = 1
+    delta = delta > 0.0 ? delta : 0.0;
+    *delta_out = delta;
+    if (delta <= D.eta) {
+        *branch = 1;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            double nc = sm.co[j] + (double)y * sm.ds[j];
+            if (m == 1) nc = (double)(float)nc;
+            sm.co[j] = nc;
+            coeffg[j] = nc;
+        }
+        __syncthreads();
+        return m;
+    }
+    *branch = 2;
+    if (m >= cap || m >= 1024) {
+        if (threadIdx.x == 0) atomicOr(&K.err[task / D.S], 4);
+        __syncthreads();
+        return m;
+    }
+    // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
+    double* L = K.L + (size_t)task * KB_DMAX * cap;
+    const double t = (double)c / (double)D.n_prbs;
+    if (threadIdx.x == 0) {
+        for (int q = 0; q < d - 1; ++q) L[(size_t)q * cap + m] = sm.x[q];
+        L[(size_t)(d - 1) * cap + m] = t;
+        coeffg[m] = (double)y;
+        sm.co[m] = (double)y;
+        sm.d0[m] = 0.0;  // the new landmark shares the current state
+        sm.lam[m] = t;
+        sm.bq[m] = t * t;
+        sm.bl[m] = -2.0 * t;
+        sm.ds[m] = -1.0;
+    }
+    __syncthreads();
+    if (m == 0) {
+        if (threadIdx.x == 0) Kinv[0] = 1.0;
+    } else {
+        const int m1 = m + 1;
+        for (int e = threadIdx.x; e < m1 * m1; e += blockDim.x) {
+            const int i = e / m1, j = e - i * m1;
+            double old = (i < m && j < m) ? Kinv[(size_t)i * cap + j] : 0.0;
+            Kinv[(size_t)i * cap + j] = old + (sm.ds[i] * sm.ds[j]) / delta;
+        }
+    }
+    __syncthreads();
+    return m + 1;
+}
+
+struct CtlArgs {
+    KbDev D;
+    KbState K;
+    const float* state;     // [n_envs][nv] state the action was taken in
+    const int32_t* action;  // [n_envs][S]
+    const int32_t* labels;  // [n_envs][S]
+    int32_t* hits;          // [n_envs][S]
+};
+
+// KBRL_Control.update_control for one learner (kbrl_control.py:83-112)
+__global__ __launch_bounds__(256) void update_control_kernel(CtlArgs A) {
+    __shared__ Lds sm;
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, n = D.n_prbs;
+    int m = K.m[task];
+    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    __syncthreads();
+    prepare_operands(D, K, task, m, d, sm);
+    const int a_i = A.action[env * D.S + s];
+    const int y = A.labels[env * D.S + s];
+    uint64_t n_pred = 0, n_mist = 0, n_grow = 0, n_eval = 0;
+
+    // ---- y_pred = predict((state, a_i / n)) (kbrl_control.py:88-89)
+    score_range(D, m, a_i, a_i, sm);
+    n_pred += 1;
+    n_eval += (uint64_t)m;
+    int y_pred = 0;
+    {
+        double f0 = sm.f[a_i];
+        if (m > 0) {
+            y_pred = f0 > 0.0 ? 1 : (f0 < 0.0 ? -1 : 0);
+            if (y_pred == 0) {
+                if (threadIdx.x == 0) sm.ired[0] = tie_draw(K, task, env, s);
+                __syncthreads();
+                y_pred = sm.ired[0];
+                __syncthreads();
+            }
+        }
+    }
+    const int hit = y == y_pred;
+    // ---- accuracy table and security factor (kbrl_control.py:92-99)
+    {
+        int margin = K.margins[env * D.S + s];
+        margin = margin > 0 ? margin : 0;
+        double* acc = K.acc + ((size_t)env * D.S + s) * n;
+        if (y_pred == 1) {
+            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+                if (!hit) {
+                    if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
+                } else {
+                    if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
+                }
+            }
+        }
+        __syncthreads();
+        if (!K.adjusted[env]) {
+            if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
+            __syncthreads();
+            int first = 0x7fffffff;
+            for (int c = threadIdx.x; c < n; c += blockDim.x)
+                if (acc[c] > D.lo) { first = c; break; }
+            if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
+            __syncthreads();
+            if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
+        }
+        if (threadIdx.x == 0) A.hits[env * D.S + s] = hit;
+    }
+    // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
+    int c_from = y == 1 ? a_i : 0;
+    const int c_to = y == 1 ? n : a_i;
+    while (c_from <= c_to) {
+        score_range(D, m, c_from, c_to, sm);
+        n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
+        // first candidate (in order) with f * y <= 0
+        if (threadIdx.x == 0) sm.ired[2] = 0x7fffffff;
+        __syncthreads();
+        int firstc = 0x7fffffff;
+        for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x)
+            if (sm.f[c] * (double)y <= 0.0) { firstc = c; break; }
+        if (firstc != 0x7fffffff) atomicMin(&sm.ired[2], firstc);
+        __syncthreads();
+        const int cstar = sm.ired[2];
+        __syncthreads();
+        const int last = cstar == 0x7fffffff ? c_to : cstar;
+        n_pred += (uint64_t)(last - c_from + 1);
+        // the predictions made on the way each consume a tie-break draw when f == 0 (Q11)
+        if (m > 0) {
+            int zeros = 0;
+            for (int c = c_from + (int)threadIdx.x; c <= last; c += blockDim.x) zeros += sm.f[c] == 0.0 ? 1 : 0;
+            int tz = (int)block_sum((double)zeros, sm);
+            if (threadIdx.x == 0 && tz > 0) K.tie_ctr[task] += (uint32_t)tz;
+        }
+        if (cstar == 0x7fffffff) break;
+        n_mist += 1;
+        kernel_column(D, m, cstar, sm);
+        int branch;
+        double delta;
+        const int m_new = apply_update(D, K, task, m, d, cstar, y, sm, &branch, &delta);
+        if (branch == 2 && m_new > m) n_grow += 1;
+        m = m_new;
+        c_from = cstar + 1;
+    }
+    if (threadIdx.x == 0) {
+        K.m[task] = m;
+        uint64_t* st = K.stats + (size_t)task * 4;
+        st[0] += n_pred;
+        st[1] += n_mist;
+        st[2] += n_grow;
+        st[3] += n_eval;
+    }
+}
+
+struct SelArgs {
+    KbDev D;
+    KbState K;
+    const float* state;  // [n_envs][nv] new state
+};
+
+// per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63)
+__global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
+    __shared__ Lds sm;
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, n = D.n_prbs;
+    const int m = K.m[task];
+    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    __syncthreads();
+    prepare_operands(D, K, task, m, d, sm);
+    score_range(D, m, 0, n, sm);
+    if (threadIdx.x == 0) sm.ired[0] = 0x7fffffff;
+    __syncthreads();
+    int firstc = 0x7fffffff;
+    if (m > 0)
+        for (int c = threadIdx.x; c <= n; c += blockDim.x)
+            if (sm.f[c] >= 0.0) { firstc = c; break; }  // positive, or a tie to be drawn
+    if (firstc != 0x7fffffff) atomicMin(&sm.ired[0], firstc);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = sm.ired[0];
+        int found = -1;
+        uint64_t n_pred = 0;
+        if (m == 0) {
+            n_pred = (uint64_t)n + 1;
+        } else {
+            int prev = -1;
+            // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
+            while (c != 0x7fffffff && c <= n) {
+                if (sm.f[c] > 0.0) { found = c; break; }
+                if (sm.f[c] == 0.0 && tie_draw(K, task, env, s) == 1) { found = c; break; }
+                prev = c;
+                int nx = 0x7fffffff;
+                for (int q = c + 1; q <= n; ++q)
+                    if (sm.f[q] >= 0.0) { nx = q; break; }
+                c = nx;
+            }
+            (void)prev;
+            n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
+        }
+        const int offset = K.security[env * D.S + s];
+        int act, margin = 0;
+        if (found >= 0) {
+            int a = n < found + offset ? n : found + offset;
+            margin = a - found;
+            act = a;
+        } else {
+            act = n;
+        }
+        K.action[env * D.S + s] = act;
+        K.margins[env * D.S + s] = margin;
+        uint64_t* st = K.stats + (size_t)task * 4;
+        st[0] += n_pred;
+        st[3] += ((uint64_t)n + 1) * (uint64_t)m;
+    }
+}
+
+// cross-learner part of select_action + adjust_action (kbrl_control.py:65-78)
+__global__ void adjust_kernel(KbDev D, KbState K, int32_t* action_out) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env >= D.n_envs) return;
+    long assigned = 0;
+    for (int s = 0; s < D.S; ++s) assigned += K.action[env * D.S + s];
+    int adjusted = 0;
+    if (assigned > D.n_prbs) {
+        adjusted = 1;
+        for (int s = 0; s < D.S; ++s) {
+            int a = K.action[env * D.S + s];
+            double p = (double)a / (double)assigned;
+            int na = (int)(int16_t)__builtin_floor((double)D.n_prbs * p);
+            K.margins[env * D.S + s] = (int)(int16_t)(K.margins[env * D.S + s] - (a - na));
+            K.action[env * D.S + s] = na;
+        }
+    }
+    K.adjusted[env] = adjusted;
+    if (action_out)
+        for (int s = 0; s < D.S; ++s) action_out[env * D.S + s] = K.action[env * D.S + s];
+}
+
+// ---- single-call entry points behind Projectron.predict / update (drop-in API, N=1 plumbing)
+
+struct OneArgs {
+    KbDev D;
+    KbState K;
+    int task;
+    int y;
+    double x[KB_DMAX];
+    double* out;  // [4]: y_pred, f, branch, delta
+};
+
+__global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
+    __shared__ Lds sm;
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int task = A.task, env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, cap = D.cap;
+    const int m = K.m[task];
+    double* kfg = K.kf + (size_t)task * cap;
+    double p = 0.0;
+    const double* L = K.L + (size_t)task * KB_DMAX * cap;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        double dist = 0.0;
+        for (int q = 0; q < d; ++q) {
+            double t = L[(size_t)q * cap + j] - A.x[q];
+            dist += t * t;
+        }
+        double k = rs_exp(-D.gamma * dist);
+        if (m == 1) k = (double)(float)k;
+        kfg[j] = k;
+        p += k * K.coeff[(size_t)task * cap + j];
+    }
+    double f = block_sum(p, sm);
+    if (m == 1) f = (double)(float)((float)kfg[0] * (float)K.coeff[(size_t)task * cap]);
+    if (threadIdx.x == 0) {
+        int y = 0;
+        if (m > 0) {
+            y = f > 0.0 ? 1 : (f < 0.0 ? -1 : 0);
+            if (y == 0) y = tie_draw(K, task, env, s);
+        } else {
+            f = 0.0;
+            kfg[0] = 0.0;
+        }
+        K.f_last[task] = f;
+        A.out[0] = (double)y;
+        A.out[1] = f;
+        K.stats[(size_t)task * 4 + 0] += 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
+    __shared__ Lds sm;
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int task = A.task, env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, cap = D.cap;
+    (void)env;
+    int m = K.m[task];
+    const double f = K.f_last[task];
+    if (!(f * (double)A.y <= 0.0)) {
+        if (threadIdx.x == 0) { A.out[2] = 0.0; A.out[3] = 0.0; }
+        return;
+    }
+    // stage x, coefficients and the cached kernel row; apply_update works on (state, c/n) so the
+    // last coordinate is handed over through sm.lam/sm.x with n_prbs-independent arithmetic
+    for (int q = threadIdx.x; q < d; q += blockDim.x) sm.x[q] = A.x[q];
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+        sm.co[j] = j < m ? K.coeff[(size_t)task * cap + j] : 0.0;
+        sm.kf[j] = j < (m > 0 ? m : 1) ? K.kf[(size_t)task * cap + j] : 0.0;
+    }
+    __syncthreads();
+    int branch;
+    double delta;
+    // generic x: reuse apply_update with c/n == x[d-1] by passing n_prbs = 1 semantics
+    KbDev D1 = D;
+    // apply_update computes t = c / n_prbs; encode the exact last coordinate via a local copy
+    // of the grow step instead (below) when the dictionary grows.
+    double* Kinv = K.Kinv + (size_t)task * cap * cap;
+    double dot;
+    if (m <= 1) {
+        float kinv = m == 0 ? 0.0f : 1.0f;
+        float ds = kinv * (float)(m == 0 ? 0.0 : sm.kf[0]);
+        if (threadIdx.x == 0) sm.ds[0] = (double)ds;
+        dot = (double)(float)(ds * (float)(m == 0 ? 0.0 : sm.kf[0]));
+        __syncthreads();
+    } else {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        for (int i = wave; i < m; i += nw) {
+            double a = 0.0;
+            for (int j = lane; j < m; j += 64) a += Kinv[(size_t)i * cap + j] * sm.kf[j];
+            for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
+            if (lane == 0) sm.ds[i] = a;
+        }
+        __syncthreads();
+        double p = 0.0;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) p += sm.ds[j] * sm.kf[j];
+        dot = block_sum(p, sm);
+    }
+    delta = 1.0 - dot;
+    delta = delta > 0.0 ? delta : 0.0;
+    (void)D1;
+    if (delta <= D.eta) {
+        branch = 1;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            double nc = sm.co[j] + (double)A.y * sm.ds[j];
+            if (m == 1) nc = (double)(float)nc;
+            K.coeff[(size_t)task * cap + j] = nc;
+        }
+    } else if (m >= cap || m >= 1024) {
+        branch = 2;
+        if (threadIdx.x == 0) atomicOr(&K.err[task / D.S], 4);
+    } else {
+        branch = 2;
+        double* L = K.L + (size_t)task * KB_DMAX * cap;
+        if (threadIdx.x == 0) {
+            for (int q = 0; q < d; ++q) L[(size_t)q * cap + m] = sm.x[q];
+            K.coeff[(size_t)task * cap + m] = (double)A.y;
+            sm.ds[m] = -1.0;
+        }
+        __syncthreads();
+        if (m == 0) {
+            if (threadIdx.x == 0) Kinv[0] = 1.0;
+        } else {
+            const int m1 = m + 1;
+            for (int e = threadIdx.x; e < m1 * m1; e += blockDim.x) {
+                const int i = e / m1, j = e - i * m1;
+                double old = (i < m && j < m) ? Kinv[(size_t)i * cap + j] : 0.0;
+                Kinv[(size_t)i * cap + j] = old + (sm.ds[i] * sm.ds[j]) / delta;
+            }
+        }
+        m += 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        K.m[task] = m;
+        A.out[2] = (double)branch;
+        A.out[3] = delta;
+        K.stats[(size_t)task * 4 + 1] += 1;
+        if (branch == 2) K.stats[(size_t)task * 4 + 2] += 1;
+    }
+}
+
+__global__ void kb_reset_kernel(KbDev D, KbState K, const int32_t* init_action, const int32_t* init_sec,
+                                const uint64_t* seeds) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int T = D.n_envs * D.S;
+    if (i < T) {
+        K.m[i] = 0;
+        K.f_last[i] = 0.0;
+        K.tie_ctr[i] = 0;
+        K.action[i] = init_action[i];
+        K.security[i] = init_sec[i];
+        K.margins[i] = 0;
+        for (int k = 0; k < 4; ++k) K.stats[(size_t)i * 4 + k] = 0;
+        for (int c = 0; c < D.n_prbs; ++c) K.acc[(size_t)i * D.n_prbs + c] = (D.lo + D.hi) / 2;
+    }
+    if (i < D.n_envs) {
+        K.seeds[i] = seeds[i];
+        K.adjusted[i] = 0;
+        K.err[i] = 0;
+    }
+}
+
+}  // namespace kb

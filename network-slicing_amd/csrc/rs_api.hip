@@ -669,3 +669,4 @@ extern "C" int rs_synchronize(rs_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }
+#include "kb_api.hip"

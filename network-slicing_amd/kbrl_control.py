@@ -1,0 +1,111 @@
+"""KBRL_Control / Learner with the reference's surface (reference kbrl_control.py:12-157).
+
+This is the N=1 host view of ranslice.kbrl_dev.VecKBRL: select_action, update_control and the
+Projectron dictionaries all run on the GPU (kb_* C ABI); Python only carries the per-step vectors.
+"""
+import numpy as np
+
+from ranslice.kbrl_dev import VecKBRL
+
+DEBUG = True
+
+
+class Learner:
+    """record (kbrl_control.py:12-21)"""
+
+    def __init__(self, algorithm, indexes, initial_action, security_factor):
+        self.algorithm = algorithm
+        self.indexes = indexes
+        self.initial_action = initial_action
+        self.security_factor = security_factor
+        self.step = 1
+
+
+class KBRL_Control:
+    def __init__(self, learners, n_prbs, alfa=0.05, accuracy_range=[0.99, 0.999], capacity=1024, device=0, seed=0):
+        self.learners = learners
+        self.accuracy_range = accuracy_range
+        self.n_slices = len(learners)
+        self.n_prbs = n_prbs
+        self.alfa = alfa
+        self.adjusted = 0
+        dims = []
+        expect = 0
+        for h in learners:
+            idx = h.indexes
+            if idx.start != expect or (idx.step not in (None, 1)):
+                raise ValueError('learner state slices must be contiguous and in order (scenario_creator.py:224-235)')
+            dims.append(idx.stop - idx.start)
+            expect = idx.stop
+        alg0 = learners[0].algorithm
+        self._dev = VecKBRL(1, dims, n_prbs, alfa=alfa, accuracy_range=tuple(accuracy_range),
+                            gamma=alg0.kernel.gamma, eta=alg0.eta, capacity=capacity, device=device)
+        self._dev.reset([[int(h.initial_action) for h in learners]], [[int(h.security_factor) for h in learners]],
+                        seeds=np.array([seed], dtype=np.uint64))
+        for s, h in enumerate(learners):
+            h.algorithm._bind(self._dev, 0, s)
+        self.action = np.array([h.initial_action for h in learners], dtype=np.int16)
+
+    # ---- public fields of the reference, read from the device
+    @property
+    def security_factors(self):
+        return self._dev.control()['security_factors'][0].astype(np.int16)
+
+    @property
+    def margins(self):
+        return self._dev.control()['margins'][0].astype(np.int16)
+
+    @property
+    def accuracies(self):
+        return self._dev.control()['accuracies'][0]
+
+    def select_action(self, state):
+        """kbrl_control.py:41-73 -> (action int16[S], adjusted)"""
+        action, adjusted = self._dev.select_action(np.asarray(state, dtype=np.float32)[None, :])
+        self.action = action[0].astype(np.int16)
+        return self.action, int(adjusted[0])
+
+    def adjust_action(self, action, assigned_prbs, n_prbs):
+        """kbrl_control.py:75-78 (kept for API parity; select_action applies it on the device)"""
+        relative_p = np.asarray(action) / assigned_prbs
+        new_action = np.array([np.floor(n_prbs * p) for p in relative_p], dtype=np.int16)
+        return new_action, action - new_action
+
+    def update_control(self, state, action, reward):
+        """kbrl_control.py:80-114 -> hits int16[S]; `reward` is the SLA label vector"""
+        self._dev.set_adjusted([int(self.adjusted)])
+        hits = self._dev.update_control(np.asarray(state, dtype=np.float32)[None, :],
+                                        np.asarray(action, dtype=np.int32)[None, :],
+                                        np.asarray(reward, dtype=np.int32)[None, :])
+        return hits[0].astype(np.int16)
+
+    def run(self, system, steps, learning_time=-1):
+        """kbrl_control.py:116-157: same loop, same history arrays and dtypes"""
+        action = self.action
+        SLA_history = np.zeros((steps), dtype=np.int16)
+        reward_history = np.zeros((steps), dtype=np.float64)
+        violation_history = np.zeros((steps), dtype=np.int16)
+        adjusted_actions = np.zeros((steps), dtype=np.int16)
+        resources_history = np.zeros((steps), dtype=np.int16)
+        hits_history = np.zeros((len(action), steps), dtype=np.int16)
+        state = system.reset()
+        hits = np.zeros(len(action), dtype=np.int16)
+        for i in range(steps):
+            new_state, reward, _, info = system.step(action)
+            SLA_labels = info['SLA_labels']
+            if learning_time < steps:
+                hits = self.update_control(state, action, SLA_labels)
+            action, self.adjusted = self.select_action(new_state)
+            state = new_state
+            SLA_history[i] = SLA_labels.sum()
+            reward_history[i] = reward
+            violation_history[i] = info['total_violations']
+            resources_history[i] = action.sum()
+            adjusted_actions[i] = self.adjusted
+            hits_history[:, i] = hits
+        print('mean resources = {}'.format(resources_history.mean()))
+        print('total violations = {}'.format(violation_history.sum()))
+        print('mean adjusted = {}'.format(adjusted_actions.mean()))
+        print('mean accuracy = {}'.format(hits_history.mean(axis=1)))
+        return {'reward': reward_history, 'resources': resources_history, 'hits': hits_history,
+                'adjusted': adjusted_actions, 'SLA': SLA_history, 'violation': violation_history}

@@ -3,18 +3,24 @@ missing or no GPU is usable: there is NO CPU fallback in the product path."""
 import ctypes as C
 import os
 
-from .config import RsConfig
+from .config import RsConfig, KbConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libranslice.so')
 
 RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
 
+KB_EXPORTS = (
+    'kb_create', 'kb_destroy', 'kb_last_error', 'kb_reset', 'kb_update_control', 'kb_select_action',
+    'kb_step_resident', 'kb_predict', 'kb_update', 'kb_get_learner', 'kb_get_control', 'kb_set_adjusted',
+    'kb_get_stats', 'kb_kernel_time_ms', 'kb_set_kernel_timing', 'kb_synchronize',
+)
+
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
     'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_kernel_time_ms',
     'rs_set_kernel_timing', 'rs_synchronize', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
-)
+) + KB_EXPORTS
 
 
 class RanSliceError(RuntimeError):
@@ -57,8 +63,27 @@ def load():
     L.rs_last_error.restype = C.c_char_p
     L.rs_destroy.argtypes = [vp]
     L.rs_destroy.restype = None
+    i64p = C.POINTER(C.c_int64)
+    L.kb_create.argtypes = [C.POINTER(KbConfig), C.c_int, C.POINTER(vp)]
+    L.kb_destroy.argtypes = [vp]
+    L.kb_destroy.restype = None
+    L.kb_last_error.argtypes = [vp]
+    L.kb_last_error.restype = C.c_char_p
+    L.kb_reset.argtypes = [vp, ip, ip, up]
+    L.kb_update_control.argtypes = [vp, fp, ip, ip, ip]
+    L.kb_select_action.argtypes = [vp, fp, ip, ip]
+    L.kb_step_resident.argtypes = [vp, vp]
+    L.kb_predict.argtypes = [vp, C.c_int, C.c_int, dp, ip, dp]
+    L.kb_update.argtypes = [vp, C.c_int, C.c_int, dp, C.c_int32, ip, dp]
+    L.kb_get_learner.argtypes = [vp, C.c_int, C.c_int, ip, dp, dp, dp]
+    L.kb_get_control.argtypes = [vp, ip, ip, ip, ip, dp]
+    L.kb_set_adjusted.argtypes = [vp, ip]
+    L.kb_get_stats.argtypes = [vp, up]
+    L.kb_kernel_time_ms.argtypes = [vp, dp, i64p]
+    L.kb_set_kernel_timing.argtypes = [vp, C.c_int]
+    L.kb_synchronize.argtypes = [vp]
     for name in EXPORTS:
-        if name not in ('rs_last_error', 'rs_destroy'):
+        if name not in ('rs_last_error', 'rs_destroy', 'kb_last_error', 'kb_destroy'):
             getattr(L, name).restype = C.c_int
     _lib = L
     return L

@@ -82,6 +82,21 @@ class RsConfig(C.Structure):
     ]
 
 
+KB_MAX_SLICES = 8
+
+# KBRL learner initialisation (reference scenario_creator.py:185-193, 218; projectron.py:25)
+KBRL_ALFA = 0.05
+EMBB_SEC, EMBB_A = (2, 8), (4, 20)
+MMTC_SEC, MMTC_A = (1, 4), (2, 10)
+KBRL_GAMMA, KBRL_ETA = 1.0, 0.1
+
+
+class KbConfig(C.Structure):
+    _fields_ = [('n_envs', C.c_int32), ('n_slices', C.c_int32), ('n_prbs', C.c_int32), ('capacity', C.c_int32),
+                ('dims', C.c_int32 * KB_MAX_SLICES), ('alfa', C.c_double), ('acc_lo', C.c_double),
+                ('acc_hi', C.c_double), ('gamma', C.c_double), ('eta', C.c_double)]
+
+
 class RsAllocRec(C.Structure):
     _fields_ = [('serial', C.c_int32), ('type', C.c_int32), ('e_snr', C.c_int32), ('prbs', C.c_int32),
                 ('bits', C.c_int64), ('queue', C.c_double), ('th', C.c_double), ('p', C.c_double)]

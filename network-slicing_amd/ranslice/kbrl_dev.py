@@ -1,0 +1,134 @@
+"""VecKBRL: N independent KBRL agents (one per env replica) on one MI355X.
+
+Batched form of the reference's kbrl_control.KBRL_Control (reference kbrl_control.py:23-157): every
+agent keeps its own per-slice Projectron dictionaries on the device; update_control / select_action
+run as HIP kernels (network-slicing_amd/csrc/kb_kbrl.hip) behind the kb_* C ABI.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .config import KbConfig, KBRL_ALFA, KBRL_ETA, KBRL_GAMMA
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_fp = C.POINTER(C.c_float)
+_up = C.POINTER(C.c_uint64)
+
+
+class VecKBRL:
+    def __init__(self, n_envs, dims, n_prbs, alfa=KBRL_ALFA, accuracy_range=(0.99, 0.999), gamma=KBRL_GAMMA,
+                 eta=KBRL_ETA, capacity=1024, device=0):
+        self.L = _lib.load()
+        cfg = KbConfig()
+        cfg.n_envs, cfg.n_slices, cfg.n_prbs, cfg.capacity = n_envs, len(dims), n_prbs, capacity
+        for i, d in enumerate(dims):
+            cfg.dims[i] = int(d)
+        cfg.alfa, cfg.acc_lo, cfg.acc_hi = alfa, accuracy_range[0], accuracy_range[1]
+        cfg.gamma, cfg.eta = gamma, eta
+        self.cfg = cfg
+        self.n_envs, self.S, self.n_prbs, self.dims = n_envs, len(dims), n_prbs, list(dims)
+        self.nv = int(sum(dims))
+        self.capacity = capacity
+        self.h = C.c_void_p()
+        self._check(self.L.kb_create(C.byref(cfg), int(device), C.byref(self.h)))
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self.L.kb_last_error(self.h).decode() if self.h else 'kb_create failed'
+            raise _lib.RanSliceError(rc, msg)
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.kb_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self, initial_action, security_factor, seeds=None):
+        ia = np.ascontiguousarray(initial_action, dtype=np.int32).reshape(self.n_envs, self.S)
+        sf = np.ascontiguousarray(security_factor, dtype=np.int32).reshape(self.n_envs, self.S)
+        if seeds is None:
+            seeds = np.arange(self.n_envs, dtype=np.uint64)
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
+        self._check(self.L.kb_reset(self.h, ia.ctypes.data_as(_ip), sf.ctypes.data_as(_ip), seeds.ctypes.data_as(_up)))
+
+    def update_control(self, state, action, labels):
+        state = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, self.nv)
+        action = np.ascontiguousarray(action, dtype=np.int32).reshape(self.n_envs, self.S)
+        labels = np.ascontiguousarray(labels, dtype=np.int32).reshape(self.n_envs, self.S)
+        hits = np.zeros((self.n_envs, self.S), dtype=np.int32)
+        self._check(self.L.kb_update_control(self.h, state.ctypes.data_as(_fp), action.ctypes.data_as(_ip),
+                                             labels.ctypes.data_as(_ip), hits.ctypes.data_as(_ip)))
+        return hits
+
+    def select_action(self, state):
+        state = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, self.nv)
+        action = np.zeros((self.n_envs, self.S), dtype=np.int32)
+        adjusted = np.zeros(self.n_envs, dtype=np.int32)
+        self._check(self.L.kb_select_action(self.h, state.ctypes.data_as(_fp), action.ctypes.data_as(_ip),
+                                            adjusted.ctypes.data_as(_ip)))
+        return action, adjusted
+
+    def step_resident(self, env):
+        self._check(self.L.kb_step_resident(self.h, env.h))
+
+    def predict(self, e, s, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y, f = C.c_int32(), C.c_double()
+        self._check(self.L.kb_predict(self.h, e, s, x.ctypes.data_as(_dp), C.byref(y), C.byref(f)))
+        return y.value, f.value
+
+    def update(self, e, s, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        br, dl = C.c_int32(), C.c_double()
+        self._check(self.L.kb_update(self.h, e, s, x.ctypes.data_as(_dp), int(y), C.byref(br), C.byref(dl)))
+        return br.value, dl.value
+
+    def learner(self, e, s, with_kinv=False):
+        m = C.c_int32()
+        self._check(self.L.kb_get_learner(self.h, e, s, C.byref(m), None, None, None))
+        m = m.value
+        d = self.dims[s] + 1
+        L = np.zeros((m, d))
+        co = np.zeros(m)
+        kinv = np.zeros((m, m)) if with_kinv else None
+        if m:
+            self._check(self.L.kb_get_learner(self.h, e, s, None, L.ctypes.data_as(_dp), co.ctypes.data_as(_dp),
+                                              kinv.ctypes.data_as(_dp) if with_kinv else None))
+        return dict(m=m, landmarks=L, coeff=co, kinv=kinv)
+
+    def control(self):
+        T = (self.n_envs, self.S)
+        margins, security, action = (np.zeros(T, dtype=np.int32) for _ in range(3))
+        adjusted = np.zeros(self.n_envs, dtype=np.int32)
+        acc = np.zeros(T + (self.n_prbs,))
+        self._check(self.L.kb_get_control(self.h, margins.ctypes.data_as(_ip), security.ctypes.data_as(_ip),
+                                          action.ctypes.data_as(_ip), adjusted.ctypes.data_as(_ip),
+                                          acc.ctypes.data_as(_dp)))
+        return dict(margins=margins, security_factors=security, action=action, adjusted=adjusted, accuracies=acc)
+
+    def set_adjusted(self, adjusted):
+        a = np.ascontiguousarray(adjusted, dtype=np.int32).reshape(self.n_envs)
+        self._check(self.L.kb_set_adjusted(self.h, a.ctypes.data_as(_ip)))
+
+    def stats(self):
+        s = (C.c_uint64 * 4)()
+        self._check(self.L.kb_get_stats(self.h, s))
+        return [int(v) for v in s]
+
+    def set_kernel_timing(self, enable=True):
+        self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))
+
+    def kernel_time_ms(self):
+        ms, n = C.c_double(), C.c_int64()
+        self._check(self.L.kb_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def synchronize(self):
+        self._check(self.L.kb_synchronize(self.h))

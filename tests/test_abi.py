@@ -1,0 +1,61 @@
+"""The C-ABI library loads and exports every symbol include/ranslice.h declares (no GPU needed)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, 'include', 'ranslice.h')).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b((?:rs|kb)_[a-z_0-9]+)\s*\(', text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from ranslice import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('libranslice.so not built (python __graft_entry__.py build)')
+    lib = C.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 30
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert set(_lib.EXPORTS) == set(names)
+
+
+def test_config_struct_matches_header():
+    """field order of the ctypes mirrors == the C structs (guards against silent ABI drift)"""
+    from ranslice.config import RsConfig, KbConfig, RsAllocRec
+    text = open(os.path.join(ROOT, 'include', 'ranslice.h')).read()
+
+    def fields(struct):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), text, flags=re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        out = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r'^(int32_t|int64_t|double|float|uint64_t)\s+', '', decl)
+            for name in decl.split(','):
+                out.append(re.sub(r'\[.*\]', '', name).strip())
+        return out
+    assert fields('rs_config') == [f[0] for f in RsConfig._fields_]
+    assert fields('kb_config') == [f[0] for f in KbConfig._fields_]
+    assert fields('rs_alloc_rec') == [f[0] for f in RsAllocRec._fields_]
+    assert C.sizeof(RsAllocRec) == 48
+
+
+def test_product_has_no_oracle_dependency():
+    """nothing under network-slicing_amd/ may import or link the oracle"""
+    pkg = os.path.join(ROOT, 'network-slicing_amd')
+    for dp, dn, fn in os.walk(pkg):
+        if 'build' in dp:
+            continue
+        for f in fn:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert 'pyoracle' not in src and 'rs_oracle' not in src and 'kb_oracle' not in src, f
