@@ -161,8 +161,10 @@ def main():
     fading = [synth_fading(t, FADING_COLS) for t in range(3)]
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, device=local_rank)
     # replica ids are global: rank r owns [r*n_envs, (r+1)*n_envs)
-    first = rank * n_envs
-    env.reset(seeds=np.arange(first, first + n_envs, dtype=np.uint64))
+    from ranslice.sharding import shard_range, replica_seeds, max_over_ranks, aggregate_throughput
+    first, count = shard_range(world * n_envs, rank, world)
+    assert count == n_envs
+    env.reset(seeds=replica_seeds(0, first, count))
 
     step_idx = 0
 
@@ -195,15 +197,10 @@ def main():
     out = env.fetch()  # also surfaces capacity-overflow errors
     assert np.isfinite(out['reward']).all()
 
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(t1 - t0, device='cuda')
 
     if rank == 0:
-        total_env_steps = world * n_envs * args.steps
-        value = total_env_steps / elapsed
+        value = aggregate_throughput(n_envs * args.steps, world, elapsed)
         # ---- roofline of the dominant kernel (per launch = one step of n_envs replicas)
         samples = (c1[0] - c0[0]) / args.steps          # fading samples read per launch
         ue_slots = (c1[3] - c0[3]) / args.steps

@@ -21,8 +21,9 @@ def main(path):
         for r in c.execute("select distinct name, %s from kernels" % ', '.join(extra)):
             print('  ', r)
     try:
-        pm = c.execute("select k.name, p.counter_name, avg(p.value), sum(p.value), count(*) from pmc_events p "
-                       "join kernels k on k.dispatch_id = p.dispatch_id group by k.name, p.counter_name").fetchall()
+        pm = c.execute("select kernel_name, counter_name, avg(v), sum(v), count(*) from (select kernel_name, "
+                       "counter_name, dispatch_id, sum(value) as v from counters_collection group by 1, 2, 3) "
+                       "group by 1, 2").fetchall()
     except sqlite3.Error as e:
         pm = []
         print('\n# no PMC data (%s)' % e)
