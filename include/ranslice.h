@@ -140,6 +140,9 @@ int rs_get_counters(rs_handle* h, uint64_t counters[4]);
 int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches);
 int rs_set_kernel_timing(rs_handle* h, int enable);
 
+/* Developer aid: cycle sums per code section of the eMBB step kernel (zeros in normal builds). */
+int rs_get_section_profile(rs_handle* h, uint64_t out[8]);
+
 int rs_synchronize(rs_handle* h);
 int rs_n_vars(const rs_handle* h);
 int rs_n_slices(const rs_handle* h);

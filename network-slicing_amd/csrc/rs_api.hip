@@ -26,6 +26,7 @@ struct rs_handle {
     MtcState mst;
     std::vector<void*> allocs;
     double* fad = nullptr;
+    double* emi = nullptr;
     uint8_t* fad_valid = nullptr;
     bool fad_loaded[RS_N_TRACES] = {false, false, false};
     std::vector<double> fad_host[RS_N_TRACES];
@@ -39,6 +40,7 @@ struct rs_handle {
     uint64_t* d_counters = nullptr;   // [n_tasks][4]
     uint64_t* d_counter_sum = nullptr;  // [4]
     rs_alloc_rec* d_trace = nullptr;
+    uint64_t* d_sections = nullptr;
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;
     int32_t clock = 0;     // slots since reset
@@ -306,6 +308,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         d.mcs_ref[m] = cfg->mcs_snr[m];
         d.mcs_x0[m] = cfg->mi_x0[cfg->mcs_mod[m]];
         d.mcs_k[m] = cfg->mi_k[cfg->mcs_mod[m]];
+        d.mcs_mod[m] = cfg->mcs_mod[m];
     }
     d.mtc_n_dev = cfg->mtc_n_devices;
     d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
@@ -338,6 +341,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_info, N * h->n_slices * 10);
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
+    DA(h->d_sections, 8);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -349,6 +353,7 @@ extern "C" void rs_destroy(rs_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fad) (void)hipFree(h->fad);
+    if (h->emi) (void)hipFree(h->emi);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
     if (h->d_trace) (void)hipFree(h->d_trace);
     for (auto& e : h->ev) {
@@ -389,9 +394,25 @@ static int upload_fading(rs_handle* h) {
         return RS_EINVAL;
     }
     if (h->fad) (void)hipFree(h->fad);
+    if (h->emi) (void)hipFree(h->emi);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
     // tail padding so that a subgroup's strided reads never leave the allocation
+    d.emi_stride = (int64_t)(elems + 16);
     HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
+    HIPCHK(h, hipMalloc((void**)&h->emi, sizeof(double) * 3 * (elems + 16)));
+    {
+        // per-modulation tables E = exp(-k_mod * fading) for MCSCodeset.response (see rs_embb.hip)
+        std::vector<double> e;
+        for (int mod = 0; mod < 3; ++mod)
+            for (int f = 0; f < RS_N_TRACES; ++f) {
+                const std::vector<double>& src = h->fad_host[f];
+                e.resize(src.size());
+                const double kk = h->cfg.mi_k[mod];
+                for (size_t i = 0; i < src.size(); ++i) e[i] = rs_exp((-kk) * src[i]);
+                HIPCHK(h, hipMemcpy(h->emi + (size_t)mod * d.emi_stride + d.fad_off[f], e.data(),
+                                    sizeof(double) * e.size(), hipMemcpyHostToDevice));
+            }
+    }
     HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
     for (int f = 0; f < RS_N_TRACES; ++f) {
         HIPCHK(h, hipMemcpyAsync(h->fad + d.fad_off[f], h->fad_host[f].data(), sizeof(double) * h->fad_host[f].size(),
@@ -445,7 +466,7 @@ extern "C" int rs_load_fading(rs_handle* h, int trace_id, const double* data, in
 // ------------------------------------------------------------------ reset / step
 
 static bool fading_ready(const rs_handle* h) {
-    return h->cfg.n_embb == 0 || (h->fad != nullptr && h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]);
+    return h->cfg.n_embb == 0 || (h->fad != nullptr && h->emi != nullptr && h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]);
 }
 
 extern "C" int rs_reset(rs_handle* h, const uint64_t* seeds, float* obs) {
@@ -489,6 +510,7 @@ static int launch_step(rs_handle* h) {
         a.D = h->ddev;
         a.S = h->st;
         a.fad = h->fad;
+        a.emi = h->emi;
         a.fad_valid = h->fad_valid;
         a.actions = h->d_actions;
         a.clock0 = h->clock;
@@ -498,6 +520,7 @@ static int launch_step(rs_handle* h) {
         a.info = h->d_info;
         a.counters = h->d_counters;
         a.trace = h->d_trace;
+        a.sections = h->d_sections;
         const int per_block = 256 / RS_GROUP;
         dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
         hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -637,6 +660,15 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
     HIPCHK(h, hipMemcpyAsync(counters, h->d_counter_sum, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     counters[1] = h->steps * (uint64_t)h->cfg.n_envs;
+    return RS_OK;
+}
+
+// cycle sums per code section of embb_step_kernel; all zero unless built with -DRS_SECTION_PROFILE
+extern "C" int rs_get_section_profile(rs_handle* h, uint64_t out[8]) {
+    if (!h || !out) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sections, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }
 

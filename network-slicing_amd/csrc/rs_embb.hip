@@ -28,6 +28,24 @@
 
 namespace rs {
 
+// Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
+#ifdef RS_SECTION_PROFILE
+#define SEC_DECL unsigned long long sec_t0 = __builtin_amdgcn_s_memtime(), sec_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SEC_MARK(i)                                              \
+    {                                                            \
+        unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
+        sec_acc[i] += t_ - sec_t0;                               \
+        sec_t0 = t_;                                             \
+    }
+#define SEC_FLUSH(buf)                                                                                  \
+    if ((threadIdx.x & 63u) == 0u)                                                                      \
+        for (int i_ = 0; i_ < 8; ++i_) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);
+#else
+#define SEC_DECL
+#define SEC_MARK(i)
+#define SEC_FLUSH(buf)
+#endif
+
 __device__ __forceinline__ int bperm(int v, int src_lane) {
     return __builtin_amdgcn_ds_bpermute(src_lane << 2, v);
 }
@@ -48,29 +66,77 @@ __device__ __forceinline__ unsigned group_ballot(bool c, int gshift) {
     return (unsigned)(__builtin_amdgcn_ballot_w64(c) >> gshift);
 }
 
-template <class T>
-__device__ __forceinline__ T group_sum(T v, int lane) {
-#pragma unroll
-    for (int d = 1; d < RS_GROUP; d <<= 1) v += bperm(v, lane ^ d);
-    return v;
+// ---- cross-lane primitives on DPP (VALU latency) instead of ds_bpermute (LDS latency).
+// DPP controls: quad_perm [1,0,3,2] = 0xB1 (lane^1), [2,3,0,1] = 0x4E (lane^2), row_half_mirror = 0x141
+// (i <-> 7-i inside 8 lanes), row_mirror = 0x140 (i <-> 15-i inside a 16-lane row), row_shr:n = 0x110+n,
+// row_shl:n = 0x100+n, row_bcast:15 = 0x142.  v_permlane16_swap (gfx950) exchanges the two rows of a group.
+#define DPP_XOR1 0xB1
+#define DPP_XOR2 0x4E
+#define DPP_HMIRROR 0x141
+#define DPP_MIRROR 0x140
+#define DPP_BCAST15 0x142
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    uint64_t u = rs_d2u(v);
+    int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
+    return rs_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+
+// sum over the 32 lanes of a group; every lane gets the total.  Used only for exactly representable
+// integers (int, or integer-valued doubles), so the association order is irrelevant.
+__device__ __forceinline__ int group_sum(int v, int lane) {
+    v += dpp_i<DPP_XOR1>(v);
+    v += dpp_i<DPP_XOR2>(v);
+    v += dpp_i<DPP_HMIRROR>(v);
+    v += dpp_i<DPP_MIRROR>(v);
+    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)r[0] + (int)r[1];
+}
+__device__ __forceinline__ double row_swap_partner_combine_add(double v) {
+    uint64_t u = rs_d2u(v);
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
+    double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
+    return a + b;
+}
+__device__ __forceinline__ double group_sum(double v, int lane) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HMIRROR>(v);
+    v += dpp_d<DPP_MIRROR>(v);
+    return row_swap_partner_combine_add(v);
 }
 
 __device__ __forceinline__ double group_max(double v, int lane) {
-#pragma unroll
-    for (int d = 1; d < RS_GROUP; d <<= 1) {
-        double o = bperm(v, lane ^ d);
-        v = o > v ? o : v;
-    }
-    return v;
+    double o;
+    o = dpp_d<DPP_XOR1>(v); v = o > v ? o : v;
+    o = dpp_d<DPP_XOR2>(v); v = o > v ? o : v;
+    o = dpp_d<DPP_HMIRROR>(v); v = o > v ? o : v;
+    o = dpp_d<DPP_MIRROR>(v); v = o > v ? o : v;
+    uint64_t u = rs_d2u(v);
+    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
+    double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
+    return a > b ? a : b;
 }
 
+// exclusive prefix sum over the 32 lanes of a group (Hillis-Steele inside each 16-lane row with
+// row_shr, then the first row's total is added to the second row with row_bcast:15)
 __device__ __forceinline__ int group_excl_scan(int v, int lane, int gl) {
     int inc = v;
-#pragma unroll
-    for (int d = 1; d < RS_GROUP; d <<= 1) {
-        int o = bperm(inc, lane - d);
-        if (gl >= d) inc += o;
-    }
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
+    inc += __builtin_amdgcn_update_dpp(0, inc, DPP_BCAST15, 0xA, 0xF, false);
     return inc - v;
 }
 
@@ -82,25 +148,38 @@ __device__ __forceinline__ int kth_set_bit(unsigned m, int k) {
 
 // numpy pairwise sum of f(0..n-1) evaluated cooperatively by the 8 lanes of a subgroup
 // (lane j == strided accumulator j of numpy's unrolled loop).  Every lane of the subgroup
-// must call it with the same n; all return the same value.  n <= 256.
+// must call it with the same n.  The result is valid in lane 0 of the subgroup (the tree part is
+// valid in all 8 lanes; the sequential remainder is folded towards lane 0 with row_shl:1).  n <= 256.
 template <class F>
 __device__ __forceinline__ double sub8_block(int off, int n, int j, int lane, F f) {
     double res = 0.0;
-    int i0 = 0;
+    const int lim = n >= 8 ? n - (n & 7) : 0;
+    const int rem = n - lim;
+    // the sequential remainder's operand is independent of the tree: fetch it first
+    double v = j < rem ? f(off + lim + j) : 0.0;
     if (n >= 8) {
-        int lim = n - (n & 7);
         double r = f(off + j);
-        for (int i = 8; i < lim; i += 8) r += f(off + i + j);
-        r += bperm(r, lane ^ 1);
-        r += bperm(r, lane ^ 2);
-        r += bperm(r, lane ^ 4);
+        for (int i = 8; i < lim; i += 32) {  // up to four independent fetches in flight, adds in numpy's order
+            const bool p1 = i + 8 < lim, p2 = i + 16 < lim, p3 = i + 24 < lim;
+            double a0 = f(off + i + j);
+            double a1 = p1 ? f(off + i + 8 + j) : 0.0;
+            double a2 = p2 ? f(off + i + 16 + j) : 0.0;
+            double a3 = p3 ? f(off + i + 24 + j) : 0.0;
+            r += a0;
+            if (p1) r += a1;
+            if (p2) r += a2;
+            if (p3) r += a3;
+        }
+        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): each pairing is commutative, so both partners agree
+        r += dpp_d<DPP_XOR1>(r);
+        r += dpp_d<DPP_XOR2>(r);
+        r += dpp_d<DPP_HMIRROR>(r);
         res = r;
-        i0 = lim;
     }
-    int rem = n - i0;
-    double v = j < rem ? f(off + i0 + j) : 0.0;
-    int base = lane & ~7;
-    for (int k = 0; k < rem; ++k) res += bperm(v, base + k);
+    for (int k = 0; k < rem; ++k) {
+        res += v;                 // lane 0: v_k
+        v = dpp_d<0x101>(v);      // row_shl:1: lane i <- lane i+1
+    }
     return res;
 }
 
@@ -158,6 +237,7 @@ struct StepArgs {
     const RsDev* D;
     RsState S;
     const double* fad;        // [trace][time][P]
+    const double* emi;        // [modulation][trace][time][P]: exp(-k_mod * fading), see response below
     const uint8_t* fad_valid; // [trace][time]
     const int32_t* actions;   // [n_envs][n_slices]
     int32_t clock0;           // slots elapsed since reset before this step
@@ -167,10 +247,11 @@ struct StepArgs {
     double* info;             // [n_envs][n_slices][10]
     uint64_t* counters;       // [n_tasks][4]
     rs_alloc_rec* trace;      // [n_tasks][slots][RS_GROUP] or null
+    uint64_t* sections;       // [8] cycle sums per code section (RS_SECTION_PROFILE builds)
 };
 
 template <bool TRACE>
-__global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
     const RsDev* __restrict__ D = A.D;
     const RsState& S = A.S;
     const int lane = (int)(threadIdx.x & 63u);
@@ -263,6 +344,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
     };
 
     const int slots = D->slots;
+    SEC_DECL
     for (int t = 0; t < slots; ++t) {
         const int now = A.clock0 + t + 1;
         const int slot_counter = t + 1;
@@ -363,6 +445,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
         }
 
         const bool is_vbr = (flags & 1) != 0;
+        SEC_MARK(0)
 
         // ================= UE.traffic_step (slice_ran.py:47-49)
         double new_bits = 0.0;
@@ -395,6 +478,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
         }
         const bool any_queue = group_ballot(active && queue > 0.0, gshift) != 0u;
 
+        SEC_MARK(1)
         // ================= channel: get_snr + estimate_snr (channel_models.py:171-191, slice_ran.py:43-45)
         int col = 0;  // element offset of this UE's fading column
         if (n_prb > 0) {
@@ -435,6 +519,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
         }
         cnt_ue += (uint64_t)n_ue;
 
+        SEC_MARK(2)
         // ================= scheduling (slice_l1.py:215-224)
         const bool sched = valid && any_queue && n_prb > 0;
         double p_rx = 0.0;
@@ -453,29 +538,66 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
             for (;;) {
                 const bool more = sched && r < n_prb;
                 if (!wave_any(more)) break;
+#ifdef RS_SECTION_PROFILE
+                sec_acc[7] += 1;  // PF loop trips (not cycles)
+#endif
+                // leader = np.argmax (first maximum) and the best of the rest
                 const double mx = group_max(m, lane);
                 const unsigned eq = group_ballot(m == mx, gshift);
-                const int idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                const int idx = __ffs((int)eq) - 1;
+                const double m_rest = gl == idx ? -2.0 : m;
+                const double m2 = group_max(m_rest, lane);
+                const unsigned eq2 = group_ballot(m_rest == m2, gshift);
+                const int idx2 = __ffs((int)eq2) - 1;
+                int take = 0;
                 if (more) {
                     if (mx == 0.0) {
                         // every queue is empty: argmax of an all-zero metric is UE 0 for all the
                         // remaining RB pairs (Q4); its local th is discarded afterwards
                         if (gl == 0) rbs += n_prb - r;
-                        r = n_prb;
-                    } else {
-                        const int prbs = n_prb - r < gran ? n_prb - r : gran;
-                        if (gl == idx) {
-                            rbs += prbs;
-                            int tx = prbs * rate < q ? prbs * rate : q;
+                    } else if (gl == idx) {
+                        // Only the leader's metric changes while it keeps winning, so the leader's lane
+                        // runs the reference loop alone until it stops being the argmax.
+                        if (m2 <= 0.0) {
+                            // nobody else has data: it wins every RB pair until drained -> closed form
+                            const int R = n_prb - r;
+                            const int per_it = gran * rate;
+                            const int k_full = (q + per_it - 1) / per_it;  // RB pairs needed to drain
+                            const int K = (R + gran - 1) / gran;           // RB pairs left
+                            const bool all = k_full >= K;
+                            const int cap_bits = R * rate;
+                            const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
+                            take = all ? K * gran : k_full * gran;
+                            rbs += all ? R : take;
                             q -= tx;
                             bits += tx;
-                            thl = pf_a * thl + pf_b * (double)bits / slot_len;
-                            m = (q > 0 ? rate_d : 0.0) / thl;
+                            m = 0.0;  // drained, or no RBs left
+                        } else {
+                            int rr = r;
+                            bool keep;
+                            do {
+                                const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
+                                rbs += prbs;
+                                const int tx = prbs * rate < q ? prbs * rate : q;
+                                q -= tx;
+                                bits += tx;
+                                rr += gran;
+                                if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
+                                    thl = pf_a * thl + pf_b * (double)bits / slot_len;
+                                    m = rate_d / thl;
+                                } else {
+                                    m = 0.0;
+                                }
+                                keep = m > m2 || (m == m2 && gl < idx2);
+                            } while (keep && rr < n_prb);
+                            take = rr - r;
                         }
-                        r += gran;
                     }
                 }
+                const int tk = bperm(take, gbase + idx);
+                if (more) r = mx == 0.0 ? n_prb : r + tk;
             }
+            SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
             const int prb_i = group_excl_scan(rbs, lane, gl);
             const unsigned smask = group_ballot(sched && active && rbs > 0, gshift);
@@ -492,16 +614,21 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
                 const double c_nom = bperm(nominal, srcl);
                 double pv = 0.0;
                 if (have) {
-                    const double* __restrict__ base = A.fad + c_off + prb_lo;
+                    // MI of RB i = 1/(1+exp(-k(x_i-x0))) with x_i = fading_i + nominal (channel_models.py:35-37,
+                    // 305-310).  exp(-k(x_i-x0)) is evaluated as E_i * C with E_i = exp(-k fading_i) tabulated
+                    // per modulation when the traces are loaded and C = exp(-k(nominal-x0)) per UE: one
+                    // multiply instead of one exp per RB (differs from the literal form by < 1e-15 relative;
+                    // the oracle evaluates it the same way, so HIP == oracle stays bit-exact).
                     const double x0 = D->mcs_x0[c_mcs], kk = D->mcs_k[c_mcs];
                     double s;
                     if (c_rbs > 1) {
-                        double sum = sub8_pairwise(c_rbs, j8, lane,
-                                                   [&](int i) { return rs_sigmoid(base[i] + c_nom, x0, kk); });
+                        const double* __restrict__ e = A.emi + (int64_t)D->mcs_mod[c_mcs] * D->emi_stride + c_off + prb_lo;
+                        const double Cue = rs_exp((-kk) * (c_nom - x0));
+                        double sum = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return 1.0 / (1.0 + e[i] * Cue); });
                         double avg = sum / (double)c_rbs;
                         s = rs_inv_sigmoid(avg, x0, kk);
                     } else {
-                        s = base[0] + c_nom;
+                        s = A.fad[c_off + prb_lo] + c_nom;
                     }
                     double x = D->mcsA * (s - D->mcs_ref[c_mcs]) - D->mcsB;
                     pv = rs_sigmoid(x, 0.0, 1.0);
@@ -509,6 +636,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
                 const double got = bperm(pv, gbase + ((my_rank & 3) << 3));
                 if (sched && active && rbs > 0 && (my_rank >> 2) == rho) p_rx = got;
             }
+            SEC_MARK(4)
             // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
             if (sched && active) {
                 bool received = false;
@@ -527,6 +655,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
             if (sched) cnt_pf += (uint64_t)((n_prb + gran - 1) / gran);
         }
 
+        SEC_MARK(5)
         // ================= SliceRANeMBB.update_info (slice_ran.py:278-305); Q2: stale bits/prbs count
         if (active) {
             acc_bits += ue_bits;
@@ -548,14 +677,17 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
             packed = group_sum(packed, lane);
             int s_c = (int)(int16_t)(packed & 0xffff);
             int s_v = (packed - s_c) >> 16;
-            double add = 0.0;
-            add = gl == 3 ? q_c / n_c : add;
-            add = gl == 4 ? (double)s_c / n_c : add;
-            add = gl == 8 ? q_v / n_v : add;
-            add = gl == 9 ? (double)s_v / n_v : add;
-            infok += add;
+            // lane 3: cbr_queue, 4: cbr_snr, 8: vbr_queue, 9: vbr_snr -- one IEEE divide per lane
+            double num = 0.0;
+            num = gl == 3 ? q_c : num;
+            num = gl == 4 ? (double)s_c : num;
+            num = gl == 8 ? q_v : num;
+            num = gl == 9 ? (double)s_v : num;
+            const double den = (double)(gl < 5 ? n_c : n_v);
+            infok += num / den;
         }
 
+        SEC_MARK(6)
         if (TRACE) {
             if (valid) {
                 rs_alloc_rec rec;
@@ -572,6 +704,7 @@ __global__ __launch_bounds__(256) void embb_step_kernel(StepArgs A) {
         }
     }
     flush();
+    SEC_FLUSH(A.sections)
 
     // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)
     const double i1 = bperm(infok, gbase + 1), i2 = bperm(infok, gbase + 2), i3 = bperm(infok, gbase + 3);

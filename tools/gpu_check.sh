@@ -1,0 +1,7 @@
+#!/bin/bash
+# quick GPU loop: parity tests then a short bench (used during kernel work)
+python -m pytest tests/test_gpu_parity.py -x -q -m gpu 2>&1 | tail -4
+python bench.py --steps 300 --warmup 30 --burn-in 400 --no-cpu-baseline 2>&1 | tail -1 | python -c "
+import json,sys
+l=json.loads(sys.stdin.readline()); r=l['roofline']
+print('env-steps/s %.0f  ms/step %.3f  kernel_ms %.3f  frac %.4f  mean_ue %.2f' % (l['value'], l['ms_per_step'], r['kernel_ms'], r['frac'], r['mean_ues_per_slice']))"
