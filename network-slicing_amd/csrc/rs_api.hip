@@ -26,7 +26,6 @@ struct rs_handle {
     MtcState mst;
     std::vector<void*> allocs;
     double* fad = nullptr;
-    double* emi = nullptr;
     uint8_t* fad_valid = nullptr;
     bool fad_loaded[RS_N_TRACES] = {false, false, false};
     std::vector<double> fad_host[RS_N_TRACES];
@@ -308,7 +307,6 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         d.mcs_ref[m] = cfg->mcs_snr[m];
         d.mcs_x0[m] = cfg->mi_x0[cfg->mcs_mod[m]];
         d.mcs_k[m] = cfg->mi_k[cfg->mcs_mod[m]];
-        d.mcs_mod[m] = cfg->mcs_mod[m];
     }
     d.mtc_n_dev = cfg->mtc_n_devices;
     d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
@@ -353,7 +351,6 @@ extern "C" void rs_destroy(rs_handle* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fad) (void)hipFree(h->fad);
-    if (h->emi) (void)hipFree(h->emi);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
     if (h->d_trace) (void)hipFree(h->d_trace);
     for (auto& e : h->ev) {
@@ -394,25 +391,9 @@ static int upload_fading(rs_handle* h) {
         return RS_EINVAL;
     }
     if (h->fad) (void)hipFree(h->fad);
-    if (h->emi) (void)hipFree(h->emi);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
     // tail padding so that a subgroup's strided reads never leave the allocation
-    d.emi_stride = (int64_t)(elems + 16);
     HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
-    HIPCHK(h, hipMalloc((void**)&h->emi, sizeof(double) * 3 * (elems + 16)));
-    {
-        // per-modulation tables E = exp(-k_mod * fading) for MCSCodeset.response (see rs_embb.hip)
-        std::vector<double> e;
-        for (int mod = 0; mod < 3; ++mod)
-            for (int f = 0; f < RS_N_TRACES; ++f) {
-                const std::vector<double>& src = h->fad_host[f];
-                e.resize(src.size());
-                const double kk = h->cfg.mi_k[mod];
-                for (size_t i = 0; i < src.size(); ++i) e[i] = rs_exp((-kk) * src[i]);
-                HIPCHK(h, hipMemcpy(h->emi + (size_t)mod * d.emi_stride + d.fad_off[f], e.data(),
-                                    sizeof(double) * e.size(), hipMemcpyHostToDevice));
-            }
-    }
     HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
     for (int f = 0; f < RS_N_TRACES; ++f) {
         HIPCHK(h, hipMemcpyAsync(h->fad + d.fad_off[f], h->fad_host[f].data(), sizeof(double) * h->fad_host[f].size(),
@@ -466,7 +447,7 @@ extern "C" int rs_load_fading(rs_handle* h, int trace_id, const double* data, in
 // ------------------------------------------------------------------ reset / step
 
 static bool fading_ready(const rs_handle* h) {
-    return h->cfg.n_embb == 0 || (h->fad != nullptr && h->emi != nullptr && h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]);
+    return h->cfg.n_embb == 0 || (h->fad != nullptr && h->fad_loaded[0] && h->fad_loaded[1] && h->fad_loaded[2]);
 }
 
 extern "C" int rs_reset(rs_handle* h, const uint64_t* seeds, float* obs) {
@@ -510,7 +491,6 @@ static int launch_step(rs_handle* h) {
         a.D = h->ddev;
         a.S = h->st;
         a.fad = h->fad;
-        a.emi = h->emi;
         a.fad_valid = h->fad_valid;
         a.actions = h->d_actions;
         a.clock0 = h->clock;

@@ -24,7 +24,6 @@ struct RsDev {
     int32_t has_nan;        // any trace column flagged invalid
     int64_t fad_off[3];     // element offset of trace f inside the table buffer
     int64_t valid_off[3];   // byte offset of trace f inside the column-valid buffer
-    int64_t emi_stride;     // elements between the per-modulation exp(-k*fading) tables (same layout as the fading buffer)
     double slot_length;
     double cbr_bits;        // CbrSource packet size = bit_rate * 1e-3 (traffic_generators.py:56-59)
     double cbr_ia_scale, cbr_hold_scale;   // 1/lambda, t_mean (slice_ran.py:208,220)
@@ -38,7 +37,6 @@ struct RsDev {
     int32_t lut_lo, lut_n;  // e_snr -> (mcs, rate) lookup, clamped outside [lut_lo, lut_lo+lut_n)
     int32_t lut_mcs[RS_LUT_MAX], lut_rate[RS_LUT_MAX];
     double mcs_ref[32], mcs_x0[32], mcs_k[32];
-    int32_t mcs_mod[32];
     double penalty;
     // mMTC
     int32_t mtc_n_dev, mtc_cap, mtc_n_rep, mtc_n_period;

@@ -26,6 +26,10 @@
 #include "../../include/rs_philox.h"
 #include "../../include/ranslice.h"
 
+#ifndef RS_ABLATE
+#define RS_ABLATE 0
+#endif
+
 namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
@@ -237,7 +241,6 @@ struct StepArgs {
     const RsDev* D;
     RsState S;
     const double* fad;        // [trace][time][P]
-    const double* emi;        // [modulation][trace][time][P]: exp(-k_mod * fading), see response below
     const uint8_t* fad_valid; // [trace][time]
     const int32_t* actions;   // [n_envs][n_slices]
     int32_t clock0;           // slots elapsed since reset before this step
@@ -252,8 +255,10 @@ struct StepArgs {
 
 template <bool TRACE>
 __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
+    __shared__ double lds_mi[256 / RS_GROUP][RS_MAX_PRBS];  // per-group MI values of the slot's RBs
     const RsDev* __restrict__ D = A.D;
     const RsState& S = A.S;
+    double* const mi = lds_mi[threadIdx.x >> 5];
     const int lane = (int)(threadIdx.x & 63u);
     const int gl = lane & 31;       // UE index owned by this lane
     const int gbase = lane & 32;    // first lane of my group inside the wave
@@ -500,7 +505,12 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
             }
             // four UEs per group at a time, one per 8-lane subgroup
+#if RS_ABLATE == 2
+            if (active) e_snr = 7 + (gl & 3);
+            for (int rho = 0; false; ++rho) {
+#else
             for (int rho = 0; wave_any(rho * 4 < n_ue); ++rho) {
+#endif
                 const int k = rho * 4 + sub;
                 const bool have = k < n_ue;
                 const int srcl = gbase + (have ? k : 0);
@@ -509,7 +519,11 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 int es = 0;
                 if (have) {
                     const double* __restrict__ base = A.fad + c_col + prb_lo;
+#if RS_ABLATE == 5
+                    double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return 0.25 * i + c_nom; });
+#else
                     double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return base[i] + c_nom; });
+#endif
                     es = (int)RS_RINT(sum / (double)n_prb);  // round(np.mean(...)): half-to-even (Q7)
                 }
                 const int got = bperm(es, gbase + ((gl & 3) << 3));
@@ -536,6 +550,10 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
             for (;;) {
+#if RS_ABLATE == 3
+                if (sched && gl == 0) { rbs = n_prb; bits = q < n_prb * rate ? q : n_prb * rate; }
+                break;
+#endif
                 const bool more = sched && r < n_prb;
                 if (!wave_any(more)) break;
 #ifdef RS_SECTION_PROFILE
@@ -600,42 +618,78 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
             const int prb_i = group_excl_scan(rbs, lane, gl);
+            const int prb_end = prb_i + rbs;
             const unsigned smask = group_ballot(sched && active && rbs > 0, gshift);
             const int nsched = __popc(smask);
             const int my_rank = __popc(smask & ((1u << gl) - 1u));
-            // ---- MCSCodeset.response (channel_models.py:297-313), one scheduled UE per subgroup
+            // ---- MCSCodeset.response (channel_models.py:297-313) in three phases.
+#if RS_ABLATE == 1
+            if (sched && active && rbs > 0) p_rx = 0.93;
+#else
+            // R1: mutual information of every allocated RB, one RB per lane (32 per pass); the
+            //     owner UE of RB k is found by walking the (few) scheduled UEs.  Values go to LDS.
+            for (int pass = 0; wave_any(sched && pass * 32 < n_prb); ++pass) {
+                const int k = pass * 32 + gl;
+                const bool inb = sched && k < n_prb;
+                int o_col = 0, o_mcs = 0, o_rbs = 0;
+                double o_nom = 0.0;
+                unsigned mm = smask;
+                while (wave_any(mm != 0u)) {
+                    const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
+                    const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
+                    const int c_u = bperm(col, src), m_u = bperm(mcs, src);
+                    const double nom_u = bperm(nominal, src);
+                    if (mm != 0u && k >= s_u && k < e_u) {
+                        o_col = c_u;
+                        o_mcs = m_u;
+                        o_rbs = e_u - s_u;
+                        o_nom = nom_u;
+                    }
+                    mm &= mm - 1u;
+                }
+                if (inb) {
+#if RS_ABLATE == 4
+                    const double x = 3.0 + 0.01 * k + o_nom;
+#else
+                    const double x = A.fad[o_col + prb_lo + k] + o_nom;
+#endif
+                    // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
+#if RS_ABLATE == 7
+                    mi[k] = 0.5 + 0.001 * x;
+#else
+                    mi[k] = o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x;
+#endif
+                }
+            }
+            // R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup, operands from LDS
+            double sum_rx = 0.0;
             for (int rho = 0; wave_any(rho * 4 < nsched); ++rho) {
                 const int k = rho * 4 + sub;
                 const bool have = k < nsched;
                 const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
                 const int c_rbs = bperm(rbs, srcl);
-                const int c_off = bperm(col + prb_i, srcl);
-                const int c_mcs = bperm(mcs, srcl);
-                const double c_nom = bperm(nominal, srcl);
-                double pv = 0.0;
+                const int c_s = bperm(prb_i, srcl);
+                double sv = 0.0;
                 if (have) {
-                    // MI of RB i = 1/(1+exp(-k(x_i-x0))) with x_i = fading_i + nominal (channel_models.py:35-37,
-                    // 305-310).  exp(-k(x_i-x0)) is evaluated as E_i * C with E_i = exp(-k fading_i) tabulated
-                    // per modulation when the traces are loaded and C = exp(-k(nominal-x0)) per UE: one
-                    // multiply instead of one exp per RB (differs from the literal form by < 1e-15 relative;
-                    // the oracle evaluates it the same way, so HIP == oracle stays bit-exact).
-                    const double x0 = D->mcs_x0[c_mcs], kk = D->mcs_k[c_mcs];
-                    double s;
-                    if (c_rbs > 1) {
-                        const double* __restrict__ e = A.emi + (int64_t)D->mcs_mod[c_mcs] * D->emi_stride + c_off + prb_lo;
-                        const double Cue = rs_exp((-kk) * (c_nom - x0));
-                        double sum = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return 1.0 / (1.0 + e[i] * Cue); });
-                        double avg = sum / (double)c_rbs;
-                        s = rs_inv_sigmoid(avg, x0, kk);
-                    } else {
-                        s = A.fad[c_off + prb_lo] + c_nom;
-                    }
-                    double x = D->mcsA * (s - D->mcs_ref[c_mcs]) - D->mcsB;
-                    pv = rs_sigmoid(x, 0.0, 1.0);
+                    const double* __restrict__ v = mi + c_s;
+                    sv = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return v[i]; });
                 }
-                const double got = bperm(pv, gbase + ((my_rank & 3) << 3));
-                if (sched && active && rbs > 0 && (my_rank >> 2) == rho) p_rx = got;
+                const double got = bperm(sv, gbase + ((my_rank & 3) << 3));
+                if ((my_rank >> 2) == rho) sum_rx = got;
             }
+            // R3: effective SNR and reception probability, every scheduled UE in its own lane
+            if (sched && active && rbs > 0) {
+                const double x0 = D->mcs_x0[mcs], kk = D->mcs_k[mcs];
+                double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
+#if RS_ABLATE == 6
+                p_rx = 0.9 + 1e-6 * sum_rx + 0.0 * x0 * kk;
+#else
+                if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
+                const double x = D->mcsA * (s_eff - D->mcs_ref[mcs]) - D->mcsB;
+                p_rx = rs_sigmoid(x, 0.0, 1.0);
+#endif
+            }
+#endif
             SEC_MARK(4)
             // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
             if (sched && active) {

@@ -75,7 +75,6 @@ struct rs_oracle {
     rso_mmtc* mmtc;
     /* fading tables, device layout [trace][time][prb] */
     double* fad[RS_N_TRACES];
-    double* emi[3][RS_N_TRACES]; /* exp(-k_mod * fading), same layout (see response_tab) */
     uint8_t* fad_valid[RS_N_TRACES];
     int fad_T[RS_N_TRACES];
     int fad_P; /* rows of the (extended) tables */
@@ -224,29 +223,6 @@ static double response(const rs_config* c, double A, double B, int mcs, const do
     return estimate_rx_prob(c, A, B, mcs, s);
 }
 
-/* The env path's form of the same function: exp(-k(x_i - x0)) with x_i = fading_i + nominal is
- * evaluated as E_i * C, E_i = exp(-k fading_i) tabulated per modulation at load time and
- * C = exp(-k (nominal - x0)) per UE.  Identical to `response` up to < 1e-15 relative (hop 1 pins it at
- * 1e-12 on fixture G7); this is the form the HIP kernel uses, bit for bit. */
-static double response_tab(const rs_config* c, double A, double B, int mcs, const double* E, const double* fadcol,
-                           double nominal, int64_t n) {
-    double s;
-    if (n > 1) {
-        int mod = c->mcs_mod[mcs];
-        double x0 = c->mi_x0[mod], k = c->mi_k[mod];
-        double Cue = rs_exp((-k) * (nominal - x0));
-        double mi[1024];
-        double* v = n <= 1024 ? mi : (double*)malloc(sizeof(double) * (size_t)n);
-        for (int64_t i = 0; i < n; ++i) v[i] = 1.0 / (1.0 + E[i] * Cue);
-        double avg = rso_pairwise_sum(v, n) / (double)n;
-        if (v != mi) free(v);
-        s = rs_inv_sigmoid(avg, x0, k);
-    } else {
-        s = fadcol[0] + nominal;
-    }
-    return estimate_rx_prob(c, A, B, mcs, s);
-}
-
 double rso_response(const rs_config* cfg, int mcs, const double* snr, int n) {
     double A, B;
     rso_mcs_factors(&A, &B);
@@ -341,12 +317,6 @@ int rso_load_fading(rs_oracle* o, int trace_id, const double* data, int rows, in
         }
         o->fad_valid[trace_id][t] = (uint8_t)!bad;
     }
-    for (int mod = 0; mod < 3; ++mod) {
-        free(o->emi[mod][trace_id]);
-        o->emi[mod][trace_id] = (double*)malloc(sizeof(double) * (size_t)P * (size_t)cols);
-        for (size_t i = 0; i < (size_t)P * (size_t)cols; ++i)
-            o->emi[mod][trace_id][i] = rs_exp((-o->cfg.mi_k[mod]) * o->fad[trace_id][i]);
-    }
     return RS_OK;
 }
 
@@ -434,7 +404,7 @@ void rso_vbr_source(const rs_config* cfg, const double* gexp, int64_t n_gexp, in
 /* ProportionalFair.allocate (schedulers.py:21-76).  snr_col[i] points at the UE's fading column
  * (full PRB axis), the slice occupies [prb_lo, prb_lo+n_prb). */
 static void pf_allocate(rs_oracle* o, const rs_config* c, double A, double B, int n_ues, rso_ue** ues,
-                        const double** snr_col, int prb_lo, int n_prb, int use_tab) {
+                        const double** snr_col, int prb_lo, int n_prb) {
     int64_t ue_rbs[RSO_MAX_UE], ue_queue[RSO_MAX_UE], ue_rate[RSO_MAX_UE], ue_bits[RSO_MAX_UE];
     int ue_mcs[RSO_MAX_UE];
     double ue_th[RSO_MAX_UE];
@@ -471,12 +441,7 @@ static void pf_allocate(rs_oracle* o, const rs_config* c, double A, double B, in
         int64_t prbs = ue_rbs[i];
         u->prbs = prbs;
         u->bits = ue_bits[i];
-        if (prbs && use_tab) {
-            /* env path: column offset inside the trace, same offset in the exp(-k fading) table */
-            const double* fc = snr_col[i] + prb_lo + prb_i;
-            const double* E = o->emi[c->mcs_mod[ue_mcs[i]]][u->ftype] + (fc - o->fad[u->ftype]);
-            u->p = response_tab(c, A, B, ue_mcs[i], E, fc, u->nominal, prbs);
-        } else if (prbs) {
+        if (prbs) {
             double sn[1024];
             double* v = prbs <= 1024 ? sn : (double*)malloc(sizeof(double) * (size_t)prbs);
             for (int64_t k = 0; k < prbs; ++k) v[k] = snr_col[i][prb_lo + prb_i + k] + u->nominal;
@@ -504,7 +469,7 @@ void rso_pf_allocate(const rs_config* cfg, int n_ue, int n_prb, const double* th
         ptr[i] = &us[i];
         cols[i] = snr + (size_t)i * n_prb;
     }
-    pf_allocate(NULL, cfg, A, B, n_ue, ptr, cols, 0, n_prb, 0);
+    pf_allocate(NULL, cfg, A, B, n_ue, ptr, cols, 0, n_prb);
     for (int i = 0; i < n_ue; ++i) {
         prbs[i] = us[i].prbs;
         bits[i] = us[i].bits;
@@ -645,7 +610,7 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
     /* ---- scheduling and transmission (slice_l1.py:215-224); Q2: skipped -> stale bits/prbs */
     int scheduled = queued_data > 0 && e->n_prbs > 0;
     if (scheduled) {
-        pf_allocate(o, c, o->mcsA, o->mcsB, e->n_ue, ptr, col, e->prb_lo, e->n_prbs, 1);
+        pf_allocate(o, c, o->mcsA, o->mcsB, e->n_ue, ptr, col, e->prb_lo, e->n_prbs);
         double b = 1.0 / c->pf_window, a = 1 - b; /* UE.__init__: b = 1/window, a = 1-b */
         for (int i = 0; i < e->n_ue; ++i) {
             rso_ue* u = &e->ue[i];
@@ -826,7 +791,6 @@ void rso_destroy(rs_oracle* o) {
     for (int t = 0; t < RS_N_TRACES; ++t) {
         free(o->fad[t]);
         free(o->fad_valid[t]);
-        for (int mod = 0; mod < 3; ++mod) free(o->emi[mod][t]);
     }
     free(o);
 }
