@@ -40,6 +40,8 @@ struct rs_handle {
     uint64_t* d_counter_sum = nullptr;  // [4]
     rs_alloc_rec* d_trace = nullptr;
     uint64_t* d_sections = nullptr;
+    int32_t* d_redo = nullptr;   // [n_tasks] tasks the fast (G < 32) launch handed to the G = 32 replay
+    int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;
     int32_t clock = 0;     // slots since reset
@@ -340,6 +342,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
     DA(h->d_sections, 8);
+    DA(h->d_redo, T ? T : 1);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -501,8 +504,8 @@ static int launch_step(rs_handle* h) {
         a.counters = h->d_counters;
         a.trace = h->d_trace;
         a.sections = h->d_sections;
-        const int per_block = 256 / RS_GROUP;
-        dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
+        a.redo = h->d_redo;
+        a.replay = 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -516,10 +519,28 @@ static int launch_step(rs_handle* h) {
             h->ev_used++;
             HIPCHK(h, hipEventRecord(e0, h->stream));
         }
-        if (h->trace_on)
-            hipLaunchKernelGGL(embb_step_kernel<true>, grid, block, 0, h->stream, a);
-        else
-            hipLaunchKernelGGL(embb_step_kernel<false>, grid, block, 0, h->stream, a);
+        auto launch = [&](int g) {
+            const int per_block = 256 / g;
+            dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
+            const bool tr = h->trace_on;
+            if (g == 8) {
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<8, false>), grid, block, 0, h->stream, a);
+            } else if (g == 16) {
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<16, false>), grid, block, 0, h->stream, a);
+            } else {
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<32, false>), grid, block, 0, h->stream, a);
+            }
+        };
+        // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
+        // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)
+        launch(h->group);
+        if (h->group < 32) {
+            a.replay = 1;
+            launch(32);
+        }
         if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
     }
     if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
@@ -640,6 +661,13 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
     HIPCHK(h, hipMemcpyAsync(counters, h->d_counter_sum, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     counters[1] = h->steps * (uint64_t)h->cfg.n_envs;
+    return RS_OK;
+}
+
+// Lanes per task of the primary eMBB launch (8, 16 or 32).  Results do not depend on it.
+extern "C" int rs_set_group_size(rs_handle* h, int lanes) {
+    if (!h || (lanes != 8 && lanes != 16 && lanes != 32)) return RS_EINVAL;
+    h->group = lanes;
     return RS_OK;
 }
 

@@ -10,8 +10,13 @@
 //   SINRSelectiveFading / MCSCodeset / macro_cell   channel_models.py
 //   CbrSource / VbrSource      traffic_generators.py
 //
-// Mapping to the machine: a 32-lane half-wave owns one (replica, slice) task for the whole
-// step, lane u = UE u; state sits in VGPRs for all 50 slots and touches HBM once in, once out.
+// Mapping to the machine: a G-lane group (G = 8, 16 or 32; 64/G tasks per wavefront) owns one
+// (replica, slice) task for the whole step, lane u = UE u; state sits in VGPRs for all 50 slots and
+// touches HBM once in, once out.  The path is bound by the latency of dependent f64 chains (divide
+// ~125, exp ~550, log ~900 cycles; tools/ubench), so throughput scales with tasks per wave: the
+// primary launch uses G = 8 and a task that needs more than 8 UE lanes (about 1 % of task-steps at
+// the reference's load) leaves its state untouched, raises a redo flag and is replayed by the G = 32
+// instance of the same kernel -- identical arithmetic, so results do not depend on G.
 // The only HBM traffic inside the loop is the fading table: a UE's per-slot column
 // [time][PRB] is contiguous, and is summed by an 8-lane subgroup in numpy's pairwise order
 // (8 strided accumulators == 8 lanes), four UEs per group at a time.  The PF loop is the
@@ -25,10 +30,6 @@
 #include "rs_device.h"
 #include "../../include/rs_philox.h"
 #include "../../include/ranslice.h"
-
-#ifndef RS_ABLATE
-#define RS_ABLATE 0
-#endif
 
 namespace rs {
 
@@ -65,15 +66,11 @@ __device__ __forceinline__ double bperm(double v, int src_lane) {
 
 __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0ull; }
 
-// ballot restricted to this lane's 32-lane group
-__device__ __forceinline__ unsigned group_ballot(bool c, int gshift) {
-    return (unsigned)(__builtin_amdgcn_ballot_w64(c) >> gshift);
-}
-
 // ---- cross-lane primitives on DPP (VALU latency) instead of ds_bpermute (LDS latency).
 // DPP controls: quad_perm [1,0,3,2] = 0xB1 (lane^1), [2,3,0,1] = 0x4E (lane^2), row_half_mirror = 0x141
 // (i <-> 7-i inside 8 lanes), row_mirror = 0x140 (i <-> 15-i inside a 16-lane row), row_shr:n = 0x110+n,
-// row_shl:n = 0x100+n, row_bcast:15 = 0x142.  v_permlane16_swap (gfx950) exchanges the two rows of a group.
+// row_shl:n = 0x100+n, row_bcast:15 = 0x142.  v_permlane16_swap (gfx950) exchanges the two rows of a
+// 32-lane group.  A group of G lanes never straddles a row boundary for G <= 16.
 #define DPP_XOR1 0xB1
 #define DPP_XOR2 0x4E
 #define DPP_HMIRROR 0x141
@@ -92,55 +89,70 @@ __device__ __forceinline__ double dpp_d(double v) {
     return rs_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
 }
 
-// sum over the 32 lanes of a group; every lane gets the total.  Used only for exactly representable
+// ballot restricted to this lane's G-lane group (bit u = lane u of the group)
+template <int G>
+__device__ __forceinline__ unsigned group_ballot(bool c, int gbase) {
+    const unsigned long long b = __builtin_amdgcn_ballot_w64(c) >> gbase;
+    return G == 32 ? (unsigned)b : ((unsigned)b & ((1u << G) - 1u));
+}
+
+// sum over the G lanes of a group; every lane gets the total.  Used only for exactly representable
 // integers (int, or integer-valued doubles), so the association order is irrelevant.
-__device__ __forceinline__ int group_sum(int v, int lane) {
+template <int G>
+__device__ __forceinline__ int group_sum(int v) {
     v += dpp_i<DPP_XOR1>(v);
     v += dpp_i<DPP_XOR2>(v);
     v += dpp_i<DPP_HMIRROR>(v);
-    v += dpp_i<DPP_MIRROR>(v);
-    auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
-    return (int)r[0] + (int)r[1];
+    if (G >= 16) v += dpp_i<DPP_MIRROR>(v);
+    if (G == 32) {
+        auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        v = (int)r[0] + (int)r[1];
+    }
+    return v;
 }
-__device__ __forceinline__ double row_swap_partner_combine_add(double v) {
-    uint64_t u = rs_d2u(v);
-    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-    double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
-    double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
-    return a + b;
-}
-__device__ __forceinline__ double group_sum(double v, int lane) {
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
     v += dpp_d<DPP_XOR1>(v);
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_HMIRROR>(v);
-    v += dpp_d<DPP_MIRROR>(v);
-    return row_swap_partner_combine_add(v);
+    if (G >= 16) v += dpp_d<DPP_MIRROR>(v);
+    if (G == 32) {
+        uint64_t u = rs_d2u(v);
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        v = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]) + rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
+    }
+    return v;
 }
 
-__device__ __forceinline__ double group_max(double v, int lane) {
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
     double o;
     o = dpp_d<DPP_XOR1>(v); v = o > v ? o : v;
     o = dpp_d<DPP_XOR2>(v); v = o > v ? o : v;
     o = dpp_d<DPP_HMIRROR>(v); v = o > v ? o : v;
-    o = dpp_d<DPP_MIRROR>(v); v = o > v ? o : v;
-    uint64_t u = rs_d2u(v);
-    auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
-    auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-    double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
-    double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
-    return a > b ? a : b;
+    if (G >= 16) { o = dpp_d<DPP_MIRROR>(v); v = o > v ? o : v; }
+    if (G == 32) {
+        uint64_t u = rs_d2u(v);
+        auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+        auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+        double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
+        double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
+        v = a > b ? a : b;
+    }
+    return v;
 }
 
-// exclusive prefix sum over the 32 lanes of a group (Hillis-Steele inside each 16-lane row with
-// row_shr, then the first row's total is added to the second row with row_bcast:15)
-__device__ __forceinline__ int group_excl_scan(int v, int lane, int gl) {
-    int inc = v;
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true);
-    inc += __builtin_amdgcn_update_dpp(0, inc, DPP_BCAST15, 0xA, 0xF, false);
+// exclusive prefix sum over the G lanes of a group: Hillis-Steele with row_shr (sources outside the
+// group masked by lane index), plus row_bcast:15 to carry row 0's total into row 1 when G = 32
+template <int G>
+__device__ __forceinline__ int group_excl_scan(int v, int gl) {
+    int inc = v, t;
+    t = __builtin_amdgcn_update_dpp(0, inc, 0x111, 0xF, 0xF, true); inc += gl >= 1 ? t : 0;
+    t = __builtin_amdgcn_update_dpp(0, inc, 0x112, 0xF, 0xF, true); inc += gl >= 2 ? t : 0;
+    t = __builtin_amdgcn_update_dpp(0, inc, 0x114, 0xF, 0xF, true); inc += gl >= 4 ? t : 0;
+    if (G >= 16) { t = __builtin_amdgcn_update_dpp(0, inc, 0x118, 0xF, 0xF, true); inc += (gl & 15) >= 8 ? t : 0; }
+    if (G == 32) inc += __builtin_amdgcn_update_dpp(0, inc, DPP_BCAST15, 0xA, 0xF, false);
     return inc - v;
 }
 
@@ -251,24 +263,31 @@ struct StepArgs {
     uint64_t* counters;       // [n_tasks][4]
     rs_alloc_rec* trace;      // [n_tasks][slots][RS_GROUP] or null
     uint64_t* sections;       // [8] cycle sums per code section (RS_SECTION_PROFILE builds)
+    int32_t* redo;            // [n_tasks] set by a G < 32 launch for tasks it could not hold; consumed by the G = 32 replay
+    int32_t replay;           // 1: process only tasks whose redo flag is set
 };
 
-template <bool TRACE>
+template <int G, bool TRACE>
 __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
-    __shared__ double lds_mi[256 / RS_GROUP][RS_MAX_PRBS];  // per-group MI values of the slot's RBs
+    constexpr int NSUB = G / 8;                      // 8-lane subgroups per group
+    constexpr int LOG_NSUB = G == 32 ? 2 : (G == 16 ? 1 : 0);
+    constexpr int TPB = 256 / G;                     // tasks per block
+    constexpr int MI_CAP = G == 8 ? 128 : RS_MAX_PRBS;  // RBs a task may hold in this instance (LDS budget)
+    __shared__ double lds_mi[TPB][MI_CAP];           // per-group MI values of the slot's RBs
     const RsDev* __restrict__ D = A.D;
     const RsState& S = A.S;
-    double* const mi = lds_mi[threadIdx.x >> 5];
+    double* const mi = lds_mi[threadIdx.x / G];
     const int lane = (int)(threadIdx.x & 63u);
-    const int gl = lane & 31;       // UE index owned by this lane
-    const int gbase = lane & 32;    // first lane of my group inside the wave
-    const int gshift = gbase;
-    const int sub = gl >> 3;        // 8-lane subgroup inside the group
+    const int gl = lane & (G - 1);       // UE index owned by this lane
+    const int gbase = lane & ~(G - 1);   // first lane of my group inside the wave
+    const int sub = gl >> 3;             // 8-lane subgroup inside the group
     const int j8 = gl & 7;
     const int n_tasks = D->n_envs * D->n_embb;
-    int task = (int)blockIdx.x * (256 / RS_GROUP) + (int)(threadIdx.x >> 5);
-    const bool valid = task < n_tasks;
-    if (!valid) task = n_tasks - 1;
+    int task = (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
+    const bool in_range = task < n_tasks;
+    if (!in_range) task = n_tasks - 1;
+    const bool selected = in_range && (!A.replay || A.redo[task] != 0);
+    if (!wave_any(selected)) return;  // replay launch: nothing flagged in this wave
     const int rep = task / D->n_embb;
     const int sl = task - rep * D->n_embb;
     const int n_slices = D->n_slices;
@@ -281,10 +300,14 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
     int prb_lo = 0;
     for (int q = 0; q < sl; ++q) prb_lo += A.actions[rep * n_slices + q];
     int n_prb = A.actions[rep * n_slices + sl];
-    if (!valid) n_prb = 0;
 
     // ---- load persistent state
-    int n_ue = valid ? S.t_n_ue[task] : 0;
+    int n_ue = selected ? S.t_n_ue[task] : 0;
+    // a G < 32 instance gives up a task that does not fit (more UEs than lanes, or more RBs than its
+    // LDS slice): nothing is written back and the G = 32 replay redoes the whole step for it
+    bool aborted = G < 32 && selected && (n_ue > G || n_prb > MI_CAP);
+    bool valid = selected && !aborted;
+    if (!valid) { n_prb = 0; n_ue = 0; }
     int cbr_at = S.t_cbr_at[task];
     int vbr_at = S.t_vbr_at[task];
     uint32_t sl_ctr = S.t_ctr[task];
@@ -293,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
     int err = 0;
 
-    const int ui = task * RS_GROUP + gl;
+    const int ui = task * RS_GROUP + gl;  // HBM layout keeps 32 UE slots per task whatever G is
     bool active = gl < n_ue;
     double queue = 0.0, th = 0.0, nominal = 0.0;
     int hold_at = RS_NEVER, e_snr = 0, findex = 0, ue_bits = 0, ue_prbs = 0, uvbr_at = RS_NEVER, flags = 0;
@@ -320,6 +343,7 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
 
     // per-step accumulators: lane k (<10) holds info[k] of this slice (slice_ran.py:270-273)
     double infok = 0.0;
+    double infok_hi = 0.0;  // G = 8 only: info[8], info[9] in lanes 0, 1
     // per-UE running sums flushed into info[] by class: traffic, th(bits), prb
     double acc_traffic = 0.0;
     int acc_bits = 0, acc_prbs = 0;
@@ -329,12 +353,12 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
         // SliceRANeMBB.update_info's three integer-valued sums (slice_ran.py:282-285,296-299):
         // exact in f64 whatever the order, so they are accumulated per UE and folded here.
         const bool is_vbr = (flags & 1) != 0;
-        double t_c = group_sum((active && !is_vbr) ? acc_traffic : 0.0, lane);
-        double t_v = group_sum((active && is_vbr) ? acc_traffic : 0.0, lane);
-        int b_c = group_sum((active && !is_vbr) ? acc_bits : 0, lane);
-        int b_v = group_sum((active && is_vbr) ? acc_bits : 0, lane);
-        int p_c = group_sum((active && !is_vbr) ? acc_prbs : 0, lane);
-        int p_v = group_sum((active && is_vbr) ? acc_prbs : 0, lane);
+        double t_c = group_sum<G>((active && !is_vbr) ? acc_traffic : 0.0);
+        double t_v = group_sum<G>((active && is_vbr) ? acc_traffic : 0.0);
+        int b_c = group_sum<G>((active && !is_vbr) ? acc_bits : 0);
+        int b_v = group_sum<G>((active && is_vbr) ? acc_bits : 0);
+        int p_c = group_sum<G>((active && !is_vbr) ? acc_prbs : 0);
+        int p_v = group_sum<G>((active && is_vbr) ? acc_prbs : 0);
         double add = 0.0;
         add = gl == 0 ? t_c : add;
         add = gl == 1 ? (double)b_c : add;
@@ -385,9 +409,24 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 if (n_pend == 0) pend_type0 = 1; else pend_type1 = 1;
                 n_pend += 1;
             }
-            if (n_ue + n_pend > RS_GROUP) {
-                err |= 1;  // RS_EOVERFLOW: UE capacity
-                n_pend = RS_GROUP - n_ue;
+            if (n_ue + n_pend > G) {
+                if (G == 32) {
+                    err |= 1;  // RS_EOVERFLOW: UE capacity
+                    n_pend = G - n_ue;
+                } else {
+                    // does not fit this instance: drop the task here, the G = 32 replay redoes the step
+                    aborted = true;
+                    valid = false;
+                    active = false;
+                    n_pend = 0;
+                    n_ue = 0;
+                    n_prb = 0;
+                    cbr_at = RS_NEVER;
+                    vbr_at = RS_NEVER;
+                    hold_at = RS_NEVER;
+                    uvbr_at = RS_NEVER;
+                    queue = 0.0;
+                }
             }
             const bool is_new = gl >= n_ue && gl < n_ue + n_pend;
             if (is_new) {
@@ -427,7 +466,7 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
         const bool depart = active && hold_at == now;
         if (wave_any(depart)) {
             flush();
-            const unsigned keep = group_ballot(active && !depart, gshift);
+            const unsigned keep = group_ballot<G>(active && !depart, gbase);
             const int n_new = __popc(keep);
             const int src = gbase + kth_set_bit(keep, gl);
             queue = bperm(queue, src);
@@ -481,7 +520,7 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             queue += new_bits;
             acc_traffic += new_bits;
         }
-        const bool any_queue = group_ballot(active && queue > 0.0, gshift) != 0u;
+        const bool any_queue = group_ballot<G>(active && queue > 0.0, gbase) != 0u;
 
         SEC_MARK(1)
         // ================= channel: get_snr + estimate_snr (channel_models.py:171-191, slice_ran.py:43-45)
@@ -504,14 +543,9 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
                 col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
             }
-            // four UEs per group at a time, one per 8-lane subgroup
-#if RS_ABLATE == 2
-            if (active) e_snr = 7 + (gl & 3);
-            for (int rho = 0; false; ++rho) {
-#else
-            for (int rho = 0; wave_any(rho * 4 < n_ue); ++rho) {
-#endif
-                const int k = rho * 4 + sub;
+            // NSUB UEs per group at a time, one per 8-lane subgroup
+            for (int rho = 0; wave_any(rho * NSUB < n_ue); ++rho) {
+                const int k = rho * NSUB + sub;
                 const bool have = k < n_ue;
                 const int srcl = gbase + (have ? k : 0);
                 const int c_col = bperm(col, srcl);
@@ -519,15 +553,11 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 int es = 0;
                 if (have) {
                     const double* __restrict__ base = A.fad + c_col + prb_lo;
-#if RS_ABLATE == 5
-                    double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return 0.25 * i + c_nom; });
-#else
                     double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return base[i] + c_nom; });
-#endif
                     es = (int)RS_RINT(sum / (double)n_prb);  // round(np.mean(...)): half-to-even (Q7)
                 }
-                const int got = bperm(es, gbase + ((gl & 3) << 3));
-                if (active && (gl >> 2) == rho) e_snr = got;
+                const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << 3));
+                if (active && (gl >> LOG_NSUB) == rho) e_snr = got;
             }
             cnt_samples += (uint64_t)n_ue * (uint64_t)n_prb;
         }
@@ -550,22 +580,18 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
             for (;;) {
-#if RS_ABLATE == 3
-                if (sched && gl == 0) { rbs = n_prb; bits = q < n_prb * rate ? q : n_prb * rate; }
-                break;
-#endif
                 const bool more = sched && r < n_prb;
                 if (!wave_any(more)) break;
 #ifdef RS_SECTION_PROFILE
                 sec_acc[7] += 1;  // PF loop trips (not cycles)
 #endif
                 // leader = np.argmax (first maximum) and the best of the rest
-                const double mx = group_max(m, lane);
-                const unsigned eq = group_ballot(m == mx, gshift);
+                const double mx = group_max<G>(m);
+                const unsigned eq = group_ballot<G>(m == mx, gbase);
                 const int idx = __ffs((int)eq) - 1;
                 const double m_rest = gl == idx ? -2.0 : m;
-                const double m2 = group_max(m_rest, lane);
-                const unsigned eq2 = group_ballot(m_rest == m2, gshift);
+                const double m2 = group_max<G>(m_rest);
+                const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
                 const int idx2 = __ffs((int)eq2) - 1;
                 int take = 0;
                 if (more) {
@@ -617,19 +643,16 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             }
             SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
-            const int prb_i = group_excl_scan(rbs, lane, gl);
+            const int prb_i = group_excl_scan<G>(rbs, gl);
             const int prb_end = prb_i + rbs;
-            const unsigned smask = group_ballot(sched && active && rbs > 0, gshift);
+            const unsigned smask = group_ballot<G>(sched && active && rbs > 0, gbase);
             const int nsched = __popc(smask);
-            const int my_rank = __popc(smask & ((1u << gl) - 1u));
+            const int my_rank = __popc(smask & ((1u << gl) - 1u));  // gl <= 31
             // ---- MCSCodeset.response (channel_models.py:297-313) in three phases.
-#if RS_ABLATE == 1
-            if (sched && active && rbs > 0) p_rx = 0.93;
-#else
             // R1: mutual information of every allocated RB, one RB per lane (32 per pass); the
             //     owner UE of RB k is found by walking the (few) scheduled UEs.  Values go to LDS.
-            for (int pass = 0; wave_any(sched && pass * 32 < n_prb); ++pass) {
-                const int k = pass * 32 + gl;
+            for (int pass = 0; wave_any(sched && pass * G < n_prb); ++pass) {
+                const int k = pass * G + gl;
                 const bool inb = sched && k < n_prb;
                 int o_col = 0, o_mcs = 0, o_rbs = 0;
                 double o_nom = 0.0;
@@ -648,23 +671,15 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                     mm &= mm - 1u;
                 }
                 if (inb) {
-#if RS_ABLATE == 4
-                    const double x = 3.0 + 0.01 * k + o_nom;
-#else
                     const double x = A.fad[o_col + prb_lo + k] + o_nom;
-#endif
                     // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
-#if RS_ABLATE == 7
-                    mi[k] = 0.5 + 0.001 * x;
-#else
                     mi[k] = o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x;
-#endif
                 }
             }
             // R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup, operands from LDS
             double sum_rx = 0.0;
-            for (int rho = 0; wave_any(rho * 4 < nsched); ++rho) {
-                const int k = rho * 4 + sub;
+            for (int rho = 0; wave_any(rho * NSUB < nsched); ++rho) {
+                const int k = rho * NSUB + sub;
                 const bool have = k < nsched;
                 const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
                 const int c_rbs = bperm(rbs, srcl);
@@ -674,22 +689,17 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                     const double* __restrict__ v = mi + c_s;
                     sv = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return v[i]; });
                 }
-                const double got = bperm(sv, gbase + ((my_rank & 3) << 3));
-                if ((my_rank >> 2) == rho) sum_rx = got;
+                const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << 3));
+                if ((my_rank >> LOG_NSUB) == rho) sum_rx = got;
             }
             // R3: effective SNR and reception probability, every scheduled UE in its own lane
             if (sched && active && rbs > 0) {
                 const double x0 = D->mcs_x0[mcs], kk = D->mcs_k[mcs];
                 double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
-#if RS_ABLATE == 6
-                p_rx = 0.9 + 1e-6 * sum_rx + 0.0 * x0 * kk;
-#else
                 if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
                 const double x = D->mcsA * (s_eff - D->mcs_ref[mcs]) - D->mcsB;
                 p_rx = rs_sigmoid(x, 0.0, 1.0);
-#endif
             }
-#endif
             SEC_MARK(4)
             // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
             if (sched && active) {
@@ -716,29 +726,42 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             acc_prbs += ue_prbs;
         }
         {
-            const unsigned m_c = group_ballot(active && !is_vbr, gshift);
-            const unsigned m_v = group_ballot(active && is_vbr, gshift);
+            const unsigned m_c = group_ballot<G>(active && !is_vbr, gbase);
+            const unsigned m_v = group_ballot<G>(active && is_vbr, gbase);
             int n_c = __popc(m_c), n_v = __popc(m_v);
             n_c = n_c > 1 ? n_c : 1;
             n_v = n_v > 1 ? n_v : 1;
             double q_c = 0.0, q_v = 0.0;
             if (wave_any(active && queue != 0.0)) {
-                q_c = group_sum((active && !is_vbr) ? queue : 0.0, lane);
-                q_v = group_sum((active && is_vbr) ? queue : 0.0, lane);
+                q_c = group_sum<G>((active && !is_vbr) ? queue : 0.0);
+                q_v = group_sum<G>((active && is_vbr) ? queue : 0.0);
             }
             // both e_snr sums in one integer reduction: |sum| < 2^15 per class
             int packed = active ? (is_vbr ? e_snr * 65536 : e_snr) : 0;
-            packed = group_sum(packed, lane);
+            packed = group_sum<G>(packed);
             int s_c = (int)(int16_t)(packed & 0xffff);
             int s_v = (packed - s_c) >> 16;
             // lane 3: cbr_queue, 4: cbr_snr, 8: vbr_queue, 9: vbr_snr -- one IEEE divide per lane
-            double num = 0.0;
-            num = gl == 3 ? q_c : num;
-            num = gl == 4 ? (double)s_c : num;
-            num = gl == 8 ? q_v : num;
-            num = gl == 9 ? (double)s_v : num;
-            const double den = (double)(gl < 5 ? n_c : n_v);
-            infok += num / den;
+            if (G >= 16) {
+                double num = 0.0;
+                num = gl == 3 ? q_c : num;
+                num = gl == 4 ? (double)s_c : num;
+                num = gl == 8 ? q_v : num;
+                num = gl == 9 ? (double)s_v : num;
+                const double den = (double)(gl < 5 ? n_c : n_v);
+                infok += num / den;
+            } else {
+                // lanes 3, 4 take the CBR quotients, lanes 0, 1 (second register) the VBR ones
+                double num = 0.0;
+                num = gl == 3 ? q_c : num;
+                num = gl == 4 ? (double)s_c : num;
+                num = gl == 0 ? q_v : num;
+                num = gl == 1 ? (double)s_v : num;
+                const double den = (double)(gl >= 3 ? n_c : n_v);
+                const double quo = num / den;
+                if (gl == 3 || gl == 4) infok += quo;
+                if (gl == 0 || gl == 1) infok_hi += quo;
+            }
         }
 
         SEC_MARK(6)
@@ -753,7 +776,12 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
                 rec.queue = active ? queue : 0.0;
                 rec.th = active ? th : 0.0;
                 rec.p = (active && sched) ? p_rx : 0.0;
-                A.trace[((size_t)task * slots + t) * RS_GROUP + gl] = rec;
+                rs_alloc_rec* row = A.trace + ((size_t)task * slots + t) * RS_GROUP;
+                row[gl] = rec;
+                if (G < 32) {  // the trace always has 32 entries per slot: clear the ones this instance has no lane for
+                    rs_alloc_rec zero = {};
+                    for (int e2 = gl + G; e2 < RS_GROUP; e2 += G) row[e2] = zero;
+                }
             }
         }
     }
@@ -762,11 +790,19 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
 
     // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)
     const double i1 = bperm(infok, gbase + 1), i2 = bperm(infok, gbase + 2), i3 = bperm(infok, gbase + 3);
-    const double i6 = bperm(infok, gbase + 6), i7 = bperm(infok, gbase + 7), i8 = bperm(infok, gbase + 8);
+    const double i6 = bperm(infok, gbase + 6), i7 = bperm(infok, gbase + 7);
+    // info[8], info[9] live in lanes 8, 9: a G = 8 group keeps them in lanes 0, 1 of a second register
+    const double i8 = G >= 16 ? bperm(infok, gbase + 8) : bperm(infok_hi, gbase + 0);
+    const unsigned e_any = group_ballot<G>(err != 0, gbase);
+    if (selected && gl == 0) A.redo[task] = aborted ? 1 : 0;
     if (valid) {
-        if (gl < RS_N_EMBB_VARS) {
+        if (gl < RS_N_EMBB_VARS && gl < G) {
             A.obs[(size_t)rep * D->n_vars + sl * RS_N_EMBB_VARS + gl] = (float)(infok / D->norm[gl]);
             A.info[((size_t)rep * n_slices + sl) * 10 + gl] = infok;
+        }
+        if (G == 8 && gl < 2) {
+            A.obs[(size_t)rep * D->n_vars + sl * RS_N_EMBB_VARS + 8 + gl] = (float)(infok_hi / D->norm[8 + gl]);
+            A.info[((size_t)rep * n_slices + sl) * 10 + 8 + gl] = infok_hi;
         }
         if (gl == 0) {
             const double obs_time = slots * slot_len;
@@ -784,9 +820,8 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             c[0] += cnt_samples;
             c[2] += cnt_pf;
             c[3] += cnt_ue;
+            if (e_any != 0u) atomicOr(&S.err[rep], 1);
         }
-        const unsigned e = group_ballot(err != 0, gshift);
-        if (gl == 0 && (e != 0u || err != 0)) atomicOr(&S.err[rep], 1);
         if (active) {
             S.u_queue[ui] = queue;
             S.u_th[ui] = th;
@@ -803,8 +838,6 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
 #pragma unroll
             for (int k = 0; k < RS_BURSTS; ++k) S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = burst[k];
         }
-    } else {
-        (void)group_ballot(err != 0, gshift);
     }
 }
 

@@ -109,6 +109,10 @@ class VecRanSlice:
         self._check(self.L.rs_get_info(self.h, info.ctypes.data_as(_dp)))
         return info
 
+    def set_group_size(self, lanes):
+        """lanes per task of the primary step launch (8, 16, 32); results do not depend on it"""
+        self._check(self.L.rs_set_group_size(self.h, int(lanes)))
+
     def set_alloc_trace(self, enable=True):
         self._check(self.L.rs_set_alloc_trace(self.h, int(bool(enable))))
 

@@ -43,12 +43,14 @@ def _actions(rng, n_envs, n_slices, n_prbs, step):
     return a.astype(np.int32)
 
 
-def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None):
+def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None, group=None):
     from ranslice.vec_env import VecRanSlice
     cfg = make_config(scenario, n_envs=n_envs)
     if churn:
         _churn(cfg)
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, seed=seed0)
+    if group is not None:
+        env.set_group_size(group)
     if check_trace:
         env.set_alloc_trace(True)
     obs0 = env.reset()
@@ -94,9 +96,47 @@ def test_scenario0_small_trace(golden_dir):
     _compare(0, n_envs=24, steps=8, fading=_small_fading(golden_dir), churn=False, seed0=1)
 
 
-def test_scenario0_churn(golden_dir):
-    """arrivals, admission control, departures, compaction, VBR bursts all fire within a few steps"""
-    _compare(0, n_envs=40, steps=30, fading=_small_fading(golden_dir), churn=True, seed0=1000)
+@pytest.mark.parametrize('group', [8, 16, 32])
+def test_scenario0_churn(golden_dir, group):
+    """arrivals, admission control, departures, compaction, VBR bursts all fire within a few steps;
+    with 8 or 16 lanes per task some slices outgrow the fast instance and are replayed by the 32-lane
+    one -- results must not depend on the group size"""
+    _compare(0, n_envs=40, steps=30, fading=_small_fading(golden_dir), churn=True, seed0=1000, group=group)
+
+
+def test_crowded_slices_replay(golden_dir):
+    """heavy arrival rate: most slices hold more than 8 UEs, so the replay path carries the batch"""
+    from ranslice.vec_env import VecRanSlice
+    fading = _small_fading(golden_dir)
+
+    def cfgf(n):
+        c = _churn(make_config(0, n_envs=n))
+        c.cbr_lambda, c.vbr_lambda, c.cbr_t_mean, c.vbr_t_mean = 8.0, 18.0, 0.8, 0.8
+        return c
+    envs = {}
+    for g in (8, 32):
+        e = VecRanSlice(n_envs=12, cfg=cfgf(12), fading=fading, seed=3)
+        e.set_group_size(g)
+        e.reset()
+        envs[g] = e
+    o = po.OracleEnv(cfgf(1), fading)
+    o.set_seed(3 + 5)
+    o.reset()
+    rng = np.random.default_rng(1)
+    peak = 0
+    for i in range(20):
+        acts = _actions(rng, 12, 5, 200, i)
+        a = envs[8].step(acts)
+        b = envs[32].step(acts)
+        assert a[0].tobytes() == b[0].tobytes() and (a[1] == b[1]).all()
+        assert envs[8].l1_info().tobytes() == envs[32].l1_info().tobytes()
+        out = o.step(acts[5])
+        assert a[0][5].tobytes() == out['obs'].tobytes()
+        peak = max(peak, envs[8].counters()[3])
+    assert envs[8].counters() == envs[32].counters()
+    assert envs[8].counters()[3] / (20 * 50 * 12 * 5) > 8.0, 'test should crowd the slices beyond 8 UEs'
+    for e in envs.values():
+        e.close()
 
 
 @pytest.mark.parametrize('scenario', [1, 2, 3])
