@@ -187,13 +187,23 @@ RS_HD double rs_acos(double x) {
 
 /* logistic 1/(1+exp(-k (x - x0))) with the reference's operation order
  * (channel_models.py:35-37): y = 1 / (1 + exp((-k) * (x - x0))) */
+/* RS_EXP_CALL / RS_LOG_CALL let a translation unit route the calls below through out-of-line copies
+ * (the HIP kernels do: keeping the polynomial constants out of the caller's loop-long live ranges is
+ * worth more registers than the call costs); the arithmetic is the same function either way. */
+#ifndef RS_EXP_CALL
+#define RS_EXP_CALL rs_exp
+#endif
+#ifndef RS_LOG_CALL
+#define RS_LOG_CALL rs_log
+#endif
+
 RS_HD double rs_sigmoid(double x, double x0, double k) {
-    return 1.0 / (1.0 + rs_exp((-k) * (x - x0)));
+    return 1.0 / (1.0 + RS_EXP_CALL((-k) * (x - x0)));
 }
 
 /* channel_models.py:39-41: x = -(1/k) * log(1/y - 1) + x0 */
 RS_HD double rs_inv_sigmoid(double y, double x0, double k) {
-    return (-(1.0 / k)) * rs_log(1.0 / y - 1.0) + x0;
+    return (-(1.0 / k)) * RS_LOG_CALL(1.0 / y - 1.0) + x0;
 }
 
 #endif /* RS_DETMATH_H */

@@ -246,6 +246,15 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         h->err = "rs_create: unsupported configuration (n_prbs <= 256, max_ue in {0,32}, max_bursts in {0,8})";
         return RS_EINVAL;
     }
+    {
+        // per-UE sums of arrived bits are folded out of order (they must be exactly representable)
+        const double cb = cfg->cbr_bit_rate * 1e-3;
+        if (cb != std::floor(cb) || cfg->vbr_p_size != std::floor(cfg->vbr_p_size) || cb < 0 || cfg->vbr_p_size < 0 ||
+            cb * cfg->slots_per_step > 1e9 || cfg->vbr_p_size * RS_BURSTS * cfg->slots_per_step > 1e9) {
+            h->err = "rs_create: CBR bits per slot and VBR packet size must be non-negative integers (< 1e9 per step)";
+            return RS_EINVAL;
+        }
+    }
     int ndev = 0;
     HIPCHK(h, hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) {

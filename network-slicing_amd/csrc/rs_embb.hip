@@ -28,8 +28,21 @@
 #include <stdint.h>
 
 #include "rs_device.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// out-of-line exp/log for device code (see include/rs_detmath.h, RS_EXP_CALL)
+__device__ double rs_exp_ool(double x);
+__device__ double rs_log_ool(double x);
+#define RS_EXP_CALL rs_exp_ool
+#define RS_LOG_CALL rs_log_ool
+#endif
 #include "../../include/rs_philox.h"
 #include "../../include/ranslice.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __noinline__ double rs_exp_ool(double x) { return rs_exp(x); }
+__device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
+#endif
 
 namespace rs {
 
@@ -268,7 +281,7 @@ struct StepArgs {
 };
 
 template <int G, bool TRACE>
-__global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
     constexpr int NSUB = G / 8;                      // 8-lane subgroups per group
     constexpr int LOG_NSUB = G == 32 ? 2 : (G == 16 ? 1 : 0);
     constexpr int TPB = 256 / G;                     // tasks per block
@@ -649,31 +662,48 @@ __global__ __launch_bounds__(256, 3) void embb_step_kernel(StepArgs A) {
             const int nsched = __popc(smask);
             const int my_rank = __popc(smask & ((1u << gl) - 1u));  // gl <= 31
             // ---- MCSCodeset.response (channel_models.py:297-313) in three phases.
-            // R1: mutual information of every allocated RB, one RB per lane (32 per pass); the
-            //     owner UE of RB k is found by walking the (few) scheduled UEs.  Values go to LDS.
-            for (int pass = 0; wave_any(sched && pass * G < n_prb); ++pass) {
-                const int k = pass * G + gl;
-                const bool inb = sched && k < n_prb;
-                int o_col = 0, o_mcs = 0, o_rbs = 0;
-                double o_nom = 0.0;
+            // R1: mutual information of every allocated RB.  Each lane takes KR RBs per pass (G*KR RBs per
+            //     group-pass); the owner UE of an RB is found by walking the (few) scheduled UEs once for all
+            //     KR positions, then the KR sigmoid chains run independently (the path is latency bound, so
+            //     instruction-level parallelism is what pays).  Values go to LDS.
+            constexpr int KR = 1;
+            for (int pass = 0; wave_any(sched && pass * G * KR < n_prb); ++pass) {
+                int o_col[KR], o_mcs[KR], o_rbs[KR];
+                double o_nom[KR];
+#pragma unroll
+                for (int z = 0; z < KR; ++z) { o_col[z] = 0; o_mcs[z] = 0; o_rbs[z] = 0; o_nom[z] = 0.0; }
+                const int k0 = pass * G * KR + gl;
                 unsigned mm = smask;
                 while (wave_any(mm != 0u)) {
                     const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
                     const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
                     const int c_u = bperm(col, src), m_u = bperm(mcs, src);
                     const double nom_u = bperm(nominal, src);
-                    if (mm != 0u && k >= s_u && k < e_u) {
-                        o_col = c_u;
-                        o_mcs = m_u;
-                        o_rbs = e_u - s_u;
-                        o_nom = nom_u;
+#pragma unroll
+                    for (int z = 0; z < KR; ++z) {
+                        const int k = k0 + z * G;
+                        if (mm != 0u && k >= s_u && k < e_u) {
+                            o_col[z] = c_u;
+                            o_mcs[z] = m_u;
+                            o_rbs[z] = e_u - s_u;
+                            o_nom[z] = nom_u;
+                        }
                     }
                     mm &= mm - 1u;
                 }
-                if (inb) {
-                    const double x = A.fad[o_col + prb_lo + k] + o_nom;
-                    // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
-                    mi[k] = o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x;
+                double xv[KR];
+#pragma unroll
+                for (int z = 0; z < KR; ++z) {
+                    const int k = k0 + z * G;
+                    xv[z] = (sched && k < n_prb) ? A.fad[o_col[z] + prb_lo + k] + o_nom[z] : 0.0;
+                }
+#pragma unroll
+                for (int z = 0; z < KR; ++z) {
+                    const int k = k0 + z * G;
+                    if (sched && k < n_prb) {
+                        // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
+                        mi[k] = o_rbs[z] > 1 ? rs_sigmoid(xv[z], D->mcs_x0[o_mcs[z]], D->mcs_k[o_mcs[z]]) : xv[z];
+                    }
                 }
             }
             // R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup, operands from LDS
