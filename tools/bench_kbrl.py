@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""BASELINE config 3: scenario_0, N env replicas on one MI355X with one KBRL agent per replica, closed loop
+entirely on the device (kb_step_resident + rs_step_resident).  Reports env-steps/s with the agent in the loop,
+kernel evaluations/s of the RBF scoring (kb_get_stats[3]) and the device time of the agent kernels.
+
+  python tools/bench_kbrl.py [--envs 4096] [--steps 300] [--warmup 100] [--capacity 256]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
+import numpy as np  # noqa: E402
+from ranslice.config import make_config, EMBB_A, EMBB_SEC  # noqa: E402
+from ranslice.fading import synth_fading  # noqa: E402
+from ranslice.kbrl_dev import VecKBRL  # noqa: E402
+from ranslice.vec_env import VecRanSlice  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--envs', type=int, default=4096)
+    ap.add_argument('--steps', type=int, default=300)
+    ap.add_argument('--warmup', type=int, default=100)
+    ap.add_argument('--capacity', type=int, default=256)
+    args = ap.parse_args()
+    N = args.envs
+    cfg = make_config(0, n_envs=N)
+    env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, 10000) for t in range(3)])
+    agent = VecKBRL(N, [10] * 5, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=args.capacity)
+    rng = np.random.default_rng(0)
+    ia = rng.integers(EMBB_A[0], EMBB_A[1], size=(N, 5)).astype(np.int32)   # scenario_creator.py:220-221
+    sf = rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, 5)).astype(np.int32)
+    env.reset()
+    agent.reset(ia, sf)
+    import ctypes as C
+    env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+
+    def run(k):
+        for _ in range(k):
+            agent.step_resident(env)
+            env.step_resident()
+    run(args.warmup)
+    env.synchronize(); agent.synchronize()
+    s0 = agent.stats()
+    agent.set_kernel_timing(True)
+    env.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    run(args.steps)
+    env.synchronize(); agent.synchronize()
+    dt = time.perf_counter() - t0
+    s1 = agent.stats()
+    kb_ms, kb_n = agent.kernel_time_ms()
+    env_ms, _ = env.kernel_time_ms()
+    out = env.fetch()
+    evals = s1[3] - s0[3]
+    m = [agent.learner(e, s)['m'] for e in range(0, N, max(1, N // 16)) for s in range(5)]
+    print(json.dumps({
+        'config': 'scenario_0, %d envs + KBRL agent per env, closed loop on device, dictionary capacity %d' % (N, args.capacity),
+        'env_steps_per_s': N * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
+        'embb_kernel_ms': env_ms, 'kb_kernel_ms_mean_of_update_and_select': kb_ms, 'kb_launches': kb_n,
+        'kernel_evaluations_per_s': evals / dt, 'predicts_per_env_step': (s1[0] - s0[0]) / (N * args.steps),
+        'mistakes_per_env_step': (s1[1] - s0[1]) / (N * args.steps),
+        'mean_dictionary_size_sample': float(np.mean(m)), 'max_dictionary_size_sample': int(np.max(m)),
+        'mean_action_sum': float(out['actions'].sum(axis=1).mean()),
+        'violations_per_env_step_last': float(out['violations'].sum(axis=1).mean()),
+    }))
+
+
+if __name__ == '__main__':
+    main()
