@@ -1,0 +1,146 @@
+"""Edge cases of the HIP path against the oracle: empty / starved / saturated slices, extreme
+allocations, capacity errors (the reference's behaviour for each is noted)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from ranslice import _lib
+from ranslice.config import make_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _fading(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    return [g['t0'], g['t1'], g['t2']]
+
+
+def _churn(cfg):
+    cfg.cbr_lambda, cfg.cbr_t_mean = 2.0 / 1.2, 0.6
+    cfg.vbr_lambda, cfg.vbr_t_mean = 5.0 / 1.2, 0.6
+    cfg.vbr_b_size, cfg.vbr_b_rate = 40, 12
+    return cfg
+
+
+def _run(cfg_fn, n_envs, action_rows, fading, seed=11, group=None):
+    from ranslice.vec_env import VecRanSlice
+    env = VecRanSlice(n_envs=n_envs, cfg=cfg_fn(n_envs), fading=fading, seed=seed)
+    if group:
+        env.set_group_size(group)
+    env.reset()
+    ors = []
+    for r in range(n_envs):
+        o = po.OracleEnv(cfg_fn(1), fading)
+        o.set_seed(seed + r)
+        o.reset()
+        ors.append(o)
+    for i, acts in enumerate(action_rows):
+        acts = np.ascontiguousarray(np.broadcast_to(acts, (n_envs, len(acts))), dtype=np.int32)
+        obs, rew, _, info = env.step(acts)
+        l1 = env.l1_info()
+        for r, o in enumerate(ors):
+            out = o.step(acts[r])
+            assert obs[r].tobytes() == out['obs'].tobytes(), (i, r)
+            assert rew[r] == out['reward'] and (info['violations'][r] == out['violations']).all()
+            assert l1[r].tobytes() == out['info'].tobytes(), (i, r)
+    env.close()
+
+
+def test_starvation_then_recovery(golden_dir):
+    """all slices get 0 PRBs for a while (reference Q2/Q3: stale e_snr/bits, walker frozen), then everything"""
+    rows = [[0, 0, 0, 0, 0]] * 6 + [[40, 40, 40, 40, 40]] * 3 + [[200, 0, 0, 0, 0], [0, 0, 0, 0, 200], [1, 1, 1, 1, 1]] + \
+           [[0, 0, 0, 0, 0]] * 2 + [[13, 7, 1, 0, 179]] * 3
+    _run(lambda n: _churn(make_config(0, n_envs=n)), 6, rows, _fading(golden_dir))
+
+
+@pytest.mark.parametrize('group', [8, 16, 32])
+def test_one_slice_takes_the_whole_carrier(golden_dir, group):
+    """a 200-PRB slice: numpy's pairwise split above 128 elements, the 8-lane instance's LDS slice (128 RBs)
+    is too small -> replay"""
+    rows = [[200, 0, 0, 0, 0], [0, 199, 1, 0, 0], [129, 0, 71, 0, 0], [128, 72, 0, 0, 0]] * 3
+    _run(lambda n: _churn(make_config(0, n_envs=n)), 5, rows, _fading(golden_dir), group=group)
+
+
+def test_mmtc_only_and_max_prbs(golden_dir):
+    """no eMBB slice at all (no fading needed), and a 256-PRB carrier (the build's maximum)"""
+    rows = [[3, 5], [0, 9], [100, 100], [1, 0]] * 5
+    _run(lambda n: make_config(None, n_envs=n, n_prbs=256, n_embb=0, n_mmtc=2), 4, rows, None)
+    # eMBB carriers wider than 2x the trace's 100 rows cannot be built (the reference's row wrap,
+    # channel_models.py:144-148, only extends to 200): 256 PRBs need traces with >= 128 rows
+    wide = [np.vstack([t, t[:28]]) for t in _fading(golden_dir)]
+    rows = [[256, 0, 0], [100, 100, 56], [3, 250, 3]] * 3
+    _run(lambda n: _churn(make_config(None, n_envs=n, n_prbs=256, n_embb=2, n_mmtc=1)), 3, rows, wide)
+
+
+def test_mmtc_backlog_saturation(golden_dir):
+    """mMTC slices starved for a long time: the FIFO grows, delays rise, SLA is violated; capacity 1024 is
+    eventually exceeded and reported (the reference's numpy arrays would simply keep growing)"""
+    from ranslice.vec_env import VecRanSlice
+    fading = _fading(golden_dir)
+    cfgf = lambda n: make_config(2, n_envs=n)
+    rows = [[20, 0, 0, 1, 0]] * 60
+    _run(cfgf, 2, rows, fading)
+    env = VecRanSlice(n_envs=2, cfg=cfgf(2), fading=fading, seed=1)
+    env.reset()
+    acts = np.array([[20, 0, 0, 0, 0]] * 2, dtype=np.int32)
+    with pytest.raises(_lib.RanSliceError) as ei:
+        for _ in range(400):
+            env.step(acts)
+    assert ei.value.code == _lib.RS_EOVERFLOW
+    env.close()
+
+
+def test_ue_capacity_overflow_is_reported(golden_dir):
+    """arrival rate far beyond the 32-UE capacity -> RS_EOVERFLOW (never a silent drop)"""
+    from ranslice.vec_env import VecRanSlice
+    cfg = make_config(0, n_envs=4)
+    cfg.cbr_lambda, cfg.vbr_lambda, cfg.cbr_t_mean, cfg.vbr_t_mean = 10.0, 200.0, 5.0, 5.0
+    env = VecRanSlice(n_envs=4, cfg=cfg, fading=_fading(golden_dir))
+    env.reset()
+    with pytest.raises(_lib.RanSliceError) as ei:
+        for _ in range(40):
+            env.step(np.full((4, 5), 30, dtype=np.int32))
+    assert ei.value.code == _lib.RS_EOVERFLOW
+    env.close()
+
+
+def test_kbrl_capacity_overflow_is_reported():
+    from ranslice.kbrl_dev import VecKBRL
+    ag = VecKBRL(1, [3], 100, capacity=4)
+    ag.reset([[5]], [[2]])
+    rng = np.random.default_rng(0)
+    with pytest.raises(_lib.RanSliceError) as ei:
+        for i in range(200):
+            x = rng.random(4) * 8.0  # far-apart points: every mistake grows the dictionary
+            y = 1 if i % 2 else -1
+            ag.predict(0, 0, x)
+            ag.update(0, 0, x, y)
+    assert ei.value.code == _lib.RS_EOVERFLOW
+    ag.close()
+
+
+def test_call_order_errors(golden_dir):
+    from ranslice.vec_env import VecRanSlice
+    import ctypes as C
+    L = _lib.load()
+    cfg = make_config(0, n_envs=1)
+    h = C.c_void_p()
+    assert L.rs_create(C.byref(cfg), 0, C.byref(h)) == 0
+    seeds = np.zeros(1, dtype=np.uint64)
+    assert L.rs_reset(h, seeds.ctypes.data_as(C.POINTER(C.c_uint64)), None) == _lib.RS_ESTATE  # fading not loaded
+    assert b'fading' in L.rs_last_error(h)
+    L.rs_destroy(h)
+    env = VecRanSlice(n_envs=1, cfg=make_config(0, n_envs=1), fading=_fading(golden_dir))
+    with pytest.raises(_lib.RanSliceError) as ei:
+        env.step(np.zeros((1, 5), dtype=np.int32))  # step before reset
+    assert ei.value.code == _lib.RS_ESTATE
+    bad = make_config(0, n_envs=1)
+    bad.n_prbs = 300
+    h2 = C.c_void_p()
+    assert L.rs_create(C.byref(bad), 0, C.byref(h2)) == _lib.RS_EINVAL
+    L.rs_destroy(h2)
+    assert L.rs_create(C.byref(cfg), 99, C.byref(h2)) == _lib.RS_EHIP  # no such device
+    L.rs_destroy(h2)
+    env.close()
