@@ -268,7 +268,7 @@ def main():
     tape = rh.Tape()
     rh.install_tape(tape)
     save('fading_small', t0=tabs[0], t1=tabs[1], t2=tabs[2])
-    todo = args.only.split(',') if args.only else ['G1', 'G3', 'G4', 'G6', 'G7', 'G9']
+    todo = args.only.split(',') if args.only else ['G1', 'G3', 'G4', 'G6', 'G7', 'G9', 'G12']
     if 'G1' in todo:
         gen_g1_g2()
     if 'G3' in todo:
@@ -279,6 +279,8 @@ def main():
         gen_g6(tape)
     if 'G7' in todo:
         gen_g7(tape)
+    if 'G12' in todo:
+        gen_g12()
     if 'G9' in todo:
         try:
             import gen_golden_kbrl
@@ -286,6 +288,45 @@ def main():
             print('G9-G11 generator not present yet')
         else:
             gen_golden_kbrl.generate(rh, tape, save)
+
+
+
+def gen_g12():
+    """ReportWrapper's action / observation mapping (wrapper.py:77-89), recorded through the reference class"""
+    import wrapper
+
+    class _Env:
+        n_slices, n_prbs, n_variables = 5, 200, 50
+
+        def __init__(self):
+            self.last = None
+
+        def reset(self):
+            return np.zeros(50, dtype=np.float32)
+
+        def step(self, action):
+            self.last = np.array(action)
+            return self.obs_in, 1.0, False, {'total_violations': 0}
+    import gym
+    gym.Wrapper.__init__ = lambda self, env: setattr(self, 'env', env)
+    gym.Wrapper.__getattr__ = lambda self, name: getattr(self.__dict__['env'], name)
+    import io
+    import contextlib
+    rng = np.random.default_rng(12)
+    env = _Env()
+    with contextlib.redirect_stdout(io.StringIO()):
+        w = wrapper.ReportWrapper(env, steps=64, control_steps=10 ** 9)
+        w.reset()
+        acts, prbs, obs_in, obs_out = [], [], [], []
+        for i in range(48):
+            a = rng.normal(0, 1, 6) if i % 3 else rng.random(6)
+            if i == 7:
+                a = np.zeros(6)
+            env.obs_in = rng.normal(0.5, 1.0, 50).astype(np.float32)
+            o, r, d, inf = w.step(a)
+            acts.append(a); prbs.append(env.last.astype(np.int32)); obs_in.append(env.obs_in); obs_out.append(np.asarray(o))
+    save('g12_report_wrapper', action=np.asarray(acts), prbs=np.asarray(prbs), obs_in=np.asarray(obs_in),
+         obs_out=np.asarray(obs_out))
 
 
 if __name__ == '__main__':
