@@ -281,12 +281,21 @@ struct StepArgs {
 };
 
 template <int G, bool TRACE>
-__global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArgs A) {
     constexpr int NSUB = G / 8;                      // 8-lane subgroups per group
     constexpr int LOG_NSUB = G == 32 ? 2 : (G == 16 ? 1 : 0);
     constexpr int TPB = 256 / G;                     // tasks per block
-    constexpr int MI_CAP = G == 8 ? 128 : RS_MAX_PRBS;  // RBs a task may hold in this instance (LDS budget)
+    constexpr int MI_CAP = G == 32 ? RS_MAX_PRBS : 112;  // RBs a task may hold in this instance (LDS budget)
     __shared__ double lds_mi[TPB][MI_CAP];           // per-group MI values of the slot's RBs
+    // Cold per-UE state lives in LDS (one slot per thread, conflict-free), so that the hot loop keeps few
+    // enough VGPRs for 4-5 resident waves per SIMD.  Timers are absolute slot numbers; `evt_at` (a VGPR)
+    // is the earliest of them, so these arrays are touched only in slots where something happens.
+    __shared__ int L_burst[RS_BURSTS][256];  // VBR burst end times, 0 = free
+    __shared__ int L_hold[256];              // departure time
+    __shared__ int L_uvbr[256];              // next burst arrival of the UE's VBR source
+    __shared__ unsigned L_serial[256], L_ctr[256];
+    __shared__ int L_acc_traf[256], L_acc_bits[256], L_acc_prbs[256];
+    __shared__ double L_nom[256];            // nominal SINR
     const RsDev* __restrict__ D = A.D;
     const RsState& S = A.S;
     double* const mi = lds_mi[threadIdx.x / G];
@@ -295,6 +304,8 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
     const int gbase = lane & ~(G - 1);   // first lane of my group inside the wave
     const int sub = gl >> 3;             // 8-lane subgroup inside the group
     const int j8 = gl & 7;
+    const int tid = (int)threadIdx.x;
+    const int tb = tid - gl;             // first thread of my group in the block
     const int n_tasks = D->n_envs * D->n_embb;
     int task = (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
     const bool in_range = task < n_tasks;
@@ -331,58 +342,76 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
 
     const int ui = task * RS_GROUP + gl;  // HBM layout keeps 32 UE slots per task whatever G is
     bool active = gl < n_ue;
-    double queue = 0.0, th = 0.0, nominal = 0.0;
-    int hold_at = RS_NEVER, e_snr = 0, findex = 0, ue_bits = 0, ue_prbs = 0, uvbr_at = RS_NEVER, flags = 0;
-    uint32_t uctr = 0, userial = 0;
-    int burst[RS_BURSTS];
+    double queue = 0.0, th = 0.0;
+    int e_snr = 0, findex = 0, ue_bits = 0, ue_prbs = 0, flags = 0;
+    int n_act = 0;          // VBR bursts still running when the slot begins
+    int evt_at = RS_NEVER;  // earliest of: departure, next burst arrival, next burst end
+    {
+        int hold_at = RS_NEVER, uvbr_at = RS_NEVER;
+        unsigned uctr = 0u, userial = 0u;
+        double nominal = 0.0;
+        if (active) {
+            queue = S.u_queue[ui];
+            th = S.u_th[ui];
+            nominal = S.u_nominal[ui];
+            hold_at = S.u_hold_at[ui];
+            e_snr = S.u_e_snr[ui];
+            findex = S.u_findex[ui];
+            ue_bits = S.u_bits[ui];
+            ue_prbs = S.u_prbs[ui];
+            uvbr_at = S.u_vbr_at[ui];
+            uctr = S.u_ctr[ui];
+            userial = S.u_serial[ui];
+            flags = S.u_flags[ui];
+        }
+        evt_at = hold_at < uvbr_at ? hold_at : uvbr_at;
 #pragma unroll
-    for (int k = 0; k < RS_BURSTS; ++k) burst[k] = 0;
-    if (active) {
-        queue = S.u_queue[ui];
-        th = S.u_th[ui];
-        nominal = S.u_nominal[ui];
-        hold_at = S.u_hold_at[ui];
-        e_snr = S.u_e_snr[ui];
-        findex = S.u_findex[ui];
-        ue_bits = S.u_bits[ui];
-        ue_prbs = S.u_prbs[ui];
-        uvbr_at = S.u_vbr_at[ui];
-        uctr = S.u_ctr[ui];
-        userial = S.u_serial[ui];
-        flags = S.u_flags[ui];
-#pragma unroll
-        for (int k = 0; k < RS_BURSTS; ++k) burst[k] = S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl];
+        for (int k = 0; k < RS_BURSTS; ++k) {
+            const int e = active ? S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] : 0;
+            L_burst[k][tid] = e;
+            if (e > A.clock0) {
+                n_act += 1;
+                evt_at = e < evt_at ? e : evt_at;
+            }
+        }
+        L_hold[tid] = hold_at;
+        L_uvbr[tid] = uvbr_at;
+        L_serial[tid] = userial;
+        L_ctr[tid] = uctr;
+        L_nom[tid] = nominal;
+        L_acc_traf[tid] = 0;
+        L_acc_bits[tid] = 0;
+        L_acc_prbs[tid] = 0;
     }
 
     // per-step accumulators: lane k (<10) holds info[k] of this slice (slice_ran.py:270-273)
     double infok = 0.0;
     double infok_hi = 0.0;  // G = 8 only: info[8], info[9] in lanes 0, 1
-    // per-UE running sums flushed into info[] by class: traffic, th(bits), prb
-    double acc_traffic = 0.0;
-    int acc_bits = 0, acc_prbs = 0;
-    uint64_t cnt_samples = 0, cnt_pf = 0, cnt_ue = 0;
+    // per-UE running sums (traffic, th(bits), prb) live in L_acc_*; flush() folds them into info[] by class
+    unsigned cnt_samples = 0u, cnt_pf = 0u, cnt_ue = 0u;  // per step: < 2^32
 
     auto flush = [&]() {
         // SliceRANeMBB.update_info's three integer-valued sums (slice_ran.py:282-285,296-299):
         // exact in f64 whatever the order, so they are accumulated per UE and folded here.
         const bool is_vbr = (flags & 1) != 0;
-        double t_c = group_sum<G>((active && !is_vbr) ? acc_traffic : 0.0);
-        double t_v = group_sum<G>((active && is_vbr) ? acc_traffic : 0.0);
+        const int acc_traffic = L_acc_traf[tid], acc_bits = L_acc_bits[tid], acc_prbs = L_acc_prbs[tid];
+        int t_c = group_sum<G>((active && !is_vbr) ? acc_traffic : 0);
+        int t_v = group_sum<G>((active && is_vbr) ? acc_traffic : 0);
         int b_c = group_sum<G>((active && !is_vbr) ? acc_bits : 0);
         int b_v = group_sum<G>((active && is_vbr) ? acc_bits : 0);
         int p_c = group_sum<G>((active && !is_vbr) ? acc_prbs : 0);
         int p_v = group_sum<G>((active && is_vbr) ? acc_prbs : 0);
         double add = 0.0;
-        add = gl == 0 ? t_c : add;
+        add = gl == 0 ? (double)t_c : add;
         add = gl == 1 ? (double)b_c : add;
         add = gl == 2 ? (double)p_c : add;
-        add = gl == 5 ? t_v : add;
+        add = gl == 5 ? (double)t_v : add;
         add = gl == 6 ? (double)b_v : add;
         add = gl == 7 ? (double)p_v : add;
         infok += add;
-        acc_traffic = 0.0;
-        acc_bits = 0;
-        acc_prbs = 0;
+        L_acc_traf[tid] = 0;
+        L_acc_bits[tid] = 0;
+        L_acc_prbs[tid] = 0;
     };
 
     const int slots = D->slots;
@@ -436,8 +465,7 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                     n_prb = 0;
                     cbr_at = RS_NEVER;
                     vbr_at = RS_NEVER;
-                    hold_at = RS_NEVER;
-                    uvbr_at = RS_NEVER;
+                    evt_at = RS_NEVER;
                     queue = 0.0;
                 }
             }
@@ -445,21 +473,23 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
             if (is_new) {
                 const int k = gl - n_ue;
                 const int type = k == 0 ? pend_type0 : pend_type1;
-                userial = next_serial + (uint32_t)k;
+                const unsigned userial = next_serial + (uint32_t)k;
                 rs_stream st = {key0, key1, (uint32_t)sl, userial, 0u};
                 queue = 0.0; th = 0.0; e_snr = 0; ue_bits = 0; ue_prbs = 0;
-                acc_traffic = 0.0; acc_bits = 0; acc_prbs = 0;
+                L_acc_traf[tid] = 0; L_acc_bits[tid] = 0; L_acc_prbs[tid] = 0;
 #pragma unroll
-                for (int q = 0; q < RS_BURSTS; ++q) burst[q] = 0;
-                uvbr_at = RS_NEVER;
+                for (int q = 0; q < RS_BURSTS; ++q) L_burst[q][tid] = 0;
+                n_act = 0;
+                int uvbr_at = RS_NEVER;
                 if (type == 1) {  // VbrSource.__init__ (traffic_generators.py:62-68)
                     int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
                     uvbr_at = v >= 1 ? now + v - 1 : RS_NEVER;  // Q5: 0 never fires
                 }
                 double hold = rs_stream_exponential(&st, type == 0 ? D->cbr_hold_scale : D->vbr_hold_scale);
                 int hv = rint_slots(hold, slot_len);
-                hold_at = hv >= 1 ? now + hv - 1 : RS_NEVER;    // Q5
+                const int hold_at = hv >= 1 ? now + hv - 1 : RS_NEVER;    // Q5
                 int ftype = 0, fstep = 1;
+                double nominal = 0.0;
                 if (hold_at != now) {  // Q13: a one-slot holding time never joins the slice
                     // SINRSelectiveFading.insert_user (channel_models.py:163-169)
                     ftype = (int)rs_stream_integers(&st, RS_N_TRACES);
@@ -467,7 +497,12 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                     fstep = rs_stream_pm1(&st);
                     nominal = macro_cell_draw(D, &st);
                 }
-                uctr = st.ctr;
+                L_hold[tid] = hold_at;
+                L_uvbr[tid] = uvbr_at;
+                L_serial[tid] = userial;
+                L_ctr[tid] = st.ctr;
+                L_nom[tid] = nominal;
+                evt_at = hold_at < uvbr_at ? hold_at : uvbr_at;
                 flags = type | (ftype << 1) | ((fstep > 0 ? 1 : 0) << 3);
                 active = true;
             }
@@ -475,63 +510,92 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
             next_serial += (uint32_t)n_pend;
         }
 
-        // ================= departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191)
-        const bool depart = active && hold_at == now;
-        if (wave_any(depart)) {
-            flush();
-            const unsigned keep = group_ballot<G>(active && !depart, gbase);
-            const int n_new = __popc(keep);
-            const int src = gbase + kth_set_bit(keep, gl);
-            queue = bperm(queue, src);
-            th = bperm(th, src);
-            nominal = bperm(nominal, src);
-            hold_at = bperm(hold_at, src);
-            e_snr = bperm(e_snr, src);
-            findex = bperm(findex, src);
-            ue_bits = bperm(ue_bits, src);
-            ue_prbs = bperm(ue_prbs, src);
-            uvbr_at = bperm(uvbr_at, src);
-            uctr = bperm(uctr, src);
-            userial = bperm(userial, src);
-            flags = bperm(flags, src);
+        // ================= per-UE timer events: departures, VBR burst ends and arrivals
+        int n_cur = n_act;  // bursts that emit in THIS slot (an arrival of this slot starts emitting next slot)
+        if (wave_any(active && evt_at == now)) {
+            // ---- departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191)
+            const bool depart = active && evt_at == now && L_hold[tid] == now;
+            if (wave_any(depart)) {
+                flush();
+                const unsigned keep = group_ballot<G>(active && !depart, gbase);
+                const int n_new = __popc(keep);
+                const int su = kth_set_bit(keep, gl);
+                const int src = gbase + su;
+                queue = bperm(queue, src);
+                th = bperm(th, src);
+                e_snr = bperm(e_snr, src);
+                findex = bperm(findex, src);
+                ue_bits = bperm(ue_bits, src);
+                ue_prbs = bperm(ue_prbs, src);
+                flags = bperm(flags, src);
+                n_act = bperm(n_act, src);
+                evt_at = bperm(evt_at, src);
+                // LDS-resident fields: every lane reads its source slot, then all write (in-order LDS)
+                const int st_ = tb + su;
+                const int m_hold = L_hold[st_], m_uvbr = L_uvbr[st_];
+                const unsigned m_ser = L_serial[st_], m_ctr = L_ctr[st_];
+                const double m_nom = L_nom[st_];
+                int m_b[RS_BURSTS];
 #pragma unroll
-            for (int k = 0; k < RS_BURSTS; ++k) burst[k] = bperm(burst[k], src);
-            n_ue = n_new;
-            active = gl < n_ue;
-            if (!active) { hold_at = RS_NEVER; uvbr_at = RS_NEVER; userial = 0; }
+                for (int k = 0; k < RS_BURSTS; ++k) m_b[k] = L_burst[k][st_];
+                n_ue = n_new;
+                active = gl < n_ue;
+                L_hold[tid] = active ? m_hold : RS_NEVER;
+                L_uvbr[tid] = active ? m_uvbr : RS_NEVER;
+                L_serial[tid] = active ? m_ser : 0u;
+                L_ctr[tid] = m_ctr;
+                L_nom[tid] = m_nom;
+#pragma unroll
+                for (int k = 0; k < RS_BURSTS; ++k) L_burst[k][tid] = m_b[k];
+                if (!active) { evt_at = RS_NEVER; n_act = 0; }
+                n_cur = n_act;
+            }
+            // ---- VbrSource.step events (traffic_generators.py:70-99) on absolute end times
+            if (active && evt_at == now) {
+                int cnt = 0, nxt = RS_NEVER;
+                int b[RS_BURSTS];
+#pragma unroll
+                for (int k = 0; k < RS_BURSTS; ++k) {
+                    b[k] = L_burst[k][tid];
+                    if (b[k] > now) {
+                        cnt += 1;
+                        nxt = b[k] < nxt ? b[k] : nxt;
+                    }
+                }
+                n_cur = cnt;  // bursts ending exactly now are dropped without emitting
+                int uvbr_at = L_uvbr[tid];
+                if (uvbr_at == now) {
+                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
+                    int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
+                    int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
+                    L_ctr[tid] = st.ctr;
+                    const int endt = d >= 1 ? now + d : RS_NEVER;  // Q5: immortal burst
+                    bool placed = false;
+#pragma unroll
+                    for (int k = 0; k < RS_BURSTS; ++k) {
+                        if (!placed && b[k] <= now) { L_burst[k][tid] = endt; placed = true; }
+                    }
+                    if (!placed) err |= 2;  // RS_EOVERFLOW: burst capacity
+                    cnt += placed ? 1 : 0;
+                    nxt = (placed && endt < nxt) ? endt : nxt;
+                    uvbr_at = v >= 1 ? now + v : RS_NEVER;
+                    L_uvbr[tid] = uvbr_at;
+                }
+                n_act = cnt;
+                const int h = L_hold[tid];
+                int e = h < uvbr_at ? h : uvbr_at;
+                evt_at = e < nxt ? e : nxt;
+            }
         }
 
         const bool is_vbr = (flags & 1) != 0;
         SEC_MARK(0)
 
         // ================= UE.traffic_step (slice_ran.py:47-49)
-        double new_bits = 0.0;
         if (active) {
-            if (!is_vbr) {
-                new_bits = D->cbr_bits;
-            } else {
-                // VbrSource.step (traffic_generators.py:70-99) on absolute end times
-                int n_act = 0;
-#pragma unroll
-                for (int k = 0; k < RS_BURSTS; ++k) n_act += burst[k] > now ? 1 : 0;
-                new_bits = (double)n_act * D->vbr_p_size;
-                if (uvbr_at == now) {
-                    rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
-                    int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
-                    int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
-                    uctr = st.ctr;
-                    int endt = d >= 1 ? now + d : RS_NEVER;  // Q5: immortal burst
-                    bool placed = false;
-#pragma unroll
-                    for (int k = 0; k < RS_BURSTS; ++k) {
-                        if (!placed && burst[k] <= now) { burst[k] = endt; placed = true; }
-                    }
-                    if (!placed) err |= 2;  // RS_EOVERFLOW: burst capacity
-                    uvbr_at = v >= 1 ? now + v : RS_NEVER;
-                }
-            }
+            const double new_bits = is_vbr ? (double)n_cur * D->vbr_p_size : D->cbr_bits;
             queue += new_bits;
-            acc_traffic += new_bits;
+            atomicAdd(&L_acc_traf[tid], (int)new_bits);
         }
         const bool any_queue = group_ballot<G>(active && queue > 0.0, gbase) != 0u;
 
@@ -546,10 +610,10 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                 for (;;) {
                     findex += fstep;
                     if (findex >= Tn || findex < 0) {
-                        rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
+                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
                         findex = (int)rs_stream_integers(&st, Tn);
                         fstep = rs_stream_pm1(&st);
-                        uctr = st.ctr;
+                        L_ctr[tid] = st.ctr;
                     }
                     if (!D->has_nan || A.fad_valid[D->valid_off[ftype] + findex]) break;  // Q10
                 }
@@ -562,7 +626,7 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                 const bool have = k < n_ue;
                 const int srcl = gbase + (have ? k : 0);
                 const int c_col = bperm(col, srcl);
-                const double c_nom = bperm(nominal, srcl);
+                const double c_nom = L_nom[tb + (have ? k : 0)];
                 int es = 0;
                 if (have) {
                     const double* __restrict__ base = A.fad + c_col + prb_lo;
@@ -572,9 +636,9 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                 const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << 3));
                 if (active && (gl >> LOG_NSUB) == rho) e_snr = got;
             }
-            cnt_samples += (uint64_t)n_ue * (uint64_t)n_prb;
+            cnt_samples += (unsigned)(n_ue * n_prb);
         }
-        cnt_ue += (uint64_t)n_ue;
+        cnt_ue += (unsigned)n_ue;
 
         SEC_MARK(2)
         // ================= scheduling (slice_l1.py:215-224)
@@ -678,7 +742,7 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                     const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
                     const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
                     const int c_u = bperm(col, src), m_u = bperm(mcs, src);
-                    const double nom_u = bperm(nominal, src);
+                    const double nom_u = L_nom[tb + (src - gbase)];
 #pragma unroll
                     for (int z = 0; z < KR; ++z) {
                         const int k = k0 + z * G;
@@ -735,9 +799,9 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
             if (sched && active) {
                 bool received = false;
                 if (rbs > 0) {
-                    rs_stream st = {key0, key1, (uint32_t)sl, userial, uctr};
+                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
                     received = rs_stream_uniform(&st) < p_rx;
-                    uctr = st.ctr;
+                    L_ctr[tid] = st.ctr;
                 }
                 if (!received) bits = 0;
                 double nq = queue - (double)bits;
@@ -746,14 +810,14 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
                 ue_bits = bits;
                 ue_prbs = rbs;
             }
-            if (sched) cnt_pf += (uint64_t)((n_prb + gran - 1) / gran);
+            if (sched) cnt_pf += (unsigned)((n_prb + gran - 1) / gran);
         }
 
         SEC_MARK(5)
         // ================= SliceRANeMBB.update_info (slice_ran.py:278-305); Q2: stale bits/prbs count
         if (active) {
-            acc_bits += ue_bits;
-            acc_prbs += ue_prbs;
+            atomicAdd(&L_acc_bits[tid], ue_bits);
+            atomicAdd(&L_acc_prbs[tid], ue_prbs);
         }
         {
             const unsigned m_c = group_ballot<G>(active && !is_vbr, gbase);
@@ -798,7 +862,7 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
         if (TRACE) {
             if (valid) {
                 rs_alloc_rec rec;
-                rec.serial = active ? (int32_t)userial : 0;
+                rec.serial = active ? (int32_t)L_serial[tid] : 0;
                 rec.type = active ? (flags & 1) : 0;
                 rec.e_snr = active ? e_snr : 0;
                 rec.prbs = active ? ue_prbs : 0;
@@ -855,18 +919,18 @@ __global__ __launch_bounds__(256, 4) void embb_step_kernel(StepArgs A) {
         if (active) {
             S.u_queue[ui] = queue;
             S.u_th[ui] = th;
-            S.u_nominal[ui] = nominal;
-            S.u_hold_at[ui] = hold_at;
+            S.u_nominal[ui] = L_nom[tid];
+            S.u_hold_at[ui] = L_hold[tid];
             S.u_e_snr[ui] = e_snr;
             S.u_findex[ui] = findex;
             S.u_bits[ui] = ue_bits;
             S.u_prbs[ui] = ue_prbs;
-            S.u_vbr_at[ui] = uvbr_at;
-            S.u_ctr[ui] = uctr;
-            S.u_serial[ui] = userial;
+            S.u_vbr_at[ui] = L_uvbr[tid];
+            S.u_ctr[ui] = L_ctr[tid];
+            S.u_serial[ui] = L_serial[tid];
             S.u_flags[ui] = flags;
 #pragma unroll
-            for (int k = 0; k < RS_BURSTS; ++k) S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = burst[k];
+            for (int k = 0; k < RS_BURSTS; ++k) S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = L_burst[k][tid];
         }
     }
 }
