@@ -170,6 +170,9 @@ typedef struct kb_config {
     double alfa;                  /* scenario_creator.py:187 */
     double acc_lo, acc_hi;        /* accuracy_range */
     double gamma, eta;            /* scenario_creator.py:218, projectron.py:25 */
+    int32_t shared_dictionary;    /* 0: one agent per replica (the reference); 1: one dictionary per slice shared by all
+                                     replicas (build-defined extension) */
+    int32_t first_env;            /* shared mode: global id of this handle's replica 0 (rank * n_envs) */
 } kb_config;
 
 typedef struct kb_handle kb_handle;
@@ -198,6 +201,22 @@ int kb_get_learner(kb_handle* k, int e, int s, int32_t* m, double* landmarks, do
 int kb_get_control(kb_handle* k, int32_t* margins, int32_t* security, int32_t* action, int32_t* adjusted,
                    double* accuracies);
 int kb_set_adjusted(kb_handle* k, const int32_t* adjusted);
+/* ---- shared-dictionary mode (kb_config.shared_dictionary = 1).  One learning step = round 0, 1, ...:
+ *   kb_shared_scan   every replica looks for its first mistake (augmentation order, kbrl_control.py:103-112)
+ *                    against the frozen shared dictionaries; round 0 also does update_control's bookkeeping
+ *                    (hits, accuracies, security factors) and needs state/action/labels (later rounds: NULL).
+ *                    counts[S] = local proposers per slice; props[S][budget][KB_PROP_WIDTH] = the first
+ *                    `budget` of them in replica order (global replica id, packed candidate/label, state).
+ *   (caller)         all-gather props/counts over RCCL, merge by global replica id, keep the first `budget`.
+ *   kb_shared_apply  apply a merged list (same on every rank) in order through Projectron.predict/update.
+ *   kb_shared_commit n_accept[S] = how many of this handle's proposers (in replica order) were in the merged
+ *                    list: they move on to their next candidate; the others propose again next round. */
+#define KB_PROP_WIDTH 18
+int kb_shared_scan(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t round,
+                   int32_t budget, int32_t* hits, int32_t* counts, double* props);
+int kb_shared_apply(kb_handle* k, const int32_t* counts, const double* props, int32_t budget);
+int kb_shared_commit(kb_handle* k, const int32_t* n_accept);
+
 /* sums over learners since kb_reset: [0] predicts, [1] mistakes, [2] insertions, [3] kernel evaluations */
 int kb_get_stats(kb_handle* k, uint64_t stats[4]);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);

@@ -16,6 +16,13 @@ struct kb_handle {
     int32_t* d_labels = nullptr;
     int32_t* d_hits = nullptr;
     double* d_out = nullptr;  // [4]
+    int32_t* d_cursor = nullptr;   // shared mode [T]
+    int32_t* d_cstar = nullptr;    // shared mode [T]
+    double* d_props = nullptr;     // shared mode [S][budget_cap][KB_PROP_W]
+    int32_t* d_counts = nullptr;   // [S]
+    uint64_t* d_gstats = nullptr;  // [4] shared-dictionary updates
+    int budget_cap = 256;
+    int n_dict = 0;
     int T = 0, nv = 0;
     bool is_reset = false;
     bool timing = false;
@@ -76,16 +83,20 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     D.hi = cfg->acc_hi;
     D.gamma = cfg->gamma;
     D.eta = cfg->eta;
+    D.shared = cfg->shared_dictionary ? 1 : 0;
+    D.first_env = cfg->first_env;
     k->nv = o;
     k->T = cfg->n_envs * cfg->n_slices;
     const size_t T = (size_t)k->T, N = (size_t)cfg->n_envs, cap = (size_t)cfg->capacity;
+    const size_t ND = D.shared ? (size_t)cfg->n_slices : T;  // dictionaries
+    k->n_dict = (int)ND;
     int rc;
     kb::KbState& K = k->K;
 #define KA(p, n, z) if ((rc = kalloc(k, &(p), (n), (z))) != RS_OK) return rc
-    KA(K.m, T, true);
-    KA(K.L, T * KB_DMAX * cap, true);
-    KA(K.coeff, T * cap, true);
-    KA(K.Kinv, T * cap * cap, false);  // entries are written before they are read
+    KA(K.m, ND, true);
+    KA(K.L, ND * KB_DMAX * cap, true);
+    KA(K.coeff, ND * cap, true);
+    KA(K.Kinv, ND * cap * cap, false);  // entries are written before they are read
     KA(K.kf, T * cap, true);
     KA(K.f_last, T, true);
     KA(K.tie_ctr, T, true);
@@ -103,6 +114,11 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_labels, T, true);
     KA(k->d_hits, T, true);
     KA(k->d_out, 4, true);
+    KA(k->d_cursor, T, true);
+    KA(k->d_cstar, T, true);
+    KA(k->d_props, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
+    KA(k->d_counts, (size_t)cfg->n_slices, true);
+    KA(k->d_gstats, 4, true);
 #undef KA
     HIPCHK(k, hipStreamSynchronize(k->stream));
     return RS_OK;
@@ -136,6 +152,8 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     hipLaunchKernelGGL(kb::kb_reset_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, k->stream, k->D, k->K,
                        k->d_action, k->d_labels, dseed);
     HIPCHK(k, hipMemsetAsync(k->d_prev_state, 0, sizeof(float) * N * k->nv, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.m, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 4, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     (void)hipFree(dseed);
@@ -206,6 +224,10 @@ extern "C" int kb_update_control(kb_handle* k, const float* state, const int32_t
     if (!k || !state || !action || !labels) return RS_EINVAL;
     if (!k->is_reset) {
         k->err = "kb_update_control: call kb_reset first";
+        return RS_ESTATE;
+    }
+    if (k->D.shared) {
+        k->err = "kb_update_control: shared-dictionary handles learn through kb_shared_scan/apply/commit";
         return RS_ESTATE;
     }
     HIPCHK(k, hipSetDevice(k->device));
@@ -314,7 +336,7 @@ extern "C" int kb_update(kb_handle* k, int e, int s, const double* x, int32_t y,
 extern "C" int kb_get_learner(kb_handle* k, int e, int s, int32_t* m_out, double* landmarks, double* coeff, double* kinv) {
     if (!k || e < 0 || e >= k->cfg.n_envs || s < 0 || s >= k->cfg.n_slices) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
-    const size_t task = (size_t)e * k->cfg.n_slices + s, cap = (size_t)k->cfg.capacity;
+    const size_t task = k->D.shared ? (size_t)s : (size_t)e * k->cfg.n_slices + s, cap = (size_t)k->cfg.capacity;
     int32_t m = 0;
     HIPCHK(k, hipMemcpyAsync(&m, k->K.m + task, sizeof m, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -370,6 +392,10 @@ extern "C" int kb_get_stats(kb_handle* k, uint64_t stats[4]) {
     for (int q = 0; q < 4; ++q) stats[q] = 0;
     for (size_t i = 0; i < (size_t)k->T; ++i)
         for (int q = 0; q < 4; ++q) stats[q] += tmp[i * 4 + q];
+    uint64_t g[4] = {0, 0, 0, 0};
+    HIPCHK(k, hipMemcpy(g, k->d_gstats, sizeof g, hipMemcpyDeviceToHost));
+    stats[1] += g[1];
+    stats[2] += g[2];
     return RS_OK;
 }
 
@@ -399,6 +425,88 @@ extern "C" int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches
 extern "C" int kb_synchronize(kb_handle* k) {
     if (!k) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    return RS_OK;
+}
+
+
+// ------------------------------------------------------------------ shared-dictionary mode
+
+extern "C" int kb_shared_scan(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels,
+                              int32_t round, int32_t budget, int32_t* hits, int32_t* counts, double* props) {
+    if (!k || !counts || !props || budget <= 0) return RS_EINVAL;
+    if (!k->D.shared || !k->is_reset) {
+        k->err = "kb_shared_scan: handle is not a reset shared-dictionary agent";
+        return RS_ESTATE;
+    }
+    if (budget > k->budget_cap) {
+        k->err = "kb_shared_scan: budget too large (<= 256)";
+        return RS_EINVAL;
+    }
+    HIPCHK(k, hipSetDevice(k->device));
+    const size_t T = (size_t)k->T, N = (size_t)k->cfg.n_envs, S = (size_t)k->cfg.n_slices;
+    if (round == 0) {
+        if (!state || !action || !labels) return RS_EINVAL;
+        for (size_t i = 0; i < T; ++i)
+            if (action[i] < 0 || action[i] > k->cfg.n_prbs || (labels[i] != 1 && labels[i] != -1)) {
+                k->err = "kb_shared_scan: action out of [0, n_prbs] or label not +-1";
+                return RS_EINVAL;
+            }
+        HIPCHK(k, hipMemcpyAsync(k->d_state, state, sizeof(float) * N * k->nv, hipMemcpyHostToDevice, k->stream));
+        HIPCHK(k, hipMemcpyAsync(k->d_action, action, sizeof(int32_t) * T, hipMemcpyHostToDevice, k->stream));
+        HIPCHK(k, hipMemcpyAsync(k->d_labels, labels, sizeof(int32_t) * T, hipMemcpyHostToDevice, k->stream));
+    }
+    kb::ScanArgs a;
+    a.D = k->D;
+    a.K = k->K;
+    a.state = k->d_state;
+    a.action = k->d_action;
+    a.labels = k->d_labels;
+    a.hits = k->d_hits;
+    a.cursor = k->d_cursor;
+    a.cstar = k->d_cstar;
+    a.round = round;
+    hipEvent_t e1;
+    int rc = kb_time_begin(k, &e1);
+    if (rc != RS_OK) return rc;
+    hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(256), 0, k->stream, a);
+    if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
+    hipLaunchKernelGGL(kb::shared_collect_kernel, dim3((unsigned)S), dim3(64), 0, k->stream, k->D, k->d_state, k->d_labels,
+                       k->d_cstar, (int)budget, k->d_props, k->d_counts);
+    HIPCHK(k, hipGetLastError());
+    if (hits && round == 0)
+        HIPCHK(k, hipMemcpyAsync(hits, k->d_hits, sizeof(int32_t) * T, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipMemcpyAsync(counts, k->d_counts, sizeof(int32_t) * S, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipMemcpyAsync(props, k->d_props, sizeof(double) * S * budget * KB_PROP_W, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    return RS_OK;
+}
+
+extern "C" int kb_shared_apply(kb_handle* k, const int32_t* counts, const double* props, int32_t budget) {
+    if (!k || !counts || !props || budget <= 0 || budget > k->budget_cap) return RS_EINVAL;
+    if (!k->D.shared || !k->is_reset) {
+        k->err = "kb_shared_apply: handle is not a reset shared-dictionary agent";
+        return RS_ESTATE;
+    }
+    HIPCHK(k, hipSetDevice(k->device));
+    const size_t S = (size_t)k->cfg.n_slices;
+    HIPCHK(k, hipMemcpyAsync(k->d_counts, counts, sizeof(int32_t) * S, hipMemcpyHostToDevice, k->stream));
+    HIPCHK(k, hipMemcpyAsync(k->d_props, props, sizeof(double) * S * budget * KB_PROP_W, hipMemcpyHostToDevice, k->stream));
+    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3((unsigned)S), dim3(256), 0, k->stream, k->D, k->K, k->d_props,
+                       k->d_counts, (int)budget, k->d_gstats);
+    HIPCHK(k, hipGetLastError());
+    return kb_check(k);
+}
+
+extern "C" int kb_shared_commit(kb_handle* k, const int32_t* n_accept) {
+    if (!k || !n_accept) return RS_EINVAL;
+    if (!k->D.shared || !k->is_reset) return RS_ESTATE;
+    HIPCHK(k, hipSetDevice(k->device));
+    const size_t S = (size_t)k->cfg.n_slices;
+    HIPCHK(k, hipMemcpyAsync(k->d_counts, n_accept, sizeof(int32_t) * S, hipMemcpyHostToDevice, k->stream));
+    hipLaunchKernelGGL(kb::shared_commit_kernel, dim3((unsigned)S), dim3(64), 0, k->stream, k->D, k->d_cstar, k->d_counts,
+                       k->d_cursor);
+    HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     return RS_OK;
 }

@@ -33,7 +33,12 @@ struct KbDev {
     int32_t dims[8];  // state variables per learner (len(x) = dims+1)
     int32_t off[8];   // first state variable of learner s
     double alfa, lo, hi, gamma, eta;
+    int32_t shared;   // 1: one dictionary per slice shared by all replicas (build-defined extension)
+    int32_t first_env; // global id of local replica 0 (shared mode proposals carry global ids)
 };
+
+// dictionary a learner (task = env * S + s) reads and writes
+__device__ __forceinline__ int dict_of(const KbDev& D, int task) { return D.shared ? task % D.S : task; }
 
 struct KbState {
     int32_t* m;        // [T] landmarks per learner (T = n_envs * S)
@@ -87,9 +92,9 @@ __device__ __forceinline__ double block_sum(double v, Lds& sm) {
 }
 
 // D0_j, lam_j and the MFMA operands for the current state (first d-1 coordinates in sm.x)
-__device__ void prepare_operands(const KbDev& D, const KbState& K, int task, int m, int d, Lds& sm) {
+__device__ void prepare_operands(const KbDev& D, const KbState& K, int dict, int m, int d, Lds& sm) {
     const int cap = D.cap;
-    const double* L = K.L + (size_t)task * KB_DMAX * cap;
+    const double* L = K.L + (size_t)dict * KB_DMAX * cap;
     for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
         double d0 = 0.0, lam = 0.0, co = 0.0;
         if (j < m) {
@@ -98,7 +103,7 @@ __device__ void prepare_operands(const KbDev& D, const KbState& K, int task, int
                 d0 += t * t;
             }
             lam = L[(size_t)(d - 1) * cap + j];
-            co = K.coeff[(size_t)task * cap + j];
+            co = K.coeff[(size_t)dict * cap + j];
         }
         sm.d0[j] = d0;
         sm.lam[j] = lam;
@@ -173,11 +178,11 @@ __device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
 
 // Projectron.update (projectron.py:39-60) for x = (state, c/n), given sm.kf.  Returns the new m.
 // branch: 1 = projection onto the dictionary, 2 = dictionary grew.
-__device__ int apply_update(const KbDev& D, const KbState& K, int task, int m, int d, int c, int y, Lds& sm,
+__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, int c, int y, Lds& sm,
                             int* branch, double* delta_out) {
     const int cap = D.cap;
-    double* Kinv = K.Kinv + (size_t)task * cap * cap;
-    double* coeffg = K.coeff + (size_t)task * cap;
+    double* Kinv = K.Kinv + (size_t)dict * cap * cap;
+    double* coeffg = K.coeff + (size_t)dict * cap;
     double dot;
     if (m <= 1) {
         float kinv = m == 0 ? 0.0f : 1.0f;
@@ -202,7 +207,11 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int task, int m, i
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
     delta = delta > 0.0 ? delta : 0.0;
     *delta_out = delta;
-    if (delta <= D.eta) {
+    // Shared-dictionary mode pools every replica's samples into one dictionary, which therefore reaches
+    // the capacity: from then on a sample is always projected onto the span (the fixed-budget reading of
+    // Projectron).  Per-replica agents follow the reference (unbounded growth) and report the overflow.
+    const bool full = D.shared && (m >= cap || m >= 1024);
+    if (delta <= D.eta || full) {
         *branch = 1;
         for (int j = threadIdx.x; j < m; j += blockDim.x) {
             double nc = sm.co[j] + (double)y * sm.ds[j];
@@ -215,12 +224,12 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int task, int m, i
     }
     *branch = 2;
     if (m >= cap || m >= 1024) {
-        if (threadIdx.x == 0) atomicOr(&K.err[task / D.S], 4);
+        if (threadIdx.x == 0) atomicOr(&K.err[err_env], 4);
         __syncthreads();
         return m;
     }
     // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
-    double* L = K.L + (size_t)task * KB_DMAX * cap;
+    double* L = K.L + (size_t)dict * KB_DMAX * cap;
     const double t = (double)c / (double)D.n_prbs;
     if (threadIdx.x == 0) {
         for (int q = 0; q < d - 1; ++q) L[(size_t)q * cap + m] = sm.x[q];
@@ -264,10 +273,11 @@ __global__ __launch_bounds__(256) void update_control_kernel(CtlArgs A) {
     const KbState& K = A.K;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
-    int m = K.m[task];
+    const int dict = dict_of(D, task);
+    int m = K.m[dict];
     if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
     __syncthreads();
-    prepare_operands(D, K, task, m, d, sm);
+    prepare_operands(D, K, dict, m, d, sm);
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
     uint64_t n_pred = 0, n_mist = 0, n_grow = 0, n_eval = 0;
@@ -347,13 +357,13 @@ __global__ __launch_bounds__(256) void update_control_kernel(CtlArgs A) {
         kernel_column(D, m, cstar, sm);
         int branch;
         double delta;
-        const int m_new = apply_update(D, K, task, m, d, cstar, y, sm, &branch, &delta);
+        const int m_new = apply_update(D, K, dict, env, m, d, cstar, y, sm, &branch, &delta);
         if (branch == 2 && m_new > m) n_grow += 1;
         m = m_new;
         c_from = cstar + 1;
     }
     if (threadIdx.x == 0) {
-        K.m[task] = m;
+        K.m[dict] = m;
         uint64_t* st = K.stats + (size_t)task * 4;
         st[0] += n_pred;
         st[1] += n_mist;
@@ -375,10 +385,11 @@ __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
     const KbState& K = A.K;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
-    const int m = K.m[task];
+    const int dict = dict_of(D, task);
+    const int m = K.m[dict];
     if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
     __syncthreads();
-    prepare_operands(D, K, task, m, d, sm);
+    prepare_operands(D, K, dict, m, d, sm);
     score_range(D, m, 0, n, sm);
     if (threadIdx.x == 0) sm.ired[0] = 0x7fffffff;
     __syncthreads();
@@ -448,6 +459,196 @@ __global__ void adjust_kernel(KbDev D, KbState K, int32_t* action_out) {
         for (int s = 0; s < D.S; ++s) action_out[env * D.S + s] = K.action[env * D.S + s];
 }
 
+// ---- shared-dictionary mode (build-defined extension): one dictionary per slice index,
+// learned from every replica on every GPU.  A step is a few rounds of
+//   scan    each replica finds its first mistake (in the reference's augmentation order) against the frozen
+//           shared dictionary                                                  [shared_scan_kernel]
+//   collect the first B proposers per slice, in replica order                  [shared_collect_kernel]
+//   (host)  all-gather of the proposal lists over RCCL, merge by global replica id, keep the first B
+//   apply   every rank applies the same merged list, in order, through Projectron.predict/update, so all
+//           ranks hold bitwise-identical dictionaries                           [shared_apply_kernel]
+//   commit  replicas whose proposal was taken move their cursor past it         [shared_commit_kernel]
+// With a single replica this is exactly the reference's sequential loop (kbrl_control.py:103-112).
+
+#define KB_PROP_W (2 + KB_DMAX)  // doubles per proposal: global replica id, c | (y << 16) packed as double, x...
+
+struct ScanArgs {
+    KbDev D;
+    KbState K;
+    const float* state;
+    const int32_t* action;
+    const int32_t* labels;
+    int32_t* hits;
+    int32_t* cursor;  // [T] next candidate to examine; < 0: range exhausted
+    int32_t* cstar;   // [T] candidate proposed in this round, -1 none
+    int32_t round;
+};
+
+__global__ __launch_bounds__(256) void shared_scan_kernel(ScanArgs A) {
+    __shared__ Lds sm;
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, n = D.n_prbs;
+    const int dict = dict_of(D, task);
+    const int m = K.m[dict];
+    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    __syncthreads();
+    prepare_operands(D, K, dict, m, d, sm);
+    const int a_i = A.action[env * D.S + s];
+    const int y = A.labels[env * D.S + s];
+    uint64_t n_pred = 0, n_eval = 0;
+    int c_from;
+    if (A.round == 0) {
+        // y_pred, accuracy table, security factor: kbrl_control.py:88-101 (as update_control_kernel)
+        score_range(D, m, a_i, a_i, sm);
+        n_pred += 1;
+        n_eval += (uint64_t)m;
+        int y_pred = 0;
+        double f0 = sm.f[a_i];
+        if (m > 0) {
+            y_pred = f0 > 0.0 ? 1 : (f0 < 0.0 ? -1 : 0);
+            if (y_pred == 0) {
+                if (threadIdx.x == 0) sm.ired[0] = tie_draw(K, task, env, s);
+                __syncthreads();
+                y_pred = sm.ired[0];
+                __syncthreads();
+            }
+        }
+        const int hit = y == y_pred;
+        int margin = K.margins[env * D.S + s];
+        margin = margin > 0 ? margin : 0;
+        double* acc = K.acc + ((size_t)env * D.S + s) * n;
+        if (y_pred == 1) {
+            for (int c = threadIdx.x; c < n; c += blockDim.x) {
+                if (!hit) {
+                    if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
+                } else {
+                    if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
+                }
+            }
+        }
+        __syncthreads();
+        if (!K.adjusted[env]) {
+            if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
+            __syncthreads();
+            int first = 0x7fffffff;
+            for (int c = threadIdx.x; c < n; c += blockDim.x)
+                if (acc[c] > D.lo) { first = c; break; }
+            if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
+            __syncthreads();
+            if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
+        }
+        if (threadIdx.x == 0) A.hits[env * D.S + s] = hit;
+        c_from = y == 1 ? a_i : 0;
+    } else {
+        c_from = A.cursor[task];
+    }
+    const int c_to = y == 1 ? n : a_i;
+    int cstar = -1;
+    if (c_from >= 0 && c_from <= c_to) {
+        score_range(D, m, c_from, c_to, sm);
+        n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
+        if (threadIdx.x == 0) sm.ired[2] = 0x7fffffff;
+        __syncthreads();
+        int firstc = 0x7fffffff;
+        for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x)
+            if (sm.f[c] * (double)y <= 0.0) { firstc = c; break; }
+        if (firstc != 0x7fffffff) atomicMin(&sm.ired[2], firstc);
+        __syncthreads();
+        if (sm.ired[2] != 0x7fffffff) cstar = sm.ired[2];
+        const int last = cstar >= 0 ? cstar : c_to;
+        n_pred += (uint64_t)(last - c_from + 1);
+        if (m > 0) {  // predictions with f == 0 consume a tie-break draw each (Q11)
+            int zeros = 0;
+            for (int c = c_from + (int)threadIdx.x; c <= last; c += blockDim.x) zeros += sm.f[c] == 0.0 ? 1 : 0;
+            int tz = (int)block_sum((double)zeros, sm);
+            if (threadIdx.x == 0 && tz > 0) K.tie_ctr[task] += (uint32_t)tz;
+        }
+    }
+    if (threadIdx.x == 0) {
+        A.cstar[task] = cstar;
+        A.cursor[task] = cstar >= 0 ? cstar : -1;  // stays on the proposal until it is committed
+        uint64_t* st = K.stats + (size_t)task * 4;
+        st[0] += n_pred;
+        st[3] += n_eval;
+    }
+}
+
+// first `budget` proposers of each slice in replica order -> props[s][i][KB_PROP_W], counts[s] = all proposers
+__global__ void shared_collect_kernel(KbDev D, const float* state, const int32_t* labels, const int32_t* cstar,
+                                      int budget, double* props, int32_t* counts) {
+    const int s = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int cnt = 0;
+    const int d = D.dims[s] + 1;
+    for (int env = 0; env < D.n_envs; ++env) {
+        const int c = cstar[env * D.S + s];
+        if (c < 0) continue;
+        if (cnt < budget) {
+            double* p = props + ((size_t)s * budget + cnt) * KB_PROP_W;
+            p[0] = (double)(D.first_env + env);
+            p[1] = (double)(c * 4 + (labels[env * D.S + s] == 1 ? 1 : 0));
+            for (int q = 0; q < d - 1; ++q) p[2 + q] = (double)state[(size_t)env * D.nv + D.off[s] + q];
+        }
+        cnt += 1;
+    }
+    counts[s] = cnt;
+}
+
+// the first n_accept[s] local proposers of slice s (replica order) had their sample applied: move on
+__global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_t* n_accept, int32_t* cursor) {
+    const int s = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int left = n_accept[s];
+    for (int env = 0; env < D.n_envs && left > 0; ++env) {
+        const int c = cstar[env * D.S + s];
+        if (c < 0) continue;
+        cursor[env * D.S + s] = c + 1;
+        left -= 1;
+    }
+}
+
+// apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
+__global__ __launch_bounds__(256) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
+                                                         int budget, uint64_t* gstats) {
+    __shared__ Lds sm;
+    const int s = blockIdx.x;
+    const int d = D.dims[s] + 1;
+    int m = K.m[s];
+    const int np = counts[s] < budget ? counts[s] : budget;
+    uint64_t n_mist = 0, n_grow = 0;
+    for (int i = 0; i < np; ++i) {
+        const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
+        const int packed = (int)p[1];
+        const int c = packed >> 2, y = (packed & 1) ? 1 : -1;
+        __syncthreads();
+        if (threadIdx.x < d - 1) sm.x[threadIdx.x] = p[2 + threadIdx.x];
+        __syncthreads();
+        prepare_operands(D, K, s, m, d, sm);
+        // Projectron.predict on (state, c/n): f = k . coeff (float32 while a single landmark is held)
+        kernel_column(D, m, c, sm);
+        double part = 0.0;
+        for (int j = threadIdx.x; j < m; j += blockDim.x) part += sm.kf[j] * sm.co[j];
+        double f = block_sum(part, sm);
+        if (m == 1) f = (double)(float)((float)sm.kf[0] * (float)sm.co[0]);
+        if (m == 0) f = 0.0;
+        if (f * (double)y <= 0.0) {  // still a mistake against the evolving dictionary
+            int branch;
+            double delta;
+            const int m_new = apply_update(D, K, s, 0, m, d, c, y, sm, &branch, &delta);
+            n_mist += 1;
+            if (branch == 2 && m_new > m) n_grow += 1;
+            m = m_new;
+        }
+    }
+    if (threadIdx.x == 0) {
+        K.m[s] = m;
+        atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
+        atomicAdd((unsigned long long*)&gstats[2], (unsigned long long)n_grow);
+    }
+}
+
 // ---- single-call entry points behind Projectron.predict / update (drop-in API, N=1 plumbing)
 
 struct OneArgs {
@@ -464,11 +665,12 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
+    const int dt = dict_of(D, task);
     const int d = D.dims[s] + 1, cap = D.cap;
-    const int m = K.m[task];
+    const int m = K.m[dt];
     double* kfg = K.kf + (size_t)task * cap;
     double p = 0.0;
-    const double* L = K.L + (size_t)task * KB_DMAX * cap;
+    const double* L = K.L + (size_t)dt * KB_DMAX * cap;
     for (int j = threadIdx.x; j < m; j += blockDim.x) {
         double dist = 0.0;
         for (int q = 0; q < d; ++q) {
@@ -478,10 +680,10 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
         double k = rs_exp(-D.gamma * dist);
         if (m == 1) k = (double)(float)k;
         kfg[j] = k;
-        p += k * K.coeff[(size_t)task * cap + j];
+        p += k * K.coeff[(size_t)dt * cap + j];
     }
     double f = block_sum(p, sm);
-    if (m == 1) f = (double)(float)((float)kfg[0] * (float)K.coeff[(size_t)task * cap]);
+    if (m == 1) f = (double)(float)((float)kfg[0] * (float)K.coeff[(size_t)dt * cap]);
     if (threadIdx.x == 0) {
         int y = 0;
         if (m > 0) {
@@ -503,9 +705,10 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
+    const int dt = dict_of(D, task);
     const int d = D.dims[s] + 1, cap = D.cap;
     (void)env;
-    int m = K.m[task];
+    int m = K.m[dt];
     const double f = K.f_last[task];
     if (!(f * (double)A.y <= 0.0)) {
         if (threadIdx.x == 0) { A.out[2] = 0.0; A.out[3] = 0.0; }
@@ -515,7 +718,7 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     // last coordinate is handed over through sm.lam/sm.x with n_prbs-independent arithmetic
     for (int q = threadIdx.x; q < d; q += blockDim.x) sm.x[q] = A.x[q];
     for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
-        sm.co[j] = j < m ? K.coeff[(size_t)task * cap + j] : 0.0;
+        sm.co[j] = j < m ? K.coeff[(size_t)dt * cap + j] : 0.0;
         sm.kf[j] = j < (m > 0 ? m : 1) ? K.kf[(size_t)task * cap + j] : 0.0;
     }
     __syncthreads();
@@ -525,7 +728,7 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     KbDev D1 = D;
     // apply_update computes t = c / n_prbs; encode the exact last coordinate via a local copy
     // of the grow step instead (below) when the dictionary grows.
-    double* Kinv = K.Kinv + (size_t)task * cap * cap;
+    double* Kinv = K.Kinv + (size_t)dt * cap * cap;
     double dot;
     if (m <= 1) {
         float kinv = m == 0 ? 0.0f : 1.0f;
@@ -554,17 +757,17 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
         for (int j = threadIdx.x; j < m; j += blockDim.x) {
             double nc = sm.co[j] + (double)A.y * sm.ds[j];
             if (m == 1) nc = (double)(float)nc;
-            K.coeff[(size_t)task * cap + j] = nc;
+            K.coeff[(size_t)dt * cap + j] = nc;
         }
     } else if (m >= cap || m >= 1024) {
         branch = 2;
         if (threadIdx.x == 0) atomicOr(&K.err[task / D.S], 4);
     } else {
         branch = 2;
-        double* L = K.L + (size_t)task * KB_DMAX * cap;
+        double* L = K.L + (size_t)dt * KB_DMAX * cap;
         if (threadIdx.x == 0) {
             for (int q = 0; q < d; ++q) L[(size_t)q * cap + m] = sm.x[q];
-            K.coeff[(size_t)task * cap + m] = (double)A.y;
+            K.coeff[(size_t)dt * cap + m] = (double)A.y;
             sm.ds[m] = -1.0;
         }
         __syncthreads();
@@ -582,7 +785,7 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        K.m[task] = m;
+        K.m[dt] = m;
         A.out[2] = (double)branch;
         A.out[3] = delta;
         K.stats[(size_t)task * 4 + 1] += 1;

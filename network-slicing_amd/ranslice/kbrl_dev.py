@@ -19,7 +19,7 @@ _up = C.POINTER(C.c_uint64)
 
 class VecKBRL:
     def __init__(self, n_envs, dims, n_prbs, alfa=KBRL_ALFA, accuracy_range=(0.99, 0.999), gamma=KBRL_GAMMA,
-                 eta=KBRL_ETA, capacity=1024, device=0):
+                 eta=KBRL_ETA, capacity=1024, device=0, shared=False, first_env=0):
         self.L = _lib.load()
         cfg = KbConfig()
         cfg.n_envs, cfg.n_slices, cfg.n_prbs, cfg.capacity = n_envs, len(dims), n_prbs, capacity
@@ -27,6 +27,7 @@ class VecKBRL:
             cfg.dims[i] = int(d)
         cfg.alfa, cfg.acc_lo, cfg.acc_hi = alfa, accuracy_range[0], accuracy_range[1]
         cfg.gamma, cfg.eta = gamma, eta
+        cfg.shared_dictionary, cfg.first_env = int(bool(shared)), int(first_env)
         self.cfg = cfg
         self.n_envs, self.S, self.n_prbs, self.dims = n_envs, len(dims), n_prbs, list(dims)
         self.nv = int(sum(dims))
@@ -132,3 +133,87 @@ class VecKBRL:
 
     def synchronize(self):
         self._check(self.L.kb_synchronize(self.h))
+
+
+PROP_W = 18  # KB_PROP_WIDTH
+
+
+def merge_proposals(all_counts, all_props, budget):
+    """Merge per-rank proposal lists into the list every rank applies: by slice, ascending global replica id,
+    truncated to `budget`.  all_counts [W][S], all_props [W][S][budget][PROP_W] -> (counts [S], props
+    [S][budget][PROP_W], taken [W][S] = how many of rank w's proposers made it).  Pure host logic (tested on
+    CPU with gloo): the result does not depend on how replicas are sharded over ranks."""
+    all_counts = np.asarray(all_counts)
+    all_props = np.asarray(all_props)
+    W, S = all_counts.shape
+    out = np.zeros((S, budget, PROP_W))
+    counts = np.zeros(S, dtype=np.int32)
+    taken = np.zeros((W, S), dtype=np.int32)
+    for s in range(S):
+        rows = []
+        for w in range(W):
+            n = min(int(all_counts[w, s]), budget)
+            for i in range(n):
+                rows.append((all_props[w, s, i, 0], w, i))
+        rows.sort()
+        rows = rows[:budget]
+        for j, (_, w, i) in enumerate(rows):
+            out[s, j] = all_props[w, s, i]
+            taken[w, s] += 1
+        counts[s] = len(rows)
+    return counts, out, taken
+
+
+class SharedVecKBRL(VecKBRL):
+    """One KBRL dictionary per slice index, learned from every replica of every rank (build-defined
+    extension; the reference trains one independent agent per run).  `exchange(counts, props)` must
+    return the lists of all ranks stacked on a leading axis ([W][S], [W][S][budget][PROP_W]) and this
+    rank's index; the default is a single rank.  With torch.distributed it is one all_gather over RCCL
+    (`rccl_exchange`)."""
+
+    def __init__(self, n_envs, dims, n_prbs, budget=64, max_rounds=4, exchange=None, **kw):
+        super().__init__(n_envs, dims, n_prbs, shared=True, **kw)
+        self.budget, self.max_rounds = budget, max_rounds
+        self.exchange = exchange or (lambda c, p: (c[None], p[None], 0))
+
+    def update_control(self, state, action, labels):
+        state = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, self.nv)
+        action = np.ascontiguousarray(action, dtype=np.int32).reshape(self.n_envs, self.S)
+        labels = np.ascontiguousarray(labels, dtype=np.int32).reshape(self.n_envs, self.S)
+        hits = np.zeros((self.n_envs, self.S), dtype=np.int32)
+        counts = np.zeros(self.S, dtype=np.int32)
+        props = np.zeros((self.S, self.budget, PROP_W))
+        self.rounds_last = 0
+        for rnd in range(self.max_rounds):
+            first = rnd == 0
+            self._check(self.L.kb_shared_scan(
+                self.h, state.ctypes.data_as(_fp) if first else None, action.ctypes.data_as(_ip) if first else None,
+                labels.ctypes.data_as(_ip) if first else None, rnd, self.budget, hits.ctypes.data_as(_ip),
+                counts.ctypes.data_as(_ip), props.ctypes.data_as(_dp)))
+            all_counts, all_props, me = self.exchange(counts, props)
+            if int(np.asarray(all_counts).sum()) == 0:
+                break
+            mc, mp, taken = merge_proposals(all_counts, all_props, self.budget)
+            mc = np.ascontiguousarray(mc, dtype=np.int32)
+            mp = np.ascontiguousarray(mp, dtype=np.float64)
+            self._check(self.L.kb_shared_apply(self.h, mc.ctypes.data_as(_ip), mp.ctypes.data_as(_dp), self.budget))
+            acc = np.ascontiguousarray(taken[me], dtype=np.int32)
+            self._check(self.L.kb_shared_commit(self.h, acc.ctypes.data_as(_ip)))
+            self.rounds_last = rnd + 1
+        return hits
+
+
+def rccl_exchange(device='cuda'):
+    """exchange() over torch.distributed (backend nccl = RCCL on ROCm): one all_gather of the proposal block"""
+    import torch
+    import torch.distributed as dist
+
+    def ex(counts, props):
+        W, me = dist.get_world_size(), dist.get_rank()
+        blk = torch.from_numpy(np.concatenate([counts.astype(np.float64), props.ravel()])).to(device)
+        out = [torch.empty_like(blk) for _ in range(W)]
+        dist.all_gather(out, blk)
+        arr = np.stack([o.cpu().numpy() for o in out])
+        S = len(counts)
+        return arr[:, :S].astype(np.int32), arr[:, S:].reshape((W,) + props.shape), me
+    return ex

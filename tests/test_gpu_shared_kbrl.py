@@ -1,0 +1,121 @@
+"""Shared-dictionary KBRL (build-defined extension: no counterpart in the reference, parity unpinned).
+Pinned by self-consistency, as SURVEY.md §8e asks: (1) with one replica it is the reference's sequential
+algorithm (equals the per-replica agent, which is pinned to the reference's goldens); (2) the learned
+dictionaries do not depend on how replicas are sharded over ranks."""
+import os
+
+import numpy as np
+import pytest
+
+from ranslice.config import make_config
+
+pytestmark = pytest.mark.gpu
+
+
+def _dims(scenario):
+    cfg = make_config(scenario)
+    return [10] * cfg.n_embb + [3] * cfg.n_mmtc, cfg.n_prbs
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_single_replica_equals_reference_algorithm(golden_dir, scenario):
+    from ranslice.kbrl_dev import SharedVecKBRL, VecKBRL
+    g = np.load(os.path.join(golden_dir, 'g10_kbrl_s%d.npz' % scenario))
+    dims, n_prbs = _dims(scenario)
+    a = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=256)
+    b = SharedVecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=256, budget=8, max_rounds=300)
+    a.reset(g['init_action'][None], g['init_sec'][None])
+    b.reset(g['init_action'][None], g['init_sec'][None])
+    steps = 70
+    for i in range(steps):
+        ha = a.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        hb = b.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        assert (ha == hb).all() and (ha[0] == g['hits'][i]).all(), i
+        nxt = g['state'][i + 1]
+        aa, ja = a.select_action(nxt[None])
+        ab, jb = b.select_action(nxt[None])
+        assert (aa == ab).all() and ja[0] == jb[0] and (aa[0] == g['action_out'][i]).all(), i
+    for s in range(len(dims)):
+        la, lb = a.learner(0, s, with_kinv=True), b.learner(0, s, with_kinv=True)
+        assert la['m'] == lb['m']
+        assert la['landmarks'].tobytes() == lb['landmarks'].tobytes()
+        assert la['coeff'].tobytes() == lb['coeff'].tobytes() and la['kinv'].tobytes() == lb['kinv'].tobytes()
+    a.close(); b.close()
+
+
+def test_dictionaries_do_not_depend_on_sharding():
+    """24 replicas on one handle == 3 handles x 8 replicas exchanging proposals (what 3 ranks do over RCCL)"""
+    from ranslice.kbrl_dev import SharedVecKBRL
+    dims, n_prbs = [10] * 5, 200
+    N, W = 24, 3
+    rng = np.random.default_rng(8)
+    ia = rng.integers(4, 20, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    whole = SharedVecKBRL(N, dims, n_prbs, capacity=256, budget=16, max_rounds=3)
+    whole.reset(ia, sf)
+    parts = []
+    box = {}
+
+    def make_exchange(w):
+        def ex(counts, props):
+            return np.stack(box['counts']), np.stack(box['props']), w
+        return ex
+    for w in range(W):
+        p = SharedVecKBRL(N // W, dims, n_prbs, capacity=256, budget=16, max_rounds=3, first_env=w * (N // W),
+                          exchange=make_exchange(w))
+        p.reset(ia[w * 8:(w + 1) * 8], sf[w * 8:(w + 1) * 8], seeds=np.arange(w * 8, (w + 1) * 8, dtype=np.uint64))
+        parts.append(p)
+
+    def parts_update(state, action, labels):
+        """drive the three 'ranks' in lockstep, round by round, as an all_gather would"""
+        import ctypes as C
+        from ranslice.kbrl_dev import PROP_W, merge_proposals
+        hits = [np.zeros((8, 5), dtype=np.int32) for _ in range(W)]
+        ip, fp, dp = C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_double)
+        for rnd in range(3):
+            cs, ps = [], []
+            for w, p in enumerate(parts):
+                st = np.ascontiguousarray(state[w * 8:(w + 1) * 8], dtype=np.float32)
+                ac = np.ascontiguousarray(action[w * 8:(w + 1) * 8], dtype=np.int32)
+                lb = np.ascontiguousarray(labels[w * 8:(w + 1) * 8], dtype=np.int32)
+                counts = np.zeros(5, dtype=np.int32)
+                props = np.zeros((5, 16, PROP_W))
+                p._check(p.L.kb_shared_scan(p.h, st.ctypes.data_as(fp) if rnd == 0 else None,
+                                            ac.ctypes.data_as(ip) if rnd == 0 else None,
+                                            lb.ctypes.data_as(ip) if rnd == 0 else None, rnd, 16,
+                                            hits[w].ctypes.data_as(ip), counts.ctypes.data_as(ip), props.ctypes.data_as(dp)))
+                cs.append(counts); ps.append(props)
+            if int(np.sum(cs)) == 0:
+                break
+            mc, mp, taken = merge_proposals(np.stack(cs), np.stack(ps), 16)
+            mc = np.ascontiguousarray(mc, dtype=np.int32); mp = np.ascontiguousarray(mp)
+            for w, p in enumerate(parts):
+                p._check(p.L.kb_shared_apply(p.h, mc.ctypes.data_as(ip), mp.ctypes.data_as(dp), 16))
+                acc = np.ascontiguousarray(taken[w], dtype=np.int32)
+                p._check(p.L.kb_shared_commit(p.h, acc.ctypes.data_as(ip)))
+        return np.concatenate(hits)
+    state = rng.random((N, 50)).astype(np.float32) * 0.5
+    for i in range(25):
+        action = rng.integers(5, 60, size=(N, 5)).astype(np.int32)
+        # a smooth ground truth: a slice is satisfied when its allocation exceeds a state-dependent demand
+        demand = (state.reshape(N, 5, 10)[:, :, [0, 5]].sum(axis=2) * 60).astype(np.int32) + 8
+        labels = np.where(action >= demand, 1, -1).astype(np.int32)
+        hw = whole.update_control(state, action, labels)
+        hp = parts_update(state, action, labels)
+        assert (hw == hp).all(), i
+        state = rng.random((N, 50)).astype(np.float32) * 0.5
+        aw, jw = whole.select_action(state)
+        ap = np.concatenate([p.select_action(state[w * 8:(w + 1) * 8])[0] for w, p in enumerate(parts)])
+        assert (aw == ap).all(), i
+    sizes = []
+    for s in range(5):
+        lw = whole.learner(0, s, with_kinv=True)
+        sizes.append(lw['m'])
+        for p in parts:
+            lp = p.learner(0, s, with_kinv=True)
+            assert lw['m'] == lp['m'] and lw['coeff'].tobytes() == lp['coeff'].tobytes()
+            assert lw['landmarks'].tobytes() == lp['landmarks'].tobytes() and lw['kinv'].tobytes() == lp['kinv'].tobytes()
+    assert min(sizes) >= 3, sizes
+    whole.close()
+    for p in parts:
+        p.close()

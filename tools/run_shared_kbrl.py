@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""BASELINE config 4: scenario_2 (1 eMBB + 4 mMTC slices), env replicas sharded over the GPUs of one node,
+ONE shared KBRL dictionary per slice learned from all replicas; the only collective is the per-round
+all_gather of proposed landmarks over RCCL (xGMI).  Launch:
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         tools/run_shared_kbrl.py --envs-per-gpu 4096 --steps 200
+
+Prints one JSON line on rank 0 (env-steps/s with the shared agent in the loop, dictionary sizes, rounds).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--scenario', type=int, default=2)
+    ap.add_argument('--envs-per-gpu', type=int, default=4096)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--budget', type=int, default=64)
+    ap.add_argument('--rounds', type=int, default=4)
+    ap.add_argument('--capacity', type=int, default=1024)
+    args = ap.parse_args()
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    use_dist = 'RANK' in os.environ
+    if use_dist:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    from ranslice.config import make_config, EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import SharedVecKBRL, rccl_exchange
+    from ranslice.sharding import shard_range, replica_seeds, max_over_ranks
+    from ranslice.vec_env import VecRanSlice
+    N = args.envs_per_gpu
+    cfg = make_config(args.scenario, n_envs=N)
+    first, count = shard_range(world * N, rank, world)
+    env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, 10000) for t in range(3)], device=local_rank)
+    dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
+    agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=args.budget, max_rounds=args.rounds, capacity=args.capacity,
+                          device=local_rank, first_env=first, exchange=rccl_exchange('cuda') if use_dist else None)
+    rng = np.random.default_rng(1000 + rank)
+    ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+    sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+    state = env.reset(seeds=replica_seeds(0, first, count))
+    agent.reset(ia, sf, seeds=replica_seeds(7, first, count))
+    action = ia.copy()
+    rounds = 0
+    viol = 0.0
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        obs, rew, _, info = env.step(action)
+        agent.update_control(state, action, info['SLA_labels'])
+        rounds += agent.rounds_last
+        action, adj = agent.select_action(obs)
+        state = obs
+        viol += float(info['total_violations'].mean())
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, device='cuda')
+    sizes = [agent.learner(0, s)['m'] for s in range(len(dims))]
+    if rank == 0:
+        print(json.dumps({'config': 'scenario_%d, %d envs x %d GPUs, shared KBRL dictionary per slice, RCCL all_gather merge'
+                                    % (args.scenario, N, world), 'env_steps_per_s': world * N * args.steps / dt,
+                          'ms_per_step': 1e3 * dt / args.steps, 'exchange_rounds_per_step': rounds / args.steps,
+                          'dictionary_sizes': sizes, 'violations_per_env_step': viol / args.steps,
+                          'mean_prbs_last': float(action.sum(axis=1).mean())}))
+    env.close(); agent.close()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
