@@ -188,16 +188,12 @@ __device__ __forceinline__ double sub8_block(int off, int n, int j, int lane, F 
     double v = j < rem ? f(off + lim + j) : 0.0;
     if (n >= 8) {
         double r = f(off + j);
-        for (int i = 8; i < lim; i += 32) {  // up to four independent fetches in flight, adds in numpy's order
-            const bool p1 = i + 8 < lim, p2 = i + 16 < lim, p3 = i + 24 < lim;
+        for (int i = 8; i < lim; i += 16) {  // two independent fetches in flight, adds in numpy's order
+            const bool p1 = i + 8 < lim;
             double a0 = f(off + i + j);
             double a1 = p1 ? f(off + i + 8 + j) : 0.0;
-            double a2 = p2 ? f(off + i + 16 + j) : 0.0;
-            double a3 = p3 ? f(off + i + 24 + j) : 0.0;
             r += a0;
             if (p1) r += a1;
-            if (p2) r += a2;
-            if (p3) r += a3;
         }
         // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): each pairing is commutative, so both partners agree
         r += dpp_d<DPP_XOR1>(r);
