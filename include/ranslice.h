@@ -145,7 +145,7 @@ int rs_set_kernel_timing(rs_handle* h, int enable);
 int rs_set_group_size(rs_handle* h, int lanes);
 
 /* Developer aid: cycle sums per code section of the eMBB step kernel (zeros in normal builds). */
-int rs_get_section_profile(rs_handle* h, uint64_t out[8]);
+int rs_get_section_profile(rs_handle* h, uint64_t out[16]);
 
 int rs_synchronize(rs_handle* h);
 int rs_n_vars(const rs_handle* h);

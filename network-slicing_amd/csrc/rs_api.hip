@@ -350,7 +350,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_info, N * h->n_slices * 10);
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
-    DA(h->d_sections, 8);
+    DA(h->d_sections, 16);
     DA(h->d_redo, T ? T : 1);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
@@ -681,10 +681,10 @@ extern "C" int rs_set_group_size(rs_handle* h, int lanes) {
 }
 
 // cycle sums per code section of embb_step_kernel; all zero unless built with -DRS_SECTION_PROFILE
-extern "C" int rs_get_section_profile(rs_handle* h, uint64_t out[8]) {
+extern "C" int rs_get_section_profile(rs_handle* h, uint64_t out[16]) {
     if (!h || !out) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(out, h->d_sections, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sections, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }

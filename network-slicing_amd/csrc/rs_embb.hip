@@ -48,7 +48,7 @@ namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
 #ifdef RS_SECTION_PROFILE
-#define SEC_DECL unsigned long long sec_t0 = __builtin_amdgcn_s_memtime(), sec_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define SEC_DECL unsigned long long sec_t0 = __builtin_amdgcn_s_memtime(), sec_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SEC_MARK(i)                                              \
     {                                                            \
         unsigned long long t_ = __builtin_amdgcn_s_memtime();    \
@@ -57,7 +57,7 @@ namespace rs {
     }
 #define SEC_FLUSH(buf)                                                                                  \
     if ((threadIdx.x & 63u) == 0u)                                                                      \
-        for (int i_ = 0; i_ < 8; ++i_) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);
+        for (int i_ = 0; i_ < 16; ++i_) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);
 #else
 #define SEC_DECL
 #define SEC_MARK(i)
@@ -271,7 +271,7 @@ struct StepArgs {
     double* info;             // [n_envs][n_slices][10]
     uint64_t* counters;       // [n_tasks][4]
     rs_alloc_rec* trace;      // [n_tasks][slots][RS_GROUP] or null
-    uint64_t* sections;       // [8] cycle sums per code section (RS_SECTION_PROFILE builds)
+    uint64_t* sections;       // [16] cycle sums per code section (RS_SECTION_PROFILE builds)
     int32_t* redo;            // [n_tasks] set by a G < 32 launch for tasks it could not hold; consumed by the G = 32 replay
     int32_t replay;           // 1: process only tasks whose redo flag is set
 };
@@ -616,6 +616,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                 flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
                 col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
             }
+            SEC_MARK(7)
             // NSUB UEs per group at a time, one per 8-lane subgroup
             for (int rho = 0; wave_any(rho * NSUB < n_ue); ++rho) {
                 const int k = rho * NSUB + sub;
@@ -652,11 +653,12 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
             int rbs = 0, bits = 0;
             double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
+            SEC_MARK(8)
             for (;;) {
                 const bool more = sched && r < n_prb;
                 if (!wave_any(more)) break;
 #ifdef RS_SECTION_PROFILE
-                sec_acc[7] += 1;  // PF loop trips (not cycles)
+                sec_acc[15] += 1;  // PF loop trips (not cycles)
 #endif
                 // leader = np.argmax (first maximum) and the best of the rest
                 const double mx = group_max<G>(m);
@@ -766,6 +768,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                     }
                 }
             }
+            SEC_MARK(9)
             // R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup, operands from LDS
             double sum_rx = 0.0;
             for (int rho = 0; wave_any(rho * NSUB < nsched); ++rho) {
@@ -782,6 +785,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                 const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << 3));
                 if ((my_rank >> LOG_NSUB) == rho) sum_rx = got;
             }
+            SEC_MARK(10)
             // R3: effective SNR and reception probability, every scheduled UE in its own lane
             if (sched && active && rbs > 0) {
                 const double x0 = D->mcs_x0[mcs], kk = D->mcs_k[mcs];

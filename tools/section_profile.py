@@ -14,27 +14,29 @@ from ranslice.vec_env import VecRanSlice  # noqa: E402
 N = 4096
 env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
 env.reset()
-for i in range(400):
+for i in range(1000):
     env.random_actions(2024, i)
     env.step_resident()
 env.synchronize()
-a = (C.c_uint64 * 8)()
+a = (C.c_uint64 * 16)()
 env.L.rs_get_section_profile(env.h, a)
 base = list(a)
 K = 100
 for i in range(K):
-    env.random_actions(2024, 400 + i)
+    env.random_actions(2024, 1000 + i)
     env.step_resident()
 env.synchronize()
 env.L.rs_get_section_profile(env.h, a)
-d = [a[i] - base[i] for i in range(8)]
-names = ['arrivals+departures', 'traffic_step', 'fading walker + e_snr', 'PF loop', 'RB scan + response',
-         'reception + tx_step', 'update_info', 'unused']
-trips = d[7]
-d[7] = 0
+d = [a[i] - base[i] for i in range(16)]
+# section i accumulates the time from the previous mark to mark i
+names = {0: 'arrivals + timer events', 1: 'traffic_step', 7: 'fading walker', 2: 'e_snr rounds (loads, pairwise sum)',
+         8: 'PF set-up (MCS lookup, first metric)', 3: 'PF loop', 9: 'RB scan + R1 (MI of every RB)',
+         10: 'R2 (pairwise sums from LDS)', 4: 'R3 (inv_sigmoid + rx prob)', 5: 'reception draw + tx_step',
+         6: 'update_info'}
+trips = d[15]
+d[15] = 0
 tot = sum(d) or 1
-waves = N * 5 / 2
-for n, v in zip(names, d):
-    print('%-24s %6.2f%%   %9.0f cycles/wave/step' % (n, 100.0 * v / tot, v / K / waves))
-print('total %.0f cycles/wave/step' % (tot / K / waves))
-print('PF loop trips per wave per slot: %.2f' % (trips / K / waves / 50))
+waves = N * 5 / 4  # 16 lanes per task
+for i in (0, 1, 7, 2, 8, 3, 9, 10, 4, 5, 6):
+    print('%-38s %6.2f%%   %9.0f cycles/wave/slot' % (names[i], 100.0 * d[i] / tot, d[i] / K / waves / 50))
+print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (tot / K / waves / 50, trips / K / waves / 50))
