@@ -12,19 +12,36 @@ from ranslice.fading import synth_fading  # noqa: E402
 from ranslice.vec_env import VecRanSlice  # noqa: E402
 
 N = 4096
+KBRL = '--kbrl' in sys.argv  # drive the env with one KBRL agent per replica instead of random actions
 env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
 env.reset()
-for i in range(1000):
-    env.random_actions(2024, i)
+if KBRL:
+    import numpy as np
+    from ranslice.kbrl_dev import VecKBRL
+    agent = VecKBRL(N, [10] * 5, 200, capacity=512)
+    rng = np.random.default_rng(0)
+    ia = rng.integers(4, 20, size=(N, 5)).astype(np.int32)
+    agent.reset(ia, rng.integers(2, 8, size=(N, 5)).astype(np.int32))
+    env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+
+
+def advance(i):
+    if KBRL:
+        agent.step_resident(env)
+    else:
+        env.random_actions(2024, i)
     env.step_resident()
+
+
+for i in range(300 if KBRL else 1000):
+    advance(i)
 env.synchronize()
 a = (C.c_uint64 * 16)()
 env.L.rs_get_section_profile(env.h, a)
 base = list(a)
 K = 100
 for i in range(K):
-    env.random_actions(2024, 1000 + i)
-    env.step_resident()
+    advance(1000 + i)
 env.synchronize()
 env.L.rs_get_section_profile(env.h, a)
 d = [a[i] - base[i] for i in range(16)]
