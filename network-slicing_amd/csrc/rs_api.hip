@@ -40,6 +40,7 @@ struct rs_handle {
     uint64_t* d_counter_sum = nullptr;  // [4]
     rs_alloc_rec* d_trace = nullptr;
     uint64_t* d_sections = nullptr;
+    double* d_mi_wide = nullptr;
     int32_t* d_redo = nullptr;   // [n_tasks] tasks the fast (G < 32) launch handed to the G = 32 replay
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
@@ -140,6 +141,7 @@ __global__ void reset_kernel(const RsDev* D, RsState S, const uint64_t* seeds_in
         S.t_vbr_at[i] = 1;
         S.t_ctr[i] = 0;
         S.t_serial[i] = 1;
+        S.t_cost[i] = 0;
     }
     if (i < D->n_envs) {
         S.seeds[i] = seeds_in[i];
@@ -336,7 +338,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
 #define DA(p, n)                                   \
     if ((rc = dalloc(h, &(p), (n))) != RS_OK) return rc
     DA(h->ddev, 1);
-    DA(s.t_n_ue, T); DA(s.t_cbr_at, T); DA(s.t_vbr_at, T); DA(s.t_ctr, T); DA(s.t_serial, T);
+    DA(s.t_n_ue, T); DA(s.t_cbr_at, T); DA(s.t_vbr_at, T); DA(s.t_ctr, T); DA(s.t_serial, T); DA(s.t_cost, T);
     DA(s.u_queue, U); DA(s.u_th, U); DA(s.u_nominal, U);
     DA(s.u_hold_at, U); DA(s.u_e_snr, U); DA(s.u_findex, U); DA(s.u_bits, U); DA(s.u_prbs, U);
     DA(s.u_vbr_at, U); DA(s.u_ctr, U); DA(s.u_serial, U); DA(s.u_flags, U);
@@ -352,6 +354,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_counter_sum, 4);
     DA(h->d_sections, 16);
     DA(h->d_redo, T ? T : 1);
+    DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -514,6 +517,7 @@ static int launch_step(rs_handle* h) {
         a.trace = h->d_trace;
         a.sections = h->d_sections;
         a.redo = h->d_redo;
+        a.mi_wide = h->d_mi_wide;
         a.replay = 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {

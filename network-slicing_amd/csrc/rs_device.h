@@ -52,6 +52,7 @@ struct RsState {
     int32_t* t_vbr_at;
     uint32_t* t_ctr;        // slice-level Philox draw counter
     uint32_t* t_serial;     // next UE serial
+    int32_t* t_cost;        // PF loop trips of the task's previous step (scheduling hint only, never affects results)
     // per UE [task][RS_GROUP]
     double* u_queue;
     double* u_th;

@@ -56,8 +56,13 @@ namespace rs {
         sec_t0 = t_;                                             \
     }
 #define SEC_FLUSH(buf)                                                                                  \
-    if ((threadIdx.x & 63u) == 0u)                                                                      \
-        for (int i_ = 0; i_ < 16; ++i_) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);
+    if ((threadIdx.x & 63u) == 0u) {                                                                    \
+        unsigned long long tot_ = 0;                                                                    \
+        for (int i_ = 0; i_ < 13; ++i_) tot_ += sec_acc[i_];                                            \
+        for (int i_ = 0; i_ < 16; ++i_)                                                                 \
+            if (i_ != 14) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);                      \
+        atomicMax((unsigned long long*)&(buf)[14], tot_); /* slowest wave of any launch so far */       \
+    }
 #else
 #define SEC_DECL
 #define SEC_MARK(i)
@@ -274,6 +279,23 @@ struct StepArgs {
     uint64_t* sections;       // [16] cycle sums per code section (RS_SECTION_PROFILE builds)
     int32_t* redo;            // [n_tasks] set by a G < 32 launch for tasks it could not hold; consumed by the G = 32 replay
     int32_t replay;           // 1: process only tasks whose redo flag is set
+    double* mi_wide;          // [n_tasks][RS_MAX_PRBS] scratch rows for slices wider than the LDS slice
+};
+
+// where R1 parks the per-RB mutual information for R2
+struct MiLds {
+    double* p;
+    __device__ __forceinline__ void st(int i, double v) const { p[i] = v; }
+    __device__ __forceinline__ double ld(int i) const { return p[i]; }
+    __device__ __forceinline__ void sync() const {}  // LDS operations of one wave complete in order
+};
+struct MiHbm {
+    double* p;
+    __device__ __forceinline__ void st(int i, double v) const { p[i] = v; }
+    __device__ __forceinline__ double ld(int i) const {  // L1-bypassing: the row is rewritten every slot
+        return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
 template <int G, bool TRACE>
@@ -281,7 +303,8 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     constexpr int NSUB = G / 8;                      // 8-lane subgroups per group
     constexpr int LOG_NSUB = G == 32 ? 2 : (G == 16 ? 1 : 0);
     constexpr int TPB = 256 / G;                     // tasks per block
-    constexpr int MI_CAP = G == 32 ? RS_MAX_PRBS : 112;  // RBs a task may hold in this instance (LDS budget)
+    constexpr int MI_CAP = G == 32 ? RS_MAX_PRBS : 112;  // RBs whose MI values fit the group's LDS slice; wider
+                                                         // slices take the LDS-free variant of R1/R2 below
     __shared__ double lds_mi[TPB][MI_CAP];           // per-group MI values of the slot's RBs
     // Cold per-UE state lives in LDS (one slot per thread, conflict-free), so that the hot loop keeps few
     // enough VGPRs for 4-5 resident waves per SIMD.  Timers are absolute slot numbers; `evt_at` (a VGPR)
@@ -323,9 +346,9 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
 
     // ---- load persistent state
     int n_ue = selected ? S.t_n_ue[task] : 0;
-    // a G < 32 instance gives up a task that does not fit (more UEs than lanes, or more RBs than its
-    // LDS slice): nothing is written back and the G = 32 replay redoes the whole step for it
-    bool aborted = G < 32 && selected && (n_ue > G || n_prb > MI_CAP);
+    // a G < 32 instance gives up a task that has more UEs than lanes: nothing is written back and the
+    // G = 32 replay redoes the whole step for it
+    bool aborted = G < 32 && selected && n_ue > G;
     bool valid = selected && !aborted;
     if (!valid) { n_prb = 0; n_ue = 0; }
     int cbr_at = S.t_cbr_at[task];
@@ -385,6 +408,22 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     double infok_hi = 0.0;  // G = 8 only: info[8], info[9] in lanes 0, 1
     // per-UE running sums (traffic, th(bits), prb) live in L_acc_*; flush() folds them into info[] by class
     unsigned cnt_samples = 0u, cnt_pf = 0u, cnt_ue = 0u;  // per step: < 2^32
+    int pf_trips = 0;  // contested PF trips of this task in this step
+    {
+        // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
+        // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
+        // get issue priority over their lighter neighbours on the SIMD for the whole step.
+        int cost = valid ? S.t_cost[task] : 0;
+#pragma unroll
+        for (int d_ = G; d_ < 64; d_ <<= 1) {
+            const int o = bperm(cost, lane ^ d_);
+            cost = o > cost ? o : cost;
+        }
+        const int c0_ = __builtin_amdgcn_readfirstlane(cost);
+        if (c0_ > 1200) __builtin_amdgcn_s_setprio(3);
+        else if (c0_ > 600) __builtin_amdgcn_s_setprio(2);
+        else if (c0_ > 300) __builtin_amdgcn_s_setprio(1);
+    }
 
     auto flush = [&]() {
         // SliceRANeMBB.update_info's three integer-valued sums (slice_ran.py:282-285,296-299):
@@ -657,6 +696,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
             for (;;) {
                 const bool more = sched && r < n_prb;
                 if (!wave_any(more)) break;
+                if (more) pf_trips += 1;
 #ifdef RS_SECTION_PROFILE
                 sec_acc[15] += 1;  // PF loop trips (not cycles)
 #endif
@@ -724,66 +764,55 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
             const int nsched = __popc(smask);
             const int my_rank = __popc(smask & ((1u << gl) - 1u));  // gl <= 31
             // ---- MCSCodeset.response (channel_models.py:297-313) in three phases.
-            // R1: mutual information of every allocated RB.  Each lane takes KR RBs per pass (G*KR RBs per
-            //     group-pass); the owner UE of an RB is found by walking the (few) scheduled UEs once for all
-            //     KR positions, then the KR sigmoid chains run independently (the path is latency bound, so
-            //     instruction-level parallelism is what pays).  Values go to LDS.
-            constexpr int KR = 1;
-            for (int pass = 0; wave_any(sched && pass * G * KR < n_prb); ++pass) {
-                int o_col[KR], o_mcs[KR], o_rbs[KR];
-                double o_nom[KR];
-#pragma unroll
-                for (int z = 0; z < KR; ++z) { o_col[z] = 0; o_mcs[z] = 0; o_rbs[z] = 0; o_nom[z] = 0.0; }
-                const int k0 = pass * G * KR + gl;
-                unsigned mm = smask;
-                while (wave_any(mm != 0u)) {
-                    const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
-                    const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
-                    const int c_u = bperm(col, src), m_u = bperm(mcs, src);
-                    const double nom_u = L_nom[tb + (src - gbase)];
-#pragma unroll
-                    for (int z = 0; z < KR; ++z) {
-                        const int k = k0 + z * G;
+            // R1 + R2.  R1: mutual information of every allocated RB, one RB per lane and pass; the owner UE of
+            // an RB is found by walking the (few) scheduled UEs.  Values go to the group's LDS slice -- or, for a
+            // slice wider than that slice (n_prb > MI_CAP, rare), to a per-task HBM scratch row read back with
+            // L1-bypassing loads.  R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup.
+            const bool wide = n_prb > MI_CAP;  // group-uniform
+            auto r1r2 = [&](auto mip, const bool sel) -> double {
+                for (int pass = 0; wave_any(sched && sel && pass * G < n_prb); ++pass) {
+                    int o_col = 0, o_mcs = 0, o_rbs = 0;
+                    double o_nom = 0.0;
+                    const int k = pass * G + gl;
+                    unsigned mm = smask;
+                    while (wave_any(mm != 0u)) {
+                        const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
+                        const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
+                        const int c_u = bperm(col, src), m_u = bperm(mcs, src);
+                        const double nom_u = L_nom[tb + (src - gbase)];
                         if (mm != 0u && k >= s_u && k < e_u) {
-                            o_col[z] = c_u;
-                            o_mcs[z] = m_u;
-                            o_rbs[z] = e_u - s_u;
-                            o_nom[z] = nom_u;
+                            o_col = c_u;
+                            o_mcs = m_u;
+                            o_rbs = e_u - s_u;
+                            o_nom = nom_u;
                         }
+                        mm &= mm - 1u;
                     }
-                    mm &= mm - 1u;
-                }
-                double xv[KR];
-#pragma unroll
-                for (int z = 0; z < KR; ++z) {
-                    const int k = k0 + z * G;
-                    xv[z] = (sched && k < n_prb) ? A.fad[o_col[z] + prb_lo + k] + o_nom[z] : 0.0;
-                }
-#pragma unroll
-                for (int z = 0; z < KR; ++z) {
-                    const int k = k0 + z * G;
-                    if (sched && k < n_prb) {
+                    if (sched && sel && k < n_prb) {
+                        const double x = A.fad[o_col + prb_lo + k] + o_nom;
                         // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
-                        mi[k] = o_rbs[z] > 1 ? rs_sigmoid(xv[z], D->mcs_x0[o_mcs[z]], D->mcs_k[o_mcs[z]]) : xv[z];
+                        mip.st(k, o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x);
                     }
                 }
-            }
-            SEC_MARK(9)
-            // R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup, operands from LDS
-            double sum_rx = 0.0;
-            for (int rho = 0; wave_any(rho * NSUB < nsched); ++rho) {
-                const int k = rho * NSUB + sub;
-                const bool have = k < nsched;
-                const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
-                const int c_rbs = bperm(rbs, srcl);
-                const int c_s = bperm(prb_i, srcl);
-                double sv = 0.0;
-                if (have) {
-                    const double* __restrict__ v = mi + c_s;
-                    sv = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return v[i]; });
+                mip.sync();
+                double acc_rx = 0.0;
+                for (int rho = 0; wave_any(sel && rho * NSUB < nsched); ++rho) {
+                    const int k = rho * NSUB + sub;
+                    const bool have = sel && k < nsched;
+                    const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
+                    const int c_rbs = bperm(rbs, srcl);
+                    const int c_s = bperm(prb_i, srcl);
+                    double sv = 0.0;
+                    if (have) sv = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return mip.ld(c_s + i); });
+                    const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << 3));
+                    if ((my_rank >> LOG_NSUB) == rho) acc_rx = got;
                 }
-                const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << 3));
-                if ((my_rank >> LOG_NSUB) == rho) sum_rx = got;
+                return acc_rx;
+            };
+            double sum_rx = r1r2(MiLds{mi}, !wide);
+            if (wave_any(sched && wide)) {
+                const double s2 = r1r2(MiHbm{A.mi_wide + (size_t)task * RS_MAX_PRBS}, wide);
+                if (wide) sum_rx = s2;
             }
             SEC_MARK(10)
             // R3: effective SNR and reception probability, every scheduled UE in its own lane
@@ -910,6 +939,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
             S.t_vbr_at[task] = vbr_at;
             S.t_ctr[task] = sl_ctr;
             S.t_serial[task] = next_serial;
+            S.t_cost[task] = pf_trips;
             uint64_t* c = A.counters + (size_t)task * 4;
             c[0] += cnt_samples;
             c[2] += cnt_pf;

@@ -52,8 +52,11 @@ names = {0: 'arrivals + timer events', 1: 'traffic_step', 7: 'fading walker', 2:
          6: 'update_info'}
 trips = d[15]
 d[15] = 0
+slowest = a[14]
+d[14] = 0
 tot = sum(d) or 1
 waves = N * 5 / 4  # 16 lanes per task
 for i in (0, 1, 7, 2, 8, 3, 9, 10, 4, 5, 6):
     print('%-38s %6.2f%%   %9.0f cycles/wave/slot' % (names[i], 100.0 * d[i] / tot, d[i] / K / waves / 50))
+print('slowest wave of any launch: %.0f cycles/slot (mean wave: %.0f)' % (slowest / 50, tot / K / waves / 50))
 print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (tot / K / waves / 50, trips / K / waves / 50))
