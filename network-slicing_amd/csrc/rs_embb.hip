@@ -146,17 +146,18 @@ __device__ __forceinline__ double group_sum(double v) {
 template <int G>
 __device__ __forceinline__ double group_max(double v) {
     double o;
-    o = dpp_d<DPP_XOR1>(v); v = o > v ? o : v;
-    o = dpp_d<DPP_XOR2>(v); v = o > v ? o : v;
-    o = dpp_d<DPP_HMIRROR>(v); v = o > v ? o : v;
-    if (G >= 16) { o = dpp_d<DPP_MIRROR>(v); v = o > v ? o : v; }
+    // operands are finite (metrics >= 0 or the -1 / -2 sentinels): fmax == the plain maximum, one v_max_f64
+    o = dpp_d<DPP_XOR1>(v); v = __builtin_fmax(o, v);
+    o = dpp_d<DPP_XOR2>(v); v = __builtin_fmax(o, v);
+    o = dpp_d<DPP_HMIRROR>(v); v = __builtin_fmax(o, v);
+    if (G >= 16) { o = dpp_d<DPP_MIRROR>(v); v = __builtin_fmax(o, v); }
     if (G == 32) {
         uint64_t u = rs_d2u(v);
         auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
         auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
         double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
         double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
-        v = a > b ? a : b;
+        v = __builtin_fmax(a, b);
     }
     return v;
 }
