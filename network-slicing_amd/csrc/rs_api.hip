@@ -23,6 +23,7 @@ struct rs_handle {
     RsDev hdev;            // host copy of the device constants
     RsDev* ddev = nullptr;
     RsState st;
+    RsState* d_st = nullptr;  // device copy of `st`
     MtcState mst;
     std::vector<void*> allocs;
     double* fad = nullptr;
@@ -354,9 +355,11 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_counter_sum, 4);
     DA(h->d_sections, 16);
     DA(h->d_redo, T ? T : 1);
+    DA(h->d_st, 1);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
+    HIPCHK(h, hipMemcpyAsync(h->d_st, &h->st, sizeof(RsState), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }
@@ -504,7 +507,7 @@ static int launch_step(rs_handle* h) {
     if (h->n_tasks > 0) {
         StepArgs a;
         a.D = h->ddev;
-        a.S = h->st;
+        a.S = h->d_st;
         a.fad = h->fad;
         a.fad_valid = h->fad_valid;
         a.actions = h->d_actions;

@@ -266,7 +266,7 @@ __device__ __forceinline__ int rint_slots(double seconds_or_slots, double slot_l
 
 struct StepArgs {
     const RsDev* D;
-    RsState S;
+    const RsState* S;         // device copy of the state pointers (kept out of the kernarg SGPRs)
     const double* fad;        // [trace][time][P]
     const uint8_t* fad_valid; // [trace][time]
     const int32_t* actions;   // [n_envs][n_slices]
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     __shared__ int L_acc_traf[256], L_acc_bits[256], L_acc_prbs[256];
     __shared__ double L_nom[256];            // nominal SINR
     const RsDev* __restrict__ D = A.D;
-    const RsState& S = A.S;
+    const RsState& S = *A.S;
     double* const mi = lds_mi[threadIdx.x / G];
     const int lane = (int)(threadIdx.x & 63u);
     const int gl = lane & (G - 1);       // UE index owned by this lane
