@@ -722,8 +722,11 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                             // nobody else has data: it wins every RB pair until drained -> closed form
                             const int R = n_prb - r;
                             const int per_it = gran * rate;
-                            const int k_full = (q + per_it - 1) / per_it;  // RB pairs needed to drain
-                            const int K = (R + gran - 1) / gran;           // RB pairs left
+                            // ceil divisions through one IEEE f64 divide each (exact: operands < 2^31 and the
+                            // quotient of two integers is never within rounding distance of the next integer);
+                            // the 32-bit integer divide costs ~40 VALU instructions on this ISA
+                            const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
+                            const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
                             const bool all = k_full >= K;
                             const int cap_bits = R * rate;
                             const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
@@ -840,7 +843,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                 ue_bits = bits;
                 ue_prbs = rbs;
             }
-            if (sched) cnt_pf += (unsigned)((n_prb + gran - 1) / gran);
+            if (sched) cnt_pf += (unsigned)((double)(n_prb + gran - 1) / (double)gran);
         }
 
         SEC_MARK(5)
