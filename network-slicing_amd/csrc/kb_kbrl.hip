@@ -95,7 +95,11 @@ __device__ __forceinline__ double block_sum(double v, Lds& sm) {
 __device__ void prepare_operands(const KbDev& D, const KbState& K, int dict, int m, int d, Lds& sm) {
     const int cap = D.cap;
     const double* L = K.L + (size_t)dict * KB_DMAX * cap;
-    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+    // entries beyond the dictionary must read as zero coefficients up to the end of the last 16-landmark tile
+    // (apply_update clears a new tile when the dictionary grows into it)
+    int lim = (m + 16) & ~15;
+    lim = lim < 1024 ? lim : 1024;
+    for (int j = threadIdx.x; j < lim; j += blockDim.x) {
         double d0 = 0.0, lam = 0.0, co = 0.0;
         if (j < m) {
             for (int q = 0; q < d - 1; ++q) {
@@ -231,6 +235,11 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
     double* L = K.L + (size_t)dict * KB_DMAX * cap;
     const double t = (double)c / (double)D.n_prbs;
+    if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < 1024) {
+        // the landmark after this one opens a new 16-landmark tile: make it read as empty
+        const int j = m + 1 + threadIdx.x;
+        sm.d0[j] = 0.0; sm.lam[j] = 0.0; sm.bq[j] = 0.0; sm.bl[j] = 0.0; sm.co[j] = 0.0;
+    }
     if (threadIdx.x == 0) {
         for (int q = 0; q < d - 1; ++q) L[(size_t)q * cap + m] = sm.x[q];
         L[(size_t)(d - 1) * cap + m] = t;
