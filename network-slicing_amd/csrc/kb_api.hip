@@ -199,7 +199,7 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
-    hipLaunchKernelGGL(kb::update_control_kernel, dim3((unsigned)k->T), dim3(256), 0, k->stream, a);
+    hipLaunchKernelGGL(kb::update_control_kernel, dim3((unsigned)k->T), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     return RS_OK;
 }
@@ -212,7 +212,7 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
-    hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T), dim3(256), 0, k->stream, a);
+    hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,
                        k->K, d_action_out);
@@ -306,9 +306,9 @@ static int kb_one(kb_handle* k, int e, int s, const double* x, int y, bool updat
     for (int q = 0; q < k->cfg.dims[s] + 1; ++q) a.x[q] = x[q];
     a.out = k->d_out;
     if (update)
-        hipLaunchKernelGGL(kb::update_one_kernel, dim3(1), dim3(256), 0, k->stream, a);
+        hipLaunchKernelGGL(kb::update_one_kernel, dim3(1), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, a);
     else
-        hipLaunchKernelGGL(kb::predict_one_kernel, dim3(1), dim3(256), 0, k->stream, a);
+        hipLaunchKernelGGL(kb::predict_one_kernel, dim3(1), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, a);
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipMemcpyAsync(out, k->d_out, sizeof(double) * 4, hipMemcpyDeviceToHost, k->stream));
     return kb_check(k);
@@ -469,7 +469,7 @@ extern "C" int kb_shared_scan(kb_handle* k, const float* state, const int32_t* a
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
-    hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(256), 0, k->stream, a);
+    hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::shared_collect_kernel, dim3((unsigned)S), dim3(64), 0, k->stream, k->D, k->d_state, k->d_labels,
                        k->d_cstar, (int)budget, k->d_props, k->d_counts);
@@ -492,7 +492,7 @@ extern "C" int kb_shared_apply(kb_handle* k, const int32_t* counts, const double
     const size_t S = (size_t)k->cfg.n_slices;
     HIPCHK(k, hipMemcpyAsync(k->d_counts, counts, sizeof(int32_t) * S, hipMemcpyHostToDevice, k->stream));
     HIPCHK(k, hipMemcpyAsync(k->d_props, props, sizeof(double) * S * budget * KB_PROP_W, hipMemcpyHostToDevice, k->stream));
-    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3((unsigned)S), dim3(256), 0, k->stream, k->D, k->K, k->d_props,
+    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3((unsigned)S), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, k->D, k->K, k->d_props,
                        k->d_counts, (int)budget, k->d_gstats);
     HIPCHK(k, hipGetLastError());
     return kb_check(k);

@@ -67,19 +67,48 @@ __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int
 }
 
 // Shared-memory working set of one learner
+// Per-block LDS working set, carved out of dynamic shared memory so a block only occupies what its
+// dictionary capacity needs (7 columns of cap rounded up to a 16-landmark tile): at capacity 256 that is
+// 17 KB instead of 60 KB, i.e. 8 resident blocks per CU instead of 2.
 struct Lds {
-    double bq[1024];   // D0_j + lam_j^2
-    double bl[1024];   // -2 lam_j
-    double lam[1024];  // lam_j (last coordinate of the landmark)
-    double d0[1024];   // D0_j
-    double co[1024];   // coeff_j
-    double kf[1024];   // kernel column of the candidate being updated
-    double ds[1024];   // d* = Kinv k_f
-    double f[KB_CAND_MAX];
-    double x[KB_DMAX];
-    double red[8];
-    int ired[8];
+    double* bq;   // D0_j + lam_j^2
+    double* bl;   // -2 lam_j
+    double* lam;  // lam_j (last coordinate of the landmark)
+    double* d0;   // D0_j
+    double* co;   // coeff_j
+    double* kf;   // kernel column of the candidate being updated
+    double* ds;   // d* = Kinv k_f
+    double* f;    // [KB_CAND_MAX]
+    double* x;    // [KB_DMAX]
+    double* red;  // [8]
+    int* ired;    // [8]
+    int capr;     // column length (capacity rounded up to 16)
 };
+
+__host__ __device__ inline int kb_capr(int cap) { return (cap + 15) & ~15; }
+__host__ __device__ inline size_t kb_lds_bytes(int cap) {
+    return ((size_t)7 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 8) * sizeof(double) + 8 * sizeof(int);
+}
+
+__device__ __forceinline__ Lds carve_lds(int cap) {
+    extern __shared__ double kb_dyn_lds[];
+    Lds sm;
+    const int c = kb_capr(cap);
+    double* p = kb_dyn_lds;
+    sm.bq = p; p += c;
+    sm.bl = p; p += c;
+    sm.lam = p; p += c;
+    sm.d0 = p; p += c;
+    sm.co = p; p += c;
+    sm.kf = p; p += c;
+    sm.ds = p; p += c;
+    sm.f = p; p += KB_CAND_MAX;
+    sm.x = p; p += KB_DMAX;
+    sm.red = p; p += 8;
+    sm.ired = (int*)p;
+    sm.capr = c;
+    return sm;
+}
 
 __device__ __forceinline__ double block_sum(double v, Lds& sm) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
@@ -98,7 +127,7 @@ __device__ void prepare_operands(const KbDev& D, const KbState& K, int dict, int
     // entries beyond the dictionary must read as zero coefficients up to the end of the last 16-landmark tile
     // (apply_update clears a new tile when the dictionary grows into it)
     int lim = (m + 16) & ~15;
-    lim = lim < 1024 ? lim : 1024;
+    lim = lim < sm.capr ? lim : sm.capr;
     for (int j = threadIdx.x; j < lim; j += blockDim.x) {
         double d0 = 0.0, lam = 0.0, co = 0.0;
         if (j < m) {
@@ -235,7 +264,7 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
     double* L = K.L + (size_t)dict * KB_DMAX * cap;
     const double t = (double)c / (double)D.n_prbs;
-    if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < 1024) {
+    if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < sm.capr) {
         // the landmark after this one opens a new 16-landmark tile: make it read as empty
         const int j = m + 1 + threadIdx.x;
         sm.d0[j] = 0.0; sm.lam[j] = 0.0; sm.bq[j] = 0.0; sm.bl[j] = 0.0; sm.co[j] = 0.0;
@@ -277,8 +306,8 @@ struct CtlArgs {
 
 // KBRL_Control.update_control for one learner (kbrl_control.py:83-112)
 __global__ __launch_bounds__(256) void update_control_kernel(CtlArgs A) {
-    __shared__ Lds sm;
     const KbDev& D = A.D;
+    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
@@ -389,8 +418,8 @@ struct SelArgs {
 
 // per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63)
 __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
-    __shared__ Lds sm;
     const KbDev& D = A.D;
+    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
@@ -494,8 +523,8 @@ struct ScanArgs {
 };
 
 __global__ __launch_bounds__(256) void shared_scan_kernel(ScanArgs A) {
-    __shared__ Lds sm;
     const KbDev& D = A.D;
+    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
@@ -621,7 +650,7 @@ __global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_
 // apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
 __global__ __launch_bounds__(256) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                          int budget, uint64_t* gstats) {
-    __shared__ Lds sm;
+    Lds sm = carve_lds(D.cap);
     const int s = blockIdx.x;
     const int d = D.dims[s] + 1;
     int m = K.m[s];
@@ -670,8 +699,8 @@ struct OneArgs {
 };
 
 __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
-    __shared__ Lds sm;
     const KbDev& D = A.D;
+    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
@@ -710,8 +739,8 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
 }
 
 __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
-    __shared__ Lds sm;
     const KbDev& D = A.D;
+    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
@@ -726,7 +755,7 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     // stage x, coefficients and the cached kernel row; apply_update works on (state, c/n) so the
     // last coordinate is handed over through sm.lam/sm.x with n_prbs-independent arithmetic
     for (int q = threadIdx.x; q < d; q += blockDim.x) sm.x[q] = A.x[q];
-    for (int j = threadIdx.x; j < 1024; j += blockDim.x) {
+    for (int j = threadIdx.x; j < sm.capr; j += blockDim.x) {
         sm.co[j] = j < m ? K.coeff[(size_t)dt * cap + j] : 0.0;
         sm.kf[j] = j < (m > 0 ? m : 1) ? K.kf[(size_t)task * cap + j] : 0.0;
     }
