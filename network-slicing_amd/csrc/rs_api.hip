@@ -13,6 +13,7 @@
 
 #include "rs_embb.hip"
 #include "rs_mmtc.hip"
+#include "rs_order.hip"
 
 using namespace rs;
 
@@ -43,6 +44,11 @@ struct rs_handle {
     uint64_t* d_sections = nullptr;
     double* d_mi_wide = nullptr;
     int32_t* d_redo = nullptr;   // [n_tasks] tasks the fast (G < 32) launch handed to the G = 32 replay
+    int32_t* d_order = nullptr;  // [n_tasks] launch order of the step tasks (rs_order.hip)
+    uint64_t* d_oslot = nullptr; // [n_tasks] counting-sort scratch
+    int* d_ohist = nullptr;      // [2][RS_ORDER_BINS] bin counters, alternating between steps
+    int order_par = 0;           // which half of d_ohist the next step counts into
+    int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;
@@ -353,8 +359,13 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_info, N * h->n_slices * 10);
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
-    DA(h->d_sections, 16);
+    DA(h->d_sections, 16 + 4 * (T ? T : 1));
     DA(h->d_redo, T ? T : 1);
+    DA(h->d_order, T ? T : 1);
+    DA(h->d_oslot, T ? T : 1);
+    DA(h->d_ohist, 2 * RS_ORDER_BINS);
+    HIPCHK(h, hipMemset(h->d_ohist, 0, sizeof(int) * 2 * RS_ORDER_BINS));
+    if (const char* e = getenv("RANSLICE_ORDER")) h->order_mode = atoi(e);
     DA(h->d_st, 1);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
@@ -522,6 +533,7 @@ static int launch_step(rs_handle* h) {
         a.redo = h->d_redo;
         a.mi_wide = h->d_mi_wide;
         a.replay = 0;
+        a.order = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -552,7 +564,19 @@ static int launch_step(rs_handle* h) {
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
         // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)
+        if (h->order_mode > 0) {
+            const int par = h->order_par;
+            h->order_par ^= 1;
+            const unsigned nb = (unsigned)((h->n_tasks + 255) / 256);
+            hipLaunchKernelGGL(order_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev, h->d_st, h->d_actions,
+                               h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot);
+            hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
+                               h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
+                               h->d_order, h->order_mode > 3 ? 1 : 0, 64 / h->group);
+            a.order = h->d_order;
+        }
         launch(h->group);
+        a.order = nullptr;
         if (h->group < 32) {
             a.replay = 1;
             launch(32);
@@ -692,6 +716,15 @@ extern "C" int rs_get_section_profile(rs_handle* h, uint64_t out[16]) {
     if (!h || !out) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpyAsync(out, h->d_sections, sizeof(uint64_t) * 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+extern "C" int rs_get_task_profile(rs_handle* h, uint64_t* out) {
+    if (!h || !out) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sections + 16, sizeof(uint64_t) * 4 * (size_t)h->n_tasks, hipMemcpyDeviceToHost,
+                             h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }

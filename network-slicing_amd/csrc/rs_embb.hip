@@ -47,6 +47,10 @@ __device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
 namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
+#ifndef RS_LPU
+#define RS_LPU 4
+#endif
+
 #ifdef RS_SECTION_PROFILE
 #define SEC_DECL unsigned long long sec_t0 = __builtin_amdgcn_s_memtime(), sec_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define SEC_MARK(i)                                              \
@@ -62,6 +66,14 @@ namespace rs {
         for (int i_ = 0; i_ < 16; ++i_)                                                                 \
             if (i_ != 14) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);                      \
         atomicMax((unsigned long long*)&(buf)[14], tot_); /* slowest wave of any launch so far */       \
+    }                                                                                                   \
+    if (gl == 0 && valid) { /* per task: cycles of its wave, UEs and RBs at the start, contested PF trips */ \
+        unsigned long long tot_ = 0;                                                                    \
+        for (int i_ = 0; i_ < 13; ++i_) tot_ += sec_acc[i_];                                            \
+        (buf)[16 + task * 4 + 0] = tot_;                                                                \
+        (buf)[16 + task * 4 + 1] = (unsigned long long)S.t_n_ue[task];                                  \
+        (buf)[16 + task * 4 + 2] = (unsigned long long)A.actions[rep * n_slices + sl];                  \
+        (buf)[16 + task * 4 + 3] = (unsigned long long)pf_trips;                                        \
     }
 #else
 #define SEC_DECL
@@ -181,46 +193,81 @@ __device__ __forceinline__ int kth_set_bit(unsigned m, int k) {
     return m ? __ffs((int)m) - 1 : 0;
 }
 
-// numpy pairwise sum of f(0..n-1) evaluated cooperatively by the 8 lanes of a subgroup
-// (lane j == strided accumulator j of numpy's unrolled loop).  Every lane of the subgroup
-// must call it with the same n.  The result is valid in lane 0 of the subgroup (the tree part is
-// valid in all 8 lanes; the sequential remainder is folded towards lane 0 with row_shl:1).  n <= 256.
-template <class F>
-__device__ __forceinline__ double sub8_block(int off, int n, int j, int lane, F f) {
+// numpy pairwise sum of f(0..n-1) evaluated cooperatively by the LPU lanes of a subgroup (LPU = 8, 4 or 2).
+// numpy's unrolled loop keeps 8 strided accumulators R_0..R_7; lane j of the subgroup owns R_(a*LPU + j),
+// a = 0..8/LPU-1, so a narrower subgroup carries more (independent) chains per lane and a group holds more
+// UEs per pass.  Every lane of the subgroup must call it with the same n.  The result is valid in lane 0 of
+// the subgroup (the tree part in all of its lanes; the sequential remainder is folded towards lane 0 with
+// row_shl:1).  n <= 128 per block.
+template <int LPU, class F>
+__device__ __forceinline__ double subl_block(int off, int n, int j, F f) {
+    constexpr int ACC = 8 / LPU;
     double res = 0.0;
     const int lim = n >= 8 ? n - (n & 7) : 0;
     const int rem = n - lim;
-    // the sequential remainder's operand is independent of the tree: fetch it first
-    double v = j < rem ? f(off + lim + j) : 0.0;
+    // the sequential remainder's operands are independent of the tree: fetch them first
+    double v[ACC];
+#pragma unroll
+    for (int a = 0; a < ACC; ++a) v[a] = a * LPU + j < rem ? f(off + lim + a * LPU + j) : 0.0;
     if (n >= 8) {
-        double r = f(off + j);
-        for (int i = 8; i < lim; i += 16) {  // two independent fetches in flight, adds in numpy's order
-            const bool p1 = i + 8 < lim;
-            double a0 = f(off + i + j);
-            double a1 = p1 ? f(off + i + 8 + j) : 0.0;
-            r += a0;
-            if (p1) r += a1;
+        double r[ACC];
+#pragma unroll
+        for (int a = 0; a < ACC; ++a) r[a] = f(off + a * LPU + j);
+        if (LPU == 8) {
+            for (int i = 8; i < lim; i += 16) {  // two independent fetches in flight, adds in numpy's order
+                const bool p1 = i + 8 < lim;
+                double a0 = f(off + i + j);
+                double a1 = p1 ? f(off + i + 8 + j) : 0.0;
+                r[0] += a0;
+                if (p1) r[0] += a1;
+            }
+        } else {
+            for (int i = 8; i < lim; i += 8) {
+                double t[ACC];
+#pragma unroll
+                for (int a = 0; a < ACC; ++a) t[a] = f(off + i + a * LPU + j);
+#pragma unroll
+                for (int a = 0; a < ACC; ++a) r[a] += t[a];
+            }
         }
-        // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)): each pairing is commutative, so both partners agree
-        r += dpp_d<DPP_XOR1>(r);
-        r += dpp_d<DPP_XOR2>(r);
-        r += dpp_d<DPP_HMIRROR>(r);
-        res = r;
+        // ((R0+R1)+(R2+R3))+((R4+R5)+(R6+R7)): each pairing is commutative, so both partners agree
+        if (LPU == 8) {
+            r[0] += dpp_d<DPP_XOR1>(r[0]);
+            r[0] += dpp_d<DPP_XOR2>(r[0]);
+            r[0] += dpp_d<DPP_HMIRROR>(r[0]);
+            res = r[0];
+        } else if (LPU == 4) {
+            r[0] += dpp_d<DPP_XOR1>(r[0]);
+            r[ACC - 1] += dpp_d<DPP_XOR1>(r[ACC - 1]);
+            r[0] += dpp_d<DPP_XOR2>(r[0]);
+            r[ACC - 1] += dpp_d<DPP_XOR2>(r[ACC - 1]);
+            res = r[0] + r[ACC - 1];
+        } else {
+#pragma unroll
+            for (int a = 0; a < ACC; ++a) r[a] += dpp_d<DPP_XOR1>(r[a]);
+            res = (r[0] + r[1 % ACC]) + (r[2 % ACC] + r[3 % ACC]);
+        }
     }
-    for (int k = 0; k < rem; ++k) {
-        res += v;                 // lane 0: v_k
-        v = dpp_d<0x101>(v);      // row_shl:1: lane i <- lane i+1
+#pragma unroll
+    for (int a = 0; a < ACC; ++a) {
+#pragma unroll
+        for (int s_ = 0; s_ < LPU; ++s_) {
+            if (a * LPU + s_ < rem) {
+                res += v[a];                 // lane 0: element a * LPU + s_ of the remainder
+                v[a] = dpp_d<0x101>(v[a]);   // row_shl:1: lane i <- lane i+1
+            }
+        }
     }
     return res;
 }
 
-template <class F>
-__device__ __forceinline__ double sub8_pairwise(int n, int j, int lane, F f) {
-    if (n <= 128) return sub8_block(0, n, j, lane, f);
+template <int LPU, class F>
+__device__ __forceinline__ double subl_pairwise(int n, int j, F f) {
+    if (n <= 128) return subl_block<LPU>(0, n, j, f);
     int n2 = n >> 1;
     n2 -= n2 & 7;
-    double a = sub8_block(0, n2, j, lane, f);
-    double b = sub8_block(n2, n - n2, j, lane, f);
+    double a = subl_block<LPU>(0, n2, j, f);
+    double b = subl_block<LPU>(n2, n - n2, j, f);
     return a + b;
 }
 
@@ -281,6 +328,7 @@ struct StepArgs {
     int32_t* redo;            // [n_tasks] set by a G < 32 launch for tasks it could not hold; consumed by the G = 32 replay
     int32_t replay;           // 1: process only tasks whose redo flag is set
     double* mi_wide;          // [n_tasks][RS_MAX_PRBS] scratch rows for slices wider than the LDS slice
+    const int32_t* order;     // [n_tasks] launch order of the tasks (rs_order.hip) or null = task index order
 };
 
 // where R1 parks the per-RB mutual information for R2
@@ -301,8 +349,10 @@ struct MiHbm {
 
 template <int G, bool TRACE>
 __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArgs A) {
-    constexpr int NSUB = G / 8;                      // 8-lane subgroups per group
-    constexpr int LOG_NSUB = G == 32 ? 2 : (G == 16 ? 1 : 0);
+    constexpr int LPU = RS_LPU;                      // lanes that share one UE's pairwise sums
+    constexpr int LOG_LPU = LPU == 8 ? 3 : (LPU == 4 ? 2 : 1);
+    constexpr int NSUB = G / LPU;                    // subgroups (UEs per pass) in a group
+    constexpr int LOG_NSUB = (G == 32 ? 5 : (G == 16 ? 4 : 3)) - LOG_LPU;
     constexpr int TPB = 256 / G;                     // tasks per block
     constexpr int MI_CAP = G == 32 ? RS_MAX_PRBS : 112;  // RBs whose MI values fit the group's LDS slice; wider
                                                          // slices take the LDS-free variant of R1/R2 below
@@ -322,14 +372,15 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     const int lane = (int)(threadIdx.x & 63u);
     const int gl = lane & (G - 1);       // UE index owned by this lane
     const int gbase = lane & ~(G - 1);   // first lane of my group inside the wave
-    const int sub = gl >> 3;             // 8-lane subgroup inside the group
-    const int j8 = gl & 7;
+    const int sub = gl >> LOG_LPU;       // subgroup inside the group
+    const int j8 = gl & (LPU - 1);
     const int tid = (int)threadIdx.x;
     const int tb = tid - gl;             // first thread of my group in the block
     const int n_tasks = D->n_envs * D->n_embb;
     int task = (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
     const bool in_range = task < n_tasks;
     if (!in_range) task = n_tasks - 1;
+    if (A.order) task = A.order[task];
     const bool selected = in_range && (!A.replay || A.redo[task] != 0);
     if (!wave_any(selected)) return;  // replay launch: nothing flagged in this wave
     const int rep = task / D->n_embb;
@@ -654,10 +705,14 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                     if (!D->has_nan || A.fad_valid[D->valid_off[ftype] + findex]) break;  // Q10
                 }
                 flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
+#ifdef RS_EXP_NOMISS  // timing experiment only: every fading load hits the cache
+                col = (int)(D->fad_off[ftype] + (int64_t)(findex & 3) * P);
+#else
                 col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
+#endif
             }
             SEC_MARK(7)
-            // NSUB UEs per group at a time, one per 8-lane subgroup
+            // NSUB UEs per group at a time, one per subgroup
             for (int rho = 0; wave_any(rho * NSUB < n_ue); ++rho) {
                 const int k = rho * NSUB + sub;
                 const bool have = k < n_ue;
@@ -667,10 +722,10 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                 int es = 0;
                 if (have) {
                     const double* __restrict__ base = A.fad + c_col + prb_lo;
-                    double sum = sub8_pairwise(n_prb, j8, lane, [&](int i) { return base[i] + c_nom; });
+                    double sum = subl_pairwise<LPU>(n_prb, j8, [&](int i) { return base[i] + c_nom; });
                     es = (int)RS_RINT(sum / (double)n_prb);  // round(np.mean(...)): half-to-even (Q7)
                 }
-                const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << 3));
+                const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << LOG_LPU));
                 if (active && (gl >> LOG_NSUB) == rho) e_snr = got;
             }
             cnt_samples += (unsigned)(n_ue * n_prb);
@@ -807,8 +862,8 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                     const int c_rbs = bperm(rbs, srcl);
                     const int c_s = bperm(prb_i, srcl);
                     double sv = 0.0;
-                    if (have) sv = sub8_pairwise(c_rbs, j8, lane, [&](int i) { return mip.ld(c_s + i); });
-                    const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << 3));
+                    if (have) sv = subl_pairwise<LPU>(c_rbs, j8, [&](int i) { return mip.ld(c_s + i); });
+                    const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << LOG_LPU));
                     if ((my_rank >> LOG_NSUB) == rho) acc_rx = got;
                 }
                 return acc_rx;

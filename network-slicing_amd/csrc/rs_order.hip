@@ -1,0 +1,99 @@
+// Launch order of the eMBB step tasks.
+//
+// All waves of a 4096-replica launch are co-resident (5 per SIMD), so the launch ends when its slowest wave
+// ends, and a wave's 64/G tasks run in lockstep: every loop runs for the largest trip count among them.
+// Measured (tools/section_profile.py): the slowest waves are the ones where two or three expensive tasks met,
+// because their peaks fall into different slots and add up.  Tasks are therefore ranked by predicted cost
+// (fading samples per slot + the contested PF trips of their previous step) and every wave gets ONE task from
+// the heavy end of the ranking and 64/G - 1 from the light end, heaviest waves first: the dispatcher fills
+// the SIMDs round by round (tools/ubench/placement.hip: every SIMD receives one wave of blocks
+// [256k, 256k + 256)), so each SIMD also gets one wave of each cost stratum, and for batches larger than the
+// chip the order is longest-processing-time-first.  The order only decides which lanes simulate which
+// (replica, slice); results do not depend on it.  RANSLICE_ORDER=0 turns it off, 1-3 sort without pairing
+// (measured slower: homogeneous heavy waves are the slowest of all).
+//
+// Counting sort in two launches: keys + per-bin ranks (atomics), then prefix sums + scatter.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rs_device.h"
+
+namespace rs {
+
+#define RS_ORDER_BINS 2048
+
+__device__ __forceinline__ int order_key(int mode, int n_ue, int n_prb, int cost) {
+    int key;
+    mode = mode > 3 ? mode - 3 : mode;
+    if (mode == 2) key = n_ue * 64 + (n_prb >> 2);  // UE count first, then width
+    else if (mode == 3) key = n_ue * n_prb + cost;  // work + last step's contested PF trips
+    else key = n_ue * n_prb;                         // fading samples per slot
+    key = key < 0 ? 0 : key;
+    return key < RS_ORDER_BINS ? key : RS_ORDER_BINS - 1;
+}
+
+// hist: this step's bin counters (zero on entry); slot[task] = bin | rank-in-bin << 11
+__global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict__ D, const RsState* __restrict__ Sp,
+                                                        const int32_t* __restrict__ actions, int mode, int* hist,
+                                                        uint64_t* slot) {
+    const int n_tasks = D->n_envs * D->n_embb;
+    const int task = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (task >= n_tasks) return;
+    const int rep = task / D->n_embb, sl = task - rep * D->n_embb;
+    const int n_prb = actions[rep * D->n_slices + sl];
+    const int bin = RS_ORDER_BINS - 1 - order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);  // heaviest first
+    const int rank = atomicAdd(&hist[bin], 1);
+    slot[task] = (uint64_t)bin | ((uint64_t)rank << 11);
+}
+
+// order[start(bin) + rank] = task; also clears the other parity's counters for the next step
+__global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restrict__ D, const int* __restrict__ hist,
+                                                            int* hist_next, const uint64_t* __restrict__ slot,
+                                                            int32_t* order, int pair, int tpw) {
+    __shared__ int start[RS_ORDER_BINS];
+    __shared__ int part[256];
+    constexpr int PER = RS_ORDER_BINS / 256;
+    int loc[PER];
+    int s = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        loc[k] = s;
+        s += hist[threadIdx.x * PER + k];
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    // exclusive scan of the 256 partial sums (Hillis-Steele)
+    int incl = s;
+    for (int d = 1; d < 256; d <<= 1) {
+        const int o = (int)threadIdx.x >= d ? part[threadIdx.x - d] : 0;
+        __syncthreads();
+        incl += o;
+        part[threadIdx.x] = incl;
+        __syncthreads();
+    }
+    const int excl = incl - s;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) start[threadIdx.x * PER + k] = excl + loc[k];
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int k = threadIdx.x; k < RS_ORDER_BINS; k += 256) hist_next[k] = 0;
+    const int n_tasks = D->n_envs * D->n_embb;
+    const int task = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (task >= n_tasks) return;
+    const uint64_t v = slot[task];
+    int p = start[(int)(v & (RS_ORDER_BINS - 1))] + (int)(v >> 11);  // rank, heaviest first
+    if (pair && tpw > 1 && n_tasks % tpw == 0) {
+        // one heavy task per wave (tpw tasks), filled up with tpw - 1 from the light end: the heavy task's
+        // trip counts then set the wave's pace alone instead of adding up with other heavy tasks' peaks
+        const int W = n_tasks / tpw;
+        if (p < W) p = tpw * p;
+        else {
+            const int q = n_tasks - 1 - p;
+            p = tpw * (q / (tpw - 1)) + 1 + q % (tpw - 1);
+        }
+    }
+    order[p] = task;
+}
+
+}  // namespace rs

@@ -60,3 +60,25 @@ for i in (0, 1, 7, 2, 8, 3, 9, 10, 4, 5, 6):
     print('%-38s %6.2f%%   %9.0f cycles/wave/slot' % (names[i], 100.0 * d[i] / tot, d[i] / K / waves / 50))
 print('slowest wave of any launch: %.0f cycles/slot (mean wave: %.0f)' % (slowest / 50, tot / K / waves / 50))
 print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (tot / K / waves / 50, trips / K / waves / 50))
+
+# per-task view of the last step: which tasks sit in the slowest waves?
+import numpy as np
+tp = np.zeros((N * 5, 4), dtype=np.uint64)
+env.L.rs_get_task_profile(env.h, tp.ctypes.data_as(C.POINTER(C.c_uint64)))
+cyc = tp[:, 0].astype(np.float64) / 50
+print('last step: wave cycles/slot percentiles 50/90/99/99.9/max: %s' % np.percentile(cyc, [50, 90, 99, 99.9, 100]).round(0))
+idx = np.argsort(-cyc)
+seen = set()
+print('slowest waves (cycles/slot : [n_ue, n_prb, pf_trips] of their tasks)')
+for i in idx:
+    c = cyc[i]
+    if c in seen:
+        continue
+    seen.add(c)
+    members = np.nonzero(cyc == c)[0]
+    print('  %8.0f : %s' % (c, ' '.join('[%d,%d,%d]' % (tp[m, 1], tp[m, 2], tp[m, 3]) for m in members)))
+    if len(seen) >= 12:
+        break
+# how well do simple predictors explain a task's wave time?
+for name, v in (('n_ue*n_prb', tp[:, 1] * tp[:, 2]), ('pf_trips', tp[:, 3]), ('n_ue', tp[:, 1]), ('n_prb', tp[:, 2])):
+    print('corr(wave cycles, %s) = %.3f' % (name, np.corrcoef(cyc, v.astype(np.float64))[0, 1]))
