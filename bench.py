@@ -122,6 +122,9 @@ def main():
     ap.add_argument('--burn-in', type=int, default=1000)
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--graph', action='store_true',
+                    help='replay the timed loop from a captured hipGraph (rs_run_random); the kernel time for the '
+                         'roofline is then taken from a separate event-timed pass of 100 steps')
     ap.add_argument('--cpu-steps', type=int, default=3000)
     args = ap.parse_args()
 
@@ -185,15 +188,24 @@ def main():
     torch.cuda.synchronize()
     env.synchronize()
     t0 = time.perf_counter()
-    run(args.steps)
+    if args.graph:
+        env.set_kernel_timing(False)
+        env.run_random(ACTION_SEED + rank, step_idx, args.steps, graph=True)
+        step_idx += args.steps
+    else:
+        run(args.steps)
     env.synchronize()
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
 
+    c1 = env.counters()
+    if args.graph:
+        env.set_kernel_timing(True)
+        run(100)
+        env.synchronize()
     kern_ms, launches = env.kernel_time_ms()
     env.set_kernel_timing(False)
-    c1 = env.counters()
     out = env.fetch()  # also surfaces capacity-overflow errors
     assert np.isfinite(out['reward']).all()
 
@@ -240,6 +252,7 @@ def main():
                 'envs_per_gpu': n_envs, 'global_envs': world * n_envs, 'burn_in_steps': args.burn_in,
                 'fading': '3 synthetic traces x %d samples x 200 PRB, f64' % FADING_COLS,
                 'parallelism': 'replica-sharded x%d, no collective in step' % world,
+                'loop': 'hipGraph replay (rs_run_random)' if args.graph else 'one launch sequence per step from the host',
             },
             'roofline': {
                 'bound': 'hbm', 'kernel': 'embb_step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

@@ -125,6 +125,11 @@ int rs_fetch(rs_handle* h, int32_t* actions, float* obs, double* reward, int32_t
  * devices, rest 0). */
 int rs_get_info(rs_handle* h, double* info);
 
+/* n_steps x { rs_random_actions(seed, step_index0 + i); rs_step_resident(); } enqueued by one call.  With
+ * use_graph != 0 the loop body is captured once as a hipGraph (two consecutive steps) and replayed; the slot
+ * clock and the script index live in device memory, so results are identical with and without the graph. */
+int rs_run_random(rs_handle* h, uint64_t seed, uint64_t step_index0, int n_steps, int use_graph);
+
 /* Enable (capacity > 0) or disable per-slot allocation tracing.  When enabled every step
  * records [n_envs][n_embb][slots_per_step][max_ue] rs_alloc_rec entries. */
 int rs_set_alloc_trace(rs_handle* h, int enable);

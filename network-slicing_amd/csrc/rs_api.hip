@@ -52,7 +52,12 @@ struct rs_handle {
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;
-    int32_t clock = 0;     // slots since reset
+    int64_t* d_run = nullptr;    // device-side run state read by the step kernels: [0] slots since reset,
+                                 // [1] step index and [2] seed of the on-device action script (rs_run_random)
+    hipGraph_t graph = nullptr;  // two captured steps (one per parity of the order counters) of rs_run_random
+    hipGraphExec_t gexec = nullptr;
+    int graph_par = 0, graph_sig = -1;
+    int32_t clock = 0;     // slots since reset (host mirror of d_run[0])
     uint64_t steps = 0;
     bool is_reset = false;
     // kernel timing
@@ -61,6 +66,8 @@ struct rs_handle {
     size_t ev_used = 0;
     std::string err;
 };
+
+static void drop_graph(rs_handle* h);
 
 #define HIPCHK(h, call)                                                                              \
     do {                                                                                             \
@@ -124,7 +131,7 @@ static int mtc_step(rs_handle* h, rs::MtcState* m) {
     a.D = h->ddev;
     a.M = *m;
     a.actions = h->d_actions;
-    a.clock0 = h->clock;
+    a.run = h->d_run;
     a.obs = h->d_obs;
     a.labels = h->d_labels;
     a.violations = h->d_viol;
@@ -157,9 +164,14 @@ __global__ void reset_kernel(const RsDev* D, RsState S, const uint64_t* seeds_in
 }
 
 // reward of RanSlice.step (ran_slice.py:45-52)
-__global__ void finalize_kernel(const RsDev* D, const int32_t* actions, const int32_t* viol, double* reward) {
+__global__ void finalize_kernel(const RsDev* D, const int32_t* actions, const int32_t* viol, double* reward,
+                                int64_t* run) {
     int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= D->n_envs) return;
+    if (r == 0) {  // last kernel of the step: advance the device-side clock and the action-script index
+        run[0] += D->slots;
+        run[1] += 1;
+    }
     int S = D->n_slices;
     long tv = 0, ta = 0;
     for (int s = 0; s < S; ++s) {
@@ -176,8 +188,13 @@ __global__ void finalize_kernel(const RsDev* D, const int32_t* actions, const in
 
 // bench action script: one wave per replica, one categorical draw
 // per PRB over S slices + "unused"; identical to rso_random_actions.
+// With `run` the seed and the step index come from the device-side run state (graph-captured loops).
 __global__ __launch_bounds__(256) void random_actions_kernel(const RsDev* D, int32_t* actions, uint64_t seed,
-                                                           uint64_t step) {
+                                                           uint64_t step, const int64_t* run) {
+    if (run) {
+        step = (uint64_t)run[1];
+        seed = (uint64_t)run[2];
+    }
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= D->n_envs) return;
@@ -197,6 +214,11 @@ __global__ __launch_bounds__(256) void random_actions_kernel(const RsDev* D, int
         for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
         if (lane == 0) actions[r * S + s] = c;
     }
+}
+
+__global__ void set_run_kernel(int64_t* run, uint64_t seed, uint64_t step) {
+    run[1] = (int64_t)step;
+    run[2] = (int64_t)seed;
 }
 
 __global__ void counter_sum_kernel(const uint64_t* per_task, int n_tasks, uint64_t* out) {
@@ -367,6 +389,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     HIPCHK(h, hipMemset(h->d_ohist, 0, sizeof(int) * 2 * RS_ORDER_BINS));
     if (const char* e = getenv("RANSLICE_ORDER")) h->order_mode = atoi(e);
     DA(h->d_st, 1);
+    DA(h->d_run, 4);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
@@ -378,6 +401,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
 extern "C" void rs_destroy(rs_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    drop_graph(h);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fad) (void)hipFree(h->fad);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
@@ -446,6 +470,7 @@ extern "C" int rs_load_fading(rs_handle* h, int trace_id, const double* data, in
         return RS_EINVAL;
     }
     HIPCHK(h, hipSetDevice(h->device));
+    drop_graph(h);
     const int P = h->cfg.n_prbs > rows ? h->cfg.n_prbs : rows;
     if (h->hdev.P != 0 && h->hdev.P != P) {
         h->err = "rs_load_fading: all traces must have the same number of rows";
@@ -496,6 +521,7 @@ extern "C" int rs_reset(rs_handle* h, const uint64_t* seeds, float* obs) {
     if (h->cfg.n_mmtc > 0) mtc_reset(h, &h->mst);
     HIPCHK(h, hipMemsetAsync(h->d_counters, 0, sizeof(uint64_t) * 4 * (h->n_tasks ? h->n_tasks : 1), h->stream));
     HIPCHK(h, hipMemsetAsync(h->d_obs, 0, sizeof(float) * N * h->n_vars, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d_run, 0, sizeof(int64_t) * 4, h->stream));
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(h->stream));
     (void)hipFree(tmp);
@@ -522,7 +548,7 @@ static int launch_step(rs_handle* h) {
         a.fad = h->fad;
         a.fad_valid = h->fad_valid;
         a.actions = h->d_actions;
-        a.clock0 = h->clock;
+        a.run = h->d_run;
         a.obs = h->d_obs;
         a.labels = h->d_labels;
         a.violations = h->d_viol;
@@ -585,7 +611,7 @@ static int launch_step(rs_handle* h) {
     }
     if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
     hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,
-                       h->d_actions, h->d_viol, h->d_reward);
+                       h->d_actions, h->d_viol, h->d_reward, h->d_run);
     HIPCHK(h, hipGetLastError());
     h->clock += h->cfg.slots_per_step;
     h->steps += 1;
@@ -657,8 +683,78 @@ extern "C" int rs_random_actions(rs_handle* h, uint64_t seed, uint64_t step_inde
     }
     if (h->cfg.n_prbs > 512) return RS_EINVAL;
     hipLaunchKernelGGL(random_actions_kernel, dim3((h->cfg.n_envs + 3) / 4), dim3(256), 0, h->stream, h->ddev,
-                       h->d_actions, seed, step_index);
+                       h->d_actions, seed, step_index, (const int64_t*)nullptr);
     HIPCHK(h, hipGetLastError());
+    return RS_OK;
+}
+
+static void drop_graph(rs_handle* h) {
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->gexec = nullptr;
+    h->graph = nullptr;
+}
+
+// one step of the on-device action script: actions from (run[2], run[1]), then RanSlice.step
+static int enqueue_scripted_step(rs_handle* h) {
+    hipLaunchKernelGGL(random_actions_kernel, dim3((h->cfg.n_envs + 3) / 4), dim3(256), 0, h->stream, h->ddev,
+                       h->d_actions, (uint64_t)0, (uint64_t)0, (const int64_t*)h->d_run);
+    return launch_step(h);
+}
+
+// n_steps x (rs_random_actions(seed, step_index0 + i); rs_step_resident()) enqueued by one call.  With use_graph
+// the loop body is captured once into a hipGraph of two consecutive steps (the order counters alternate
+// between two buffers) and replayed; the slot clock and the action-script index live in device memory
+// (d_run) so that the captured kernels need no per-step arguments.  Results are identical either way.
+extern "C" int rs_run_random(rs_handle* h, uint64_t seed, uint64_t step_index0, int n_steps, int use_graph) {
+    if (!h || n_steps < 0) return RS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->n_slices > 8 || h->cfg.n_prbs > 512) {
+        h->err = "rs_run_random: at most 8 slices and 512 PRBs";
+        return RS_EINVAL;
+    }
+    if (!h->is_reset) {
+        h->err = "rs_run_random: call rs_reset first";
+        return RS_ESTATE;
+    }
+    if ((int64_t)h->clock + (int64_t)n_steps * h->cfg.slots_per_step > 2000000000) {
+        h->err = "rs_run_random: slot clock would overflow; reset the environment";
+        return RS_ESTATE;
+    }
+    hipLaunchKernelGGL(set_run_kernel, dim3(1), dim3(1), 0, h->stream, h->d_run, seed, step_index0);
+    int done = 0, rc;
+    if (use_graph && !h->timing && n_steps >= 2) {
+        if (h->gexec && h->graph_par != h->order_par) {  // realign with the parity the graph was captured at
+            if ((rc = enqueue_scripted_step(h)) != RS_OK) return rc;
+            done += 1;
+        }
+        if (!h->gexec) {
+            const int32_t clock0 = h->clock;
+            const uint64_t steps0 = h->steps;
+            h->graph_par = h->order_par;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            const int rc1 = enqueue_scripted_step(h);
+            const int rc2 = rc1 == RS_OK ? enqueue_scripted_step(h) : rc1;
+            const hipError_t ec = hipStreamEndCapture(h->stream, &h->graph);
+            h->clock = clock0;
+            h->steps = steps0;
+            h->order_par = h->graph_par;
+            if (rc2 != RS_OK || ec != hipSuccess) {
+                drop_graph(h);
+                if (rc2 == RS_OK) h->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ec);
+                return rc2 != RS_OK ? rc2 : RS_EHIP;
+            }
+            HIPCHK(h, hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+        }
+        while (n_steps - done >= 2) {
+            HIPCHK(h, hipGraphLaunch(h->gexec, h->stream));
+            h->clock += 2 * h->cfg.slots_per_step;
+            h->steps += 2;
+            done += 2;
+        }
+    }
+    for (; done < n_steps; ++done)
+        if ((rc = enqueue_scripted_step(h)) != RS_OK) return rc;
     return RS_OK;
 }
 
@@ -679,6 +775,7 @@ extern "C" int rs_set_alloc_trace(rs_handle* h, int enable) {
         HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(rs_alloc_rec) * (n ? n : 1)));
     }
     h->trace_on = enable != 0;
+    drop_graph(h);
     return RS_OK;
 }
 
@@ -708,6 +805,7 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
 extern "C" int rs_set_group_size(rs_handle* h, int lanes) {
     if (!h || (lanes != 8 && lanes != 16 && lanes != 32)) return RS_EINVAL;
     h->group = lanes;
+    drop_graph(h);
     return RS_OK;
 }
 

@@ -317,7 +317,7 @@ struct StepArgs {
     const double* fad;        // [trace][time][P]
     const uint8_t* fad_valid; // [trace][time]
     const int32_t* actions;   // [n_envs][n_slices]
-    int32_t clock0;           // slots elapsed since reset before this step
+    const int64_t* run;       // device-side run state: [0] slots elapsed since reset before this step (rs_api.hip)
     float* obs;               // [n_envs][n_vars]
     int32_t* labels;          // [n_envs][n_slices]
     int32_t* violations;      // [n_envs][n_slices]
@@ -368,6 +368,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     __shared__ double L_nom[256];            // nominal SINR
     const RsDev* __restrict__ D = A.D;
     const RsState& S = *A.S;
+    const int clock0 = (int)A.run[0];
     double* const mi = lds_mi[threadIdx.x / G];
     const int lane = (int)(threadIdx.x & 63u);
     const int gl = lane & (G - 1);       // UE index owned by this lane
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
         for (int k = 0; k < RS_BURSTS; ++k) {
             const int e = active ? S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] : 0;
             L_burst[k][tid] = e;
-            if (e > A.clock0) {
+            if (e > clock0) {
                 n_act += 1;
                 evt_at = e < evt_at ? e : evt_at;
             }
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     const int slots = D->slots;
     SEC_DECL
     for (int t = 0; t < slots; ++t) {
-        const int now = A.clock0 + t + 1;
+        const int now = clock0 + t + 1;
         const int slot_counter = t + 1;
 
         // ================= SliceRANeMBB.slot: arrivals (slice_ran.py:205-249)

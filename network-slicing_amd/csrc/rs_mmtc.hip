@@ -73,7 +73,7 @@ struct MtcArgs {
     const RsDev* D;
     MtcState M;
     const int32_t* actions;
-    int32_t clock0;
+    const int64_t* run;  // device-side run state: [0] = slots elapsed since reset
     float* obs;
     int32_t* labels;
     int32_t* violations;
@@ -115,8 +115,9 @@ __global__ __launch_bounds__(256) void mtc_step_kernel(MtcArgs A) {
     int err = 0;
 
     const int slots = D->slots;
+    const int clock0 = (int)A.run[0];
     for (int t = 0; t < slots; ++t) {
-        const int now = A.clock0 + t + 1;  // SliceL1mMTC.time (slice_l1.py:88)
+        const int now = clock0 + t + 1;  // SliceL1mMTC.time (slice_l1.py:88)
         // ---- arrivals in device-index order (slice_ran.py:106-121, slice_l1.py:76-82)
         if (__builtin_amdgcn_ballot_w64(min_next == now) != 0ull) {
 #pragma unroll

@@ -18,7 +18,7 @@ KB_EXPORTS = (
 
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
-    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_kernel_time_ms',
+    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
     'rs_set_kernel_timing', 'rs_synchronize', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
 ) + KB_EXPORTS
 
@@ -49,6 +49,7 @@ def load():
     L.rs_step.argtypes = [vp, ip, fp, dp, ip, ip]
     L.rs_step_resident.argtypes = [vp]
     L.rs_random_actions.argtypes = [vp, C.c_uint64, C.c_uint64]
+    L.rs_run_random.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int, C.c_int]
     L.rs_fetch.argtypes = [vp, ip, fp, dp, ip, ip]
     L.rs_get_info.argtypes = [vp, dp]
     L.rs_set_alloc_trace.argtypes = [vp, C.c_int]

@@ -92,6 +92,11 @@ class VecRanSlice:
     def step_resident(self):
         self._check(self.L.rs_step_resident(self.h))
 
+    def run_random(self, seed, step_index0, n_steps, graph=False):
+        """n_steps x (random_actions(seed, step_index0 + i); step_resident()) enqueued by one call; with
+        graph=True the loop body is replayed from a captured hipGraph (same results)."""
+        self._check(self.L.rs_run_random(self.h, int(seed), int(step_index0), int(n_steps), 1 if graph else 0))
+
     def fetch(self):
         actions = np.zeros((self.n_envs, self.n_slices), dtype=np.int32)
         self._check(self.L.rs_fetch(self.h, actions.ctypes.data_as(_ip), self._obs.ctypes.data_as(_fp),

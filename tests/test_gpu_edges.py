@@ -144,3 +144,42 @@ def test_call_order_errors(golden_dir):
     assert L.rs_create(C.byref(cfg), 99, C.byref(h2)) == _lib.RS_EHIP  # no such device
     L.rs_destroy(h2)
     env.close()
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_graph_captured_loop_equals_step_by_step(golden_dir, scenario):
+    """rs_run_random: the hipGraph replay (device-side slot clock and script index), the plain one-call loop and
+    the call-per-step loop leave identical observations, labels, rewards and info behind; odd step counts,
+    re-entry at the other counter parity and a reset in between included."""
+    from ranslice.vec_env import VecRanSlice
+    fading = _fading(golden_dir)
+    N = 96
+
+    def make():
+        e = VecRanSlice(n_envs=N, cfg=_churn(make_config(scenario, n_envs=N)), fading=fading, seed=5)
+        e.reset()
+        return e
+
+    ref, loop, graph = make(), make(), make()
+    plan = [(0, 7), (7, 2), (9, 1), (10, 12)]
+    for step0, n in plan:
+        for i in range(n):
+            ref.random_actions(77, step0 + i)
+            ref.step_resident()
+        loop.run_random(77, step0, n, graph=False)
+        graph.run_random(77, step0, n, graph=True)
+        a, b, c = ref.fetch(), loop.fetch(), graph.fetch()
+        for k in ('actions', 'obs', 'reward', 'labels', 'violations'):
+            assert np.array_equal(a[k], b[k]), (k, step0)
+            assert np.array_equal(a[k], c[k]), (k, step0)
+        assert np.array_equal(ref.l1_info(), graph.l1_info())
+    # reset keeps the captured graph valid (the clock restarts on the device)
+    ref.reset()
+    graph.reset()
+    for i in range(6):
+        ref.random_actions(3, i)
+        ref.step_resident()
+    graph.run_random(3, 0, 6, graph=True)
+    a, c = ref.fetch(), graph.fetch()
+    for k in ('actions', 'obs', 'reward', 'labels', 'violations'):
+        assert np.array_equal(a[k], c[k]), k

@@ -11,7 +11,7 @@ from ranslice.config import make_config  # noqa: E402
 from ranslice.fading import synth_fading  # noqa: E402
 from ranslice.vec_env import VecRanSlice  # noqa: E402
 
-N = 4096
+N = int(os.environ.get('PROFILE_ENVS', '4096'))
 KBRL = '--kbrl' in sys.argv  # drive the env with one KBRL agent per replica instead of random actions
 env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
 env.reset()
