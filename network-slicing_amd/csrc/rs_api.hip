@@ -345,6 +345,26 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
             return RS_EINVAL;
         }
     }
+    {
+        // The PF metric update divides pf_b * bits by the slot length once per granted RB pair, inside a chain
+        // of dependent operations.  With the correctly rounded reciprocal, q = x * rc; r = fma(-q, d, x);
+        // q' = fma(r, rc, q) is the correctly rounded quotient for almost every x; `bits` is an integer no
+        // larger than n_prbs * max rate, so instead of arguing about the exceptions every reachable value is
+        // compared with the true divide here, and the kernel uses the short form only if all of them agree.
+        int max_rate = 0;
+        for (int i = 0; i < d.lut_n; ++i) max_rate = d.lut_rate[i] > max_rate ? d.lut_rate[i] : max_rate;
+        const double dl = cfg->slot_length, rc = 1.0 / dl;
+        bool same = std::isfinite(rc) && dl > 0.0;
+        const long long top = (long long)cfg->n_prbs * max_rate;
+        for (long long b = 0; same && b <= top; ++b) {
+            const double x = d.pf_b * (double)b;
+            const double q = x * rc;
+            const double r = std::fma(-q, dl, x);
+            same = std::fma(r, rc, q) == x / dl;
+        }
+        d.slot_rc = rc;
+        d.pf_div_fast = (same && !getenv("RANSLICE_EXACT_DIV")) ? 1 : 0;  // the variable forces the divide (tests)
+    }
     for (int m = 0; m < cfg->n_mcs; ++m) {
         d.mcs_ref[m] = cfg->mcs_snr[m];
         d.mcs_x0[m] = cfg->mi_x0[cfg->mcs_mod[m]];

@@ -33,6 +33,9 @@ struct RsDev {
     double prop_A, prop_B;
     double mcsA, mcsB;      // MCSCodeset.compute_factors (channel_models.py:272-279)
     double pf_a, pf_b;      // 1 - 1/window, 1/window (schedulers.py:16-17, slice_ran.py:30-31)
+    double slot_rc;         // RN(1 / slot_length)
+    int32_t pf_div_fast;    // 1: (pf_b * bits) / slot_length may be formed as q = x * slot_rc refined by two fmas;
+                            // rs_create checked every integer `bits` a slot can reach against the IEEE divide
     int32_t gran;           // PF granularity
     int32_t lut_lo, lut_n;  // e_snr -> (mcs, rate) lookup, clamped outside [lut_lo, lut_lo+lut_n)
     int32_t lut_mcs[RS_LUT_MAX], lut_rate[RS_LUT_MAX];

@@ -107,16 +107,28 @@ __device__ __forceinline__ bool wave_any(bool c) { return __builtin_amdgcn_ballo
 #define DPP_MIRROR 0x140
 #define DPP_BCAST15 0x142
 
+// The permutations used through dpp_i / dpp_d read only lanes of the caller's own subgroup, which share its
+// EXEC state, so every destination lane has a valid source and no `old` operand has to be materialised
+// (row_shl:1 in the pairwise remainder may pull an undefined value into a subgroup's last lane; it never
+// reaches lane 0 within the LPU - 1 shifts that are consumed).
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false);
+    return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, false);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     uint64_t u = rs_d2u(v);
-    int lo = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
+    int lo = __builtin_amdgcn_mov_dpp((int)(uint32_t)u, CTRL, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_mov_dpp((int)(uint32_t)(u >> 32), CTRL, 0xF, 0xF, false);
     return rs_u2d(((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo);
+}
+// maximum of two finite doubles: one v_max_f64 (the generic fmax also quiets its operands first).  The result
+// usually feeds a DPP move next, and the compiler cannot see a VALU write inside the asm, so the two wait
+// states that hazard needs are spelled out here.
+__device__ __forceinline__ double max_finite(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2\n\ts_nop 1" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // ballot restricted to this lane's G-lane group (bit u = lane u of the group)
@@ -158,18 +170,18 @@ __device__ __forceinline__ double group_sum(double v) {
 template <int G>
 __device__ __forceinline__ double group_max(double v) {
     double o;
-    // operands are finite (metrics >= 0 or the -1 / -2 sentinels): fmax == the plain maximum, one v_max_f64
-    o = dpp_d<DPP_XOR1>(v); v = __builtin_fmax(o, v);
-    o = dpp_d<DPP_XOR2>(v); v = __builtin_fmax(o, v);
-    o = dpp_d<DPP_HMIRROR>(v); v = __builtin_fmax(o, v);
-    if (G >= 16) { o = dpp_d<DPP_MIRROR>(v); v = __builtin_fmax(o, v); }
+    // operands are finite (metrics >= 0 or the -1 / -2 sentinels)
+    o = dpp_d<DPP_XOR1>(v); v = max_finite(o, v);
+    o = dpp_d<DPP_XOR2>(v); v = max_finite(o, v);
+    o = dpp_d<DPP_HMIRROR>(v); v = max_finite(o, v);
+    if (G >= 16) { o = dpp_d<DPP_MIRROR>(v); v = max_finite(o, v); }
     if (G == 32) {
         uint64_t u = rs_d2u(v);
         auto lo = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
         auto hi = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
         double a = rs_u2d(((uint64_t)hi[0] << 32) | lo[0]);
         double b = rs_u2d(((uint64_t)hi[1] << 32) | lo[1]);
-        v = __builtin_fmax(a, b);
+        v = max_finite(a, b);
     }
     return v;
 }
@@ -347,8 +359,10 @@ struct MiHbm {
     __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 };
 
+// 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
+// instances are test tooling: they keep the register budget of 3 waves per SIMD, which needs no spills.
 template <int G, bool TRACE>
-__global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_kernel(StepArgs A) {
     constexpr int LPU = RS_LPU;                      // lanes that share one UE's pairwise sums
     constexpr int LOG_LPU = LPU == 8 ? 3 : (LPU == 4 ? 2 : 1);
     constexpr int NSUB = G / LPU;                    // subgroups (UEs per pass) in a group
@@ -390,6 +404,8 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
     const int P = D->P;
     const double slot_len = D->slot_length;
     const double pf_a = D->pf_a, pf_b = D->pf_b;
+    const double slot_rc = D->slot_rc;
+    const bool pf_div_fast = D->pf_div_fast != 0;
     const int gran = D->gran;
 
     // set_prbs (node_b.py:71-74): contiguous ranges in slice order
@@ -501,6 +517,17 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
         L_acc_bits[tid] = 0;
         L_acc_prbs[tid] = 0;
     };
+
+    // pf_b * bits / slot_length of the throughput averages (schedulers.py:54, slice_ran.py:55)
+    auto pf_share = [&](int b) -> double {
+        const double xb = pf_b * (double)b;
+        if (pf_div_fast) {  // == xb / slot_len for every `bits` a slot can reach (checked by rs_create)
+            const double q0 = xb * slot_rc;
+            return __builtin_fma(__builtin_fma(-q0, slot_len, xb), slot_rc, q0);
+        }
+        return xb / slot_len;
+    };
+    const unsigned pf_pairs = (unsigned)((double)(n_prb + gran - 1) / (double)gran);  // RB pairs per scheduled slot
 
     const int slots = D->slots;
     SEC_DECL
@@ -749,6 +776,12 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
             int rbs = 0, bits = 0;
             double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
+            // leader (first maximum) and runner-up of the group's metrics.  After a contested run only the
+            // leader's metric has changed and it ended below the runner-up, so the runner-up is the next leader
+            // and only the new runner-up needs a reduction; `need_full` (group-uniform) asks for both.
+            bool need_full = true;
+            double mx = 0.0;
+            int idx = 0;
             SEC_MARK(8)
             for (;;) {
                 const bool more = sched && r < n_prb;
@@ -757,10 +790,14 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
 #ifdef RS_SECTION_PROFILE
                 sec_acc[15] += 1;  // PF loop trips (not cycles)
 #endif
-                // leader = np.argmax (first maximum) and the best of the rest
-                const double mx = group_max<G>(m);
-                const unsigned eq = group_ballot<G>(m == mx, gbase);
-                const int idx = __ffs((int)eq) - 1;
+                if (wave_any(more && need_full)) {
+                    const double fm = group_max<G>(m);
+                    const unsigned eq = group_ballot<G>(m == fm, gbase);
+                    if (need_full) {
+                        mx = fm;
+                        idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                    }
+                }
                 const double m_rest = gl == idx ? -2.0 : m;
                 const double m2 = group_max<G>(m_rest);
                 const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
@@ -802,19 +839,30 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                                 bits += tx;
                                 rr += gran;
                                 if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
-                                    thl = pf_a * thl + pf_b * (double)bits / slot_len;
+                                    thl = pf_a * thl + pf_share(bits);
                                     m = rate_d / thl;
+                                    keep = m > m2 || (m == m2 && gl < idx2);
                                 } else {
                                     m = 0.0;
+                                    keep = false;  // m2 > 0 here
                                 }
-                                keep = m > m2 || (m == m2 && gl < idx2);
                             } while (keep && rr < n_prb);
                             take = rr - r;
                         }
                     }
                 }
                 const int tk = bperm(take, gbase + idx);
-                if (more) r = mx == 0.0 ? n_prb : r + tk;
+                if (more) {
+                    r = mx == 0.0 ? n_prb : r + tk;
+                    if (mx != 0.0 && m2 > 0.0) {
+                        // the run ended below the runner-up (or the RBs ran out): next leader is known
+                        need_full = false;
+                        mx = m2;
+                        idx = idx2;
+                    } else {
+                        need_full = true;
+                    }
+                }
             }
             SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
@@ -895,11 +943,11 @@ __global__ __launch_bounds__(256, G == 16 ? 5 : 3) void embb_step_kernel(StepArg
                 if (!received) bits = 0;
                 double nq = queue - (double)bits;
                 queue = nq > 0.0 ? nq : 0.0;
-                th = pf_a * th + pf_b * (double)bits / slot_len;
+                th = pf_a * th + pf_share(bits);
                 ue_bits = bits;
                 ue_prbs = rbs;
             }
-            if (sched) cnt_pf += (unsigned)((double)(n_prb + gran - 1) / (double)gran);
+            if (sched) cnt_pf += pf_pairs;
         }
 
         SEC_MARK(5)

@@ -104,6 +104,22 @@ def test_scenario0_churn(golden_dir, group):
     _compare(0, n_envs=40, steps=30, fading=_small_fading(golden_dir), churn=True, seed0=1000, group=group)
 
 
+@pytest.mark.parametrize('scenario,n_envs,steps', [(0, 160, 30), (2, 96, 20), (3, 96, 20)])
+def test_production_instance_soak(golden_dir, scenario, n_envs, steps):
+    """The instance that serves step() in production (no allocation trace; 5 waves per SIMD, the only one that
+    spills registers) against the oracle on every replica: observations, rewards, labels, violations and the
+    ten info sums bit for bit, through arrivals, departures, bursts and empty slices."""
+    _compare(scenario, n_envs=n_envs, steps=steps, fading=_small_fading(golden_dir), churn=True, seed0=500,
+             check_trace=False)
+
+
+def test_exact_divide_fallback(golden_dir, monkeypatch):
+    """rs_create replaces (pf_b * bits) / slot_length by a reciprocal + two fmas after checking every reachable
+    `bits`; RANSLICE_EXACT_DIV forces the IEEE divide instead.  Both must match the oracle."""
+    monkeypatch.setenv('RANSLICE_EXACT_DIV', '1')
+    _compare(0, n_envs=48, steps=12, fading=_small_fading(golden_dir), churn=True, seed0=77, check_trace=False)
+
+
 def test_crowded_slices_replay(golden_dir):
     """heavy arrival rate: most slices hold more than 8 UEs, so the replay path carries the batch"""
     from ranslice.vec_env import VecRanSlice

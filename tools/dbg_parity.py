@@ -1,0 +1,47 @@
+import os, sys, numpy as np
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/network-slicing_amd')
+from oracle import pyoracle as po
+from ranslice.config import make_config
+from ranslice.vec_env import VecRanSlice
+g = np.load('/root/repo/tests/golden/fading_small.npz'); fading = [g['t0'], g['t1'], g['t2']]
+N = 8
+def mk(n):
+    c = make_config(0, n_envs=n)
+    if os.environ.get('DBG_CHURN') == '1':
+        c.cbr_lambda, c.cbr_t_mean = 2.0 / 1.2, 0.6
+        c.vbr_lambda, c.vbr_t_mean = 5.0 / 1.2, 0.6
+        c.vbr_b_size, c.vbr_b_rate = 40, 12
+    return c
+env = VecRanSlice(n_envs=N, cfg=mk(N), fading=fading, seed=7)
+TR = os.environ.get("DBG_TRACE") == "1"
+if TR: env.set_alloc_trace(True)
+env.reset()
+ors = []
+for r in range(N):
+    o = po.OracleEnv(mk(1), fading); o.set_seed(7 + r); o.reset(); ors.append(o)
+rng = np.random.default_rng(1)
+for i in range(12):
+    acts = rng.multinomial(200, [1/6]*6, size=N)[:, :5].astype(np.int32)
+    obs, rew, done, info = env.step(acts)
+    tr = env.alloc_trace() if TR else None
+    for r in range(N):
+        out = ors[r].step(acts[r], trace=TR)
+        if obs[r].tobytes() != out['obs'].tobytes():
+            d = np.nonzero(obs[r] != out['obs'])[0]
+            print('step', i, 'rep', r, 'obs idx', d, obs[r][d], out['obs'][d])
+            if not TR: sys.exit(0)
+            t = tr[r]; ot = out["trace"]
+            for s in range(5):
+                for slot in range(50):
+                    a, b = t[s, slot], ot[s, slot][:32] if ot.shape[2] >= 32 else ot[s, slot]
+                    n = min(len(a), len(b))
+                    if a[:n].tobytes() != b[:n].tobytes():
+                        print(' first trace diff slice', s, 'slot', slot)
+                        for sl2 in range(max(0, slot - 14), slot + 1):
+                            print('  slot', sl2, 'hip', [(int(x['serial']), int(x['prbs']), int(x['bits']), float(x['queue'])) for x in t[s, sl2][:4]])
+                            print('  slot', sl2, 'ora', [(int(x['serial']), int(x['prbs']), int(x['bits']), float(x['queue'])) for x in ot[s, sl2][:4]])
+                        break
+                else: continue
+                break
+            sys.exit(0)
+print('all equal')
