@@ -67,6 +67,7 @@ namespace rs {
             if (i_ != 14) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);                      \
         atomicMax((unsigned long long*)&(buf)[14], tot_); /* slowest wave of any launch so far */       \
     }                                                                                                   \
+    if ((threadIdx.x & 63u) != 0u && sec_acc[13]) atomicAdd((unsigned long long*)&(buf)[13], sec_acc[13]); \
     if (gl == 0 && valid) { /* per task: cycles of its wave, UEs and RBs at the start, contested PF trips */ \
         unsigned long long tot_ = 0;                                                                    \
         for (int i_ = 0; i_ < 13; ++i_) tot_ += sec_acc[i_];                                            \
@@ -803,6 +804,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
                 const int idx2 = __ffs((int)eq2) - 1;
                 int take = 0;
+                SEC_MARK(11)
                 if (more) {
                     if (mx == 0.0) {
                         // every queue is empty: argmax of an all-zero metric is UE 0 for all the
@@ -832,6 +834,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                             int rr = r;
                             bool keep;
                             do {
+#ifdef RS_SECTION_PROFILE
+                                sec_acc[13] += 1;  // leader-run iterations (all lanes are summed)
+#endif
                                 const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
                                 rbs += prbs;
                                 const int tx = prbs * rate < q ? prbs * rate : q;
@@ -851,6 +856,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                         }
                     }
                 }
+                SEC_MARK(12)
                 const int tk = bperm(take, gbase + idx);
                 if (more) {
                     r = mx == 0.0 ? n_prb : r + tk;

@@ -46,17 +46,20 @@ env.synchronize()
 env.L.rs_get_section_profile(env.h, a)
 d = [a[i] - base[i] for i in range(16)]
 # section i accumulates the time from the previous mark to mark i
-names = {0: 'arrivals + timer events', 1: 'traffic_step', 7: 'fading walker', 2: 'e_snr rounds (loads, pairwise sum)',
-         8: 'PF set-up (MCS lookup, first metric)', 3: 'PF loop', 9: 'RB scan + R1 (MI of every RB)',
+names = {11: 'PF trip: leader / runner-up reductions', 12: 'PF trip: leader run or closed form', 0: 'arrivals + timer events', 1: 'traffic_step', 7: 'fading walker', 2: 'e_snr rounds (loads, pairwise sum)',
+         8: 'PF set-up (MCS lookup, first metric)', 3: 'PF trip: take broadcast + loop control', 9: 'RB scan + R1 (MI of every RB)',
          10: 'R2 (pairwise sums from LDS)', 4: 'R3 (inv_sigmoid + rx prob)', 5: 'reception draw + tx_step',
          6: 'update_info'}
 trips = d[15]
+runs = d[13]
+d[13] = 0
 d[15] = 0
+print('leader-run iterations per task per slot: %.2f' % (runs / K / (N * 5) / 50))
 slowest = a[14]
 d[14] = 0
 tot = sum(d) or 1
 waves = N * 5 / 4  # 16 lanes per task
-for i in (0, 1, 7, 2, 8, 3, 9, 10, 4, 5, 6):
+for i in (0, 1, 7, 2, 8, 11, 12, 3, 9, 10, 4, 5, 6):
     print('%-38s %6.2f%%   %9.0f cycles/wave/slot' % (names[i], 100.0 * d[i] / tot, d[i] / K / waves / 50))
 print('slowest wave of any launch: %.0f cycles/slot (mean wave: %.0f)' % (slowest / 50, tot / K / waves / 50))
 print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (tot / K / waves / 50, trips / K / waves / 50))
