@@ -7,9 +7,11 @@ from ranslice.config import make_config
 from ranslice.fading import synth_fading
 from ranslice.vec_env import VecRanSlice
 fading = [synth_fading(t, 10000) for t in range(3)]
+SC = int(os.environ.get('SWEEP_SCENARIO', '0'))
+GROUPS = [int(g) for g in os.environ.get('SWEEP_GROUPS', '8,16,32').split(',')]
 for N in [int(x) for x in (sys.argv[1:] or ['4096', '16384'])]:
-    for g in (8, 16, 32):
-        env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=fading)
+    for g in GROUPS:
+        env = VecRanSlice(n_envs=N, cfg=make_config(SC, n_envs=N), fading=fading)
         env.set_group_size(g)
         env.reset()
         for i in range(400):
@@ -23,5 +25,6 @@ for N in [int(x) for x in (sys.argv[1:] or ['4096', '16384'])]:
         env.synchronize()
         dt = time.perf_counter() - t0
         ms, n = env.kernel_time_ms()
+        print('scenario %d ' % SC, end='')
         print('N=%6d group=%2d : %.3f ms/step (embb kernels %.3f ms)  %.2f M env-steps/s' % (N, g, 1e3 * dt / K, ms, N * K / dt / 1e6), flush=True)
         env.close()
