@@ -47,6 +47,11 @@ __device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
 namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
+#ifndef RS_PRIO_A
+#define RS_PRIO_A 10u
+#define RS_PRIO_B 4u
+#define RS_PRIO_C 2u
+#endif
 #ifndef RS_LPU
 #define RS_LPU 4
 #endif
@@ -483,16 +488,24 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
         // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
         // get issue priority over their lighter neighbours on the SIMD for the whole step.
-        int cost = valid ? S.t_cost[task] : 0;
+        if (A.order) {
+            // launch order = cost rank (rs_order.hip): the heaviest tenth of the waves, the next fifth, ...
+            const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
+            if (w * RS_PRIO_A < nw) __builtin_amdgcn_s_setprio(3);
+            else if (w * RS_PRIO_B < nw) __builtin_amdgcn_s_setprio(2);
+            else if (w * RS_PRIO_C < nw) __builtin_amdgcn_s_setprio(1);
+        } else {
+            int cost = valid ? S.t_cost[task] : 0;
 #pragma unroll
-        for (int d_ = G; d_ < 64; d_ <<= 1) {
-            const int o = bperm(cost, lane ^ d_);
-            cost = o > cost ? o : cost;
+            for (int d_ = G; d_ < 64; d_ <<= 1) {
+                const int o = bperm(cost, lane ^ d_);
+                cost = o > cost ? o : cost;
+            }
+            const int c0_ = __builtin_amdgcn_readfirstlane(cost);
+            if (c0_ > 1200) __builtin_amdgcn_s_setprio(3);
+            else if (c0_ > 600) __builtin_amdgcn_s_setprio(2);
+            else if (c0_ > 300) __builtin_amdgcn_s_setprio(1);
         }
-        const int c0_ = __builtin_amdgcn_readfirstlane(cost);
-        if (c0_ > 1200) __builtin_amdgcn_s_setprio(3);
-        else if (c0_ > 600) __builtin_amdgcn_s_setprio(2);
-        else if (c0_ > 300) __builtin_amdgcn_s_setprio(1);
     }
 
     auto flush = [&]() {
