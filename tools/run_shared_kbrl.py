@@ -26,7 +26,9 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--budget', type=int, default=64)
     ap.add_argument('--rounds', type=int, default=4)
-    ap.add_argument('--capacity', type=int, default=1024)
+    ap.add_argument('--capacity', type=int, default=256,
+                    help='landmarks per shared dictionary; a full dictionary projects instead of growing, and one '
+                         'projection reads capacity^2 doubles of Kinv from a single workgroup')
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
     import torch

@@ -9,7 +9,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 cfg = make_config(2, n_envs=N)
 env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, 10000) for t in range(3)])
 dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
-agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=1024)
+CAP = int(os.environ.get('SHARED_CAP', '1024'))
+agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=int(os.environ.get('SHARED_BUDGET', '64')), max_rounds=int(os.environ.get('SHARED_ROUNDS', '4')), capacity=CAP)
 rng = np.random.default_rng(1000)
 ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)), rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
 sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)), rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
