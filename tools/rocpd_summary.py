@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 rocpd SQLite database (kernel trace, optionally PMC counters) as text.
-usage: python tools/rocpd_summary.py <results.db> [> profiles/<name>.txt]"""
+usage: python tools/rocpd_summary.py <results.db> [--last N] [> profiles/<name>.txt]
+--last N also prints the mean duration of the last N launches of the dominant kernel (= a bench run's timed
+region, which is what bench.py's HIP-event kernel time covers)."""
 import sqlite3
 import sys
 
 
-def main(path):
+def main(path, last=0):
     c = sqlite3.connect(path)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
@@ -15,6 +17,10 @@ def main(path):
     print('%-60s %8s %14s %12s %12s %12s %7s' % ('kernel', 'calls', 'total_ns', 'avg_ns', 'min_ns', 'max_ns', 'pct'))
     for n, k, t, a, mn, mx in rows:
         print('%-60s %8d %14d %12.0f %12d %12d %6.2f%%' % (n[:60], k, t, a, mn, mx, 100.0 * t / tot))
+    if last and rows:
+        top = rows[0][0]
+        d = [r[0] for r in c.execute("select end - start from kernels where name = ? order by start desc limit ?", (top, last))]
+        print('\n# last %d launches of %s: mean %.0f ns (min %d, max %d)' % (len(d), top[:60], sum(d) / max(1, len(d)), min(d), max(d)))
     extra = [x for x in ('vgpr_count', 'accum_vgpr_count', 'sgpr_count', 'lds_size', 'scratch_size', 'workgroup_size', 'grid_size') if x in cols]
     if extra:
         print('\n# per-kernel resources (%s)' % ', '.join(extra))
@@ -34,4 +40,4 @@ def main(path):
 
 
 if __name__ == '__main__':
-    main(sys.argv[1])
+    main(sys.argv[1], int(sys.argv[sys.argv.index('--last') + 1]) if '--last' in sys.argv else 0)
