@@ -61,10 +61,8 @@ RS_HD double rs_pow2i(int k) { return rs_u2d((uint64_t)(k + 1023) << 52); }
 
 /* exp(x): Cody-Waite reduction x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor in Horner
  * form (truncation 4e-18), scaled by 2^k in two exact steps. */
-RS_HD double rs_exp(double x) {
-    if (x != x) return x;
-    if (x > 709.782712893384) return rs_inf();
-    if (x < -745.2) return 0.0;
+/* the arithmetic of rs_exp for finite x in [-745.2, 709.78]: no branches, so independent calls interleave */
+RS_HD double rs_exp_core(double x) {
     double kd = RS_RINT(x * RS_INV_LN2);
     double r = RS_FMA(-kd, RS_LN2_HI, x);
     r = RS_FMA(-kd, RS_LN2_LO, r);
@@ -86,6 +84,19 @@ RS_HD double rs_exp(double x) {
     int k1 = k >> 1;
     int k2 = k - k1;
     return (p * rs_pow2i(k1)) * rs_pow2i(k2);
+}
+
+RS_HD double rs_exp(double x) {
+    if (x != x) return x;
+    if (x > 709.782712893384) return rs_inf();
+    if (x < -745.2) return 0.0;
+    return rs_exp_core(x);
+}
+
+/* rs_exp for x <= 0 (not NaN) without control flow: identical values */
+RS_HD double rs_exp_nonpos(double x) {
+    const double v = rs_exp_core(x < -745.2 ? -745.2 : x);
+    return x < -745.2 ? 0.0 : v;
 }
 
 /* log(x): x = 2^e m, m in [sqrt(1/2), sqrt(2)); log m = 2 atanh(s), s = (m-1)/(m+1),

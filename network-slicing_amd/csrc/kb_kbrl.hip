@@ -188,7 +188,7 @@ __device__ void score_range(const KbDev& D, int m, int c_lo, int c_hi, Lds& sm) 
             for (int r = 0; r < 4; ++r) {
                 const int jj = jt * 16 + kq + 4 * r;
                 double dist = acc[r] > 0.0 ? acc[r] : 0.0;
-                part += rs_exp(-D.gamma * dist) * sm.co[jj];
+                part += rs_exp_nonpos(-D.gamma * dist) * sm.co[jj];  // dist >= 0: branch-free, the 4 chains interleave
             }
         }
         part += __shfl_xor(part, 16);
