@@ -152,7 +152,8 @@ int rs_set_group_size(rs_handle* h, int lanes);
 /* Developer aid: cycle sums per code section of the eMBB step kernel (zeros in normal builds). */
 int rs_get_section_profile(rs_handle* h, uint64_t out[16]);
 /* Developer aid (profile builds): per eMBB task [n_envs * n_embb][4] = cycles of the task's wave in the last step,
- * UEs and RBs at its start, contested PF loop trips. */
+ * UEs and RBs at its start, contested PF loop trips; then 16 more values: the section cycle sums of the slowest
+ * wave seen so far (out must hold 4 * n_tasks + 16 values). */
 int rs_get_task_profile(rs_handle* h, uint64_t* out);
 
 int rs_synchronize(rs_handle* h);

@@ -401,7 +401,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_info, N * h->n_slices * 10);
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
-    DA(h->d_sections, 16 + 4 * (T ? T : 1));
+    DA(h->d_sections, 16 + 4 * (T ? T : 1) + 16);
     DA(h->d_redo, T ? T : 1);
     DA(h->d_order, T ? T : 1);
     DA(h->d_oslot, T ? T : 1);
@@ -842,8 +842,9 @@ extern "C" int rs_get_section_profile(rs_handle* h, uint64_t out[16]) {
 extern "C" int rs_get_task_profile(rs_handle* h, uint64_t* out) {
     if (!h || !out) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(out, h->d_sections + 16, sizeof(uint64_t) * 4 * (size_t)h->n_tasks, hipMemcpyDeviceToHost,
-                             h->stream));
+    // [n_tasks][4] per-task records followed by the 16 section sums of the slowest wave seen so far
+    HIPCHK(h, hipMemcpyAsync(out, h->d_sections + 16, sizeof(uint64_t) * (4 * (size_t)h->n_tasks + 16),
+                             hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
 }

@@ -70,7 +70,9 @@ namespace rs {
         for (int i_ = 0; i_ < 13; ++i_) tot_ += sec_acc[i_];                                            \
         for (int i_ = 0; i_ < 16; ++i_)                                                                 \
             if (i_ != 14) atomicAdd((unsigned long long*)&(buf)[i_], sec_acc[i_]);                      \
-        atomicMax((unsigned long long*)&(buf)[14], tot_); /* slowest wave of any launch so far */       \
+        /* slowest wave of any launch so far; its own section split goes to a second bank (racy, profiling only) */ \
+        if (tot_ > atomicMax((unsigned long long*)&(buf)[14], tot_))                                    \
+            for (int i_ = 0; i_ < 16; ++i_) (buf)[16 + 4 * (size_t)n_tasks + i_] = sec_acc[i_];        \
     }                                                                                                   \
     if ((threadIdx.x & 63u) != 0u && sec_acc[13]) atomicAdd((unsigned long long*)&(buf)[13], sec_acc[13]); \
     if (gl == 0 && valid) { /* per task: cycles of its wave, UEs and RBs at the start, contested PF trips */ \

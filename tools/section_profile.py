@@ -66,8 +66,13 @@ print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (to
 
 # per-task view of the last step: which tasks sit in the slowest waves?
 import numpy as np
-tp = np.zeros((N * 5, 4), dtype=np.uint64)
-env.L.rs_get_task_profile(env.h, tp.ctypes.data_as(C.POINTER(C.c_uint64)))
+raw = np.zeros(N * 5 * 4 + 16, dtype=np.uint64)
+env.L.rs_get_task_profile(env.h, raw.ctypes.data_as(C.POINTER(C.c_uint64)))
+tp = raw[:N * 5 * 4].reshape(N * 5, 4)
+sw = raw[N * 5 * 4:].astype(np.float64)
+print('section split of the slowest wave of the run (cycles/slot):')
+for i in (0, 1, 7, 2, 8, 11, 12, 3, 9, 10, 4, 5, 6):
+    print('   %-38s %9.0f  %5.1f%%' % (names[i], sw[i] / 50, 100.0 * sw[i] / max(1.0, sw[:13].sum())))
 cyc = tp[:, 0].astype(np.float64) / 50
 print('last step: wave cycles/slot percentiles 50/90/99/99.9/max: %s' % np.percentile(cyc, [50, 90, 99, 99.9, 100]).round(0))
 idx = np.argsort(-cyc)
