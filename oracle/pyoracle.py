@@ -53,6 +53,7 @@ def lib():
         L.rso_error.argtypes = [C.c_void_p]
         L.rso_get_counters.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
         L.rso_max_ue.argtypes = [C.c_void_p]
+        L.rso_get_mtc_queue.argtypes = [C.c_void_p, C.c_int, _lp, _lp, C.c_int, _lp]
         L.rso_random_actions.argtypes = [C.POINTER(RsConfig), C.c_uint64, C.c_uint64, C.c_int64, _ip]
         L.rso_bench_run.restype = C.c_double
         L.rso_bench_run.argtypes = [C.c_void_p, C.c_uint64, C.c_int64, C.c_uint64, C.c_int64]
@@ -143,6 +144,15 @@ class OracleEnv:
         if trace:
             out['trace'] = tr
         return out
+
+    def mtc_queue(self, s, cap=4096):
+        """(time, remaining repetitions, arrival times) of mMTC slice s's FIFO, head first"""
+        rep = np.zeros(cap, dtype=np.int64)
+        start = np.zeros(cap, dtype=np.int64)
+        t = np.zeros(1, dtype=np.int64)
+        n = self.L.rso_get_mtc_queue(self.h, int(s), _p(rep, _lp), _p(start, _lp), cap, _p(t, _lp))
+        assert 0 <= n <= cap
+        return int(t[0]), rep[:n].copy(), start[:n].copy()
 
     def bench_run(self, action_seed, replica, step0, n_steps):
         return self.L.rso_bench_run(self.h, int(action_seed), int(replica), int(step0), int(n_steps))

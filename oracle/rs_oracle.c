@@ -809,6 +809,17 @@ void rso_set_seed(rs_oracle* o, uint64_t seed) {
 }
 const char* rso_error(const rs_oracle* o) { return o->errmsg; }
 void rso_get_counters(const rs_oracle* o, uint64_t counters[4]) { memcpy(counters, o->counters, sizeof o->counters); }
+int rso_get_mtc_queue(const rs_oracle* o, int s, int64_t* rep, int64_t* start, int cap, int64_t* time) {
+    if (!o || s < 0 || s >= o->cfg.n_mmtc) return -1;
+    const rso_mmtc* m = &o->mmtc[s];
+    for (int i = 0; i < m->n_users && i < cap; ++i) {
+        rep[i] = m->q_rep[i];
+        start[i] = m->q_start[i];
+    }
+    if (time) *time = m->time;
+    return m->n_users;
+}
+
 int rso_max_ue(const rs_oracle* o) { return o->max_ue; }
 
 /* NodeB.reset (node_b.py:17-22) */

@@ -48,6 +48,9 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
 const char* rso_error(const rs_oracle* o);
 void rso_get_counters(const rs_oracle* o, uint64_t counters[4]);
 int rso_max_ue(const rs_oracle* o);
+/* SliceL1mMTC state of mMTC slice `s` (slice_l1.py:29-38): FIFO of pending devices (remaining repetitions,
+ * arrival time), head first; returns n_users (at most cap entries are written), *time = SliceL1mMTC.time */
+int rso_get_mtc_queue(const rs_oracle* o, int s, int64_t* rep, int64_t* start, int cap, int64_t* time);
 
 /* bench action script shared with rs_random_actions */
 void rso_random_actions(const rs_config* cfg, uint64_t seed, uint64_t step_index, int64_t replica,

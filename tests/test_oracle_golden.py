@@ -130,6 +130,9 @@ def test_g7_full_step(path, golden_dir):
     slot_i = 0
     ue_off = 0
     n_embb = cfg.n_embb
+    arrivals, departures = [], []        # G5: (slot since reset, slice, type, serial) / (slot, slice, serial)
+    present = [dict() for _ in range(n_embb)]
+    q_i = q_off = 0                       # G8 cursors
     for i, act in enumerate(g['actions']):
         out = env.step(act, trace=True)
         assert out['obs'].tobytes() == g['obs'][i].tobytes(), 'obs bits differ at step %d' % i
@@ -160,5 +163,30 @@ def test_g7_full_step(path, golden_dir):
                 hit = r['p'] != 0
                 np.testing.assert_allclose(r['p'][hit], gf[hit, 2], rtol=PROB_RTOL, atol=0)
                 assert (gi[~hit, 2] == 0).all() or True
+                # G5: arrivals = serials first seen in this slot, departures = serials gone since the last slot
+                now = {int(x['serial']): int(x['type']) for x in r}
+                gslot = i * cfg.slots_per_step + t
+                for ser in sorted(set(now) - set(present[s])):
+                    arrivals.append((gslot, s, now[ser], ser))
+                for ser in present[s]:           # dict order = UE list order, the order departures() walks
+                    if ser not in now:
+                        departures.append((gslot, s, ser))
+                present[s] = now
+        # G8: SliceL1mMTC FIFO (time, remaining repetitions, arrival times) after the step
+        for s in range(cfg.n_mmtc):
+            tm, rep, start = env.mtc_queue(s)
+            n = int(g['g8_n_users'][q_i])
+            assert tm == int(g['g8_time'][q_i]) and len(rep) == n, 'mMTC queue length differs at step %d' % i
+            assert (rep == g['g8_repetitions'][q_off:q_off + n]).all()
+            assert (start == g['g8_t_start'][q_off:q_off + n]).all()
+            q_i += 1
+            q_off += n
     assert env.tape_pos() == len(g['tape_kind']), 'oracle consumed a different number of draws'
     assert slot_i == len(g['slot_n_ue'])
+    assert q_i == len(g['g8_n_users']) and q_off == len(g['g8_repetitions'])
+    # G5: SliceRANeMBB.slot's arrivals (with their CAC decisions) and departures, slot by slot
+    ga = [tuple(int(v) for v in row) for row in g['g5_arrivals']]
+    gd = [tuple(int(v) for v in row) for row in g['g5_departures']]
+    assert sorted(arrivals) == sorted(ga), 'arrival slots / types / serials differ'
+    assert sorted(departures) == sorted(gd), 'departure slots / serials differ'
+    assert len(ga) > 0

@@ -197,6 +197,27 @@ def run_g7(tape, scenario, seed, steps, churn):
 
     slot_rec = []
     orig_slot = slice_l1.SliceL1eMBB.slot
+    # G5: who arrives and who departs, slot by slot (SliceRANeMBB.slot, slice_ran.py:263-268); UE ids are turned
+    # into the arrival rank inside their slice (1-based) so that they do not depend on the shared id counter
+    import slice_ran
+    orig_ran_slot = slice_ran.SliceRANeMBB.slot
+    rank, n_arr, ran_slot = {}, {}, {}
+    g5_arr, g5_dep = [], []
+
+    def ran_slot_hook(self):
+        arrivals, departures = orig_ran_slot(self)
+        t = ran_slot.get(self.id, 0)
+        ran_slot[self.id] = t + 1
+        for ue in arrivals:
+            n_arr[self.id] = n_arr.get(self.id, 0) + 1
+            rank[ue.id] = n_arr[self.id]
+            g5_arr.append((t, self.id, 0 if ue.type == 0 else 1, rank[ue.id]))
+        for uid in departures:
+            g5_dep.append((t, self.id, rank[uid]))
+        return arrivals, departures
+    slice_ran.SliceRANeMBB.slot = ran_slot_hook
+    # G8: the mMTC L1 FIFO after every step (SliceL1mMTC, slice_l1.py:29-38,86-108)
+    g8_n, g8_rep, g8_start, g8_time = [], [], [], []
 
     def slot_hook(self):
         orig_slot(self)
@@ -221,8 +242,15 @@ def run_g7(tape, scenario, seed, steps, churn):
                 else:
                     row[s, :3] = [d[k] for k in MMTC_INFO]
             info.append(row)
+            for l1 in env.node_b.slices_l1:
+                if l1.type == 'mMTC':
+                    g8_n.append(int(l1.n_users))
+                    g8_time.append(int(l1.time))
+                    g8_rep.extend(int(x) for x in l1.repetitions)
+                    g8_start.extend(int(x) for x in l1.t_start)
     finally:
         slice_l1.SliceL1eMBB.slot = orig_slot
+        slice_ran.SliceRANeMBB.slot = orig_ran_slot
         sc.CBR_description.clear()
         sc.CBR_description.update(saved[0])
         sc.VBR_description.clear()
@@ -236,7 +264,11 @@ def run_g7(tape, scenario, seed, steps, churn):
     return dict(scenario=np.int32(scenario), seed=np.int64(seed), churn=np.int32(churn), actions=acts.astype(np.int32),
                 tape_kind=kind, tape_val=val, obs0=np.asarray(obs0, dtype=np.float32), obs=np.asarray(obs),
                 reward=np.asarray(rew), labels=np.asarray(lab), violations=np.asarray(vio), info=np.asarray(info),
-                slot_n_ue=n_ue, slot_ue_int=ue_int, slot_ue_f64=ue_f64)
+                slot_n_ue=n_ue, slot_ue_int=ue_int, slot_ue_f64=ue_f64,
+                g5_arrivals=np.asarray(g5_arr, dtype=np.int64).reshape(-1, 4),
+                g5_departures=np.asarray(g5_dep, dtype=np.int64).reshape(-1, 3),
+                g8_n_users=np.asarray(g8_n, dtype=np.int64), g8_time=np.asarray(g8_time, dtype=np.int64),
+                g8_repetitions=np.asarray(g8_rep, dtype=np.int64), g8_t_start=np.asarray(g8_start, dtype=np.int64))
 
 
 def gen_g7(tape):
