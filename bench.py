@@ -226,11 +226,14 @@ def main():
         alg_bytes = b_fading + b_state + b_io
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         traffic = None
+        valu_frac = None
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
-                    traffic = json.load(f).get('embb_step_kernel_bytes_per_launch')
+                    prof = json.load(f)
+                    traffic = prof.get('embb_step_kernel_bytes_per_launch')
+                    valu_frac = prof.get('valu_issue_frac')
             except Exception:
                 traffic = None
         line = {
@@ -260,6 +263,8 @@ def main():
                 'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'launches_timed': launches,
                 'bytes_per_env_step': alg_bytes / n_envs, 'mean_ues_per_slice': mean_ue,
                 'pf_iterations_per_env_step': (c1[2] - c0[2]) / args.steps / n_envs,
+                # what actually limits the kernel: f64 VALU issue share from the committed SQ counters
+                'valu_issue_frac_profiled': valu_frac,
             },
         }
         line['cpu_baseline'] = cpu_base
