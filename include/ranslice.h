@@ -145,7 +145,8 @@ int rs_get_counters(rs_handle* h, uint64_t counters[4]);
 int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches);
 int rs_set_kernel_timing(rs_handle* h, int enable);
 
-/* Lanes per (replica, eMBB slice) task in the primary step launch: 8, 16 (default) or 32.  Tasks that need
+/* Lanes per (replica, eMBB slice) task in the primary step launch: 8, 16 or 32 (default: 32 up to 6144 tasks,
+ * 16 above).  Tasks that need
  * more UE lanes are replayed by the 32-lane instance; results are identical for every setting. */
 int rs_set_group_size(rs_handle* h, int lanes);
 

@@ -408,6 +408,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_ohist, 2 * RS_ORDER_BINS);
     HIPCHK(h, hipMemset(h->d_ohist, 0, sizeof(int) * 2 * RS_ORDER_BINS));
     if (const char* e = getenv("RANSLICE_ORDER")) h->order_mode = atoi(e);
+    // Lanes per task: with few tasks the step is pure latency and the 32-lane instance (more lanes per sum and per
+    // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
+    // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
+    h->group = h->n_tasks <= 6144 ? 32 : 16;
     DA(h->d_st, 1);
     DA(h->d_run, 4);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
