@@ -53,6 +53,8 @@ def main():
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
         fut = ex.map(oracle_run, [(scenario, seed0 + r, [a[r] for a in acts], churn) for r in range(n)], chunksize=4)
         env = VecRanSlice(n_envs=n, cfg=cfg, fading=[g['t0'], g['t1'], g['t2']], seed=seed0)
+        if os.environ.get('SOAK_GROUP'):
+            env.set_group_size(int(os.environ['SOAK_GROUP']))
         env.reset()
         hip = []
         for a in acts:
