@@ -33,18 +33,27 @@ __device__ __forceinline__ int order_key(int mode, int n_ue, int n_prb, int cost
     return key < RS_ORDER_BINS ? key : RS_ORDER_BINS - 1;
 }
 
-// hist: this step's bin counters (zero on entry); slot[task] = bin | rank-in-bin << 11
+// hist: this step's bin counters (zero on entry); slot[task] = bin | rank-in-bin << 11.  Ranks are taken inside the
+// block first (LDS atomics), then one global atomic per (block, occupied bin) reserves the block's range.
 __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict__ D, const RsState* __restrict__ Sp,
                                                         const int32_t* __restrict__ actions, int mode, int* hist,
                                                         uint64_t* slot) {
+    __shared__ int cnt[RS_ORDER_BINS];  // tasks of this block per bin, then the block's base rank in the bin
+    for (int k = threadIdx.x; k < RS_ORDER_BINS; k += 256) cnt[k] = 0;
+    __syncthreads();
     const int n_tasks = D->n_envs * D->n_embb;
     const int task = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (task >= n_tasks) return;
-    const int rep = task / D->n_embb, sl = task - rep * D->n_embb;
-    const int n_prb = actions[rep * D->n_slices + sl];
-    const int bin = RS_ORDER_BINS - 1 - order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);  // heaviest first
-    const int rank = atomicAdd(&hist[bin], 1);
-    slot[task] = (uint64_t)bin | ((uint64_t)rank << 11);
+    int bin = 0, local = 0;
+    if (task < n_tasks) {
+        const int rep = task / D->n_embb, sl = task - rep * D->n_embb;
+        const int n_prb = actions[rep * D->n_slices + sl];
+        bin = RS_ORDER_BINS - 1 - order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);  // heaviest first
+        local = atomicAdd(&cnt[bin], 1);
+    }
+    __syncthreads();
+    if (task < n_tasks && local == 0) cnt[bin] = atomicAdd(&hist[bin], cnt[bin]);  // first of its bin in the block
+    __syncthreads();
+    if (task < n_tasks) slot[task] = (uint64_t)bin | ((uint64_t)(cnt[bin] + local) << 11);
 }
 
 // order[start(bin) + rank] = task; also clears the other parity's counters for the next step
