@@ -47,6 +47,9 @@ __device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
 namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
+#ifndef RS_GRANT_FRAC
+#define RS_GRANT_FRAC 4u
+#endif
 #ifndef RS_PRIO_A
 #define RS_PRIO_A 10u
 #define RS_PRIO_B 4u
@@ -486,11 +489,16 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     // per-UE running sums (traffic, th(bits), prb) live in L_acc_*; flush() folds them into info[] by class
     unsigned cnt_samples = 0u, cnt_pf = 0u, cnt_ue = 0u;  // per step: < 2^32
     int pf_trips = 0;  // contested PF trips of this task in this step
+    // The heaviest waves of the launch (by cost rank) set its duration through their dependent chains, the others
+    // through their instruction count: the former schedule with one trip per RB pair and overlapped chains, the
+    // latter with the leader-run loop (fewer instructions per task).  Wave-uniform.
+    bool grant_loop = false;
     {
         // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
         // get issue priority over their lighter neighbours on the SIMD for the whole step.
         if (A.order) {
+            grant_loop = (blockIdx.x * 4u + (threadIdx.x >> 6)) * RS_GRANT_FRAC < gridDim.x * 4u;
             // launch order = cost rank (rs_order.hip): the heaviest tenth of the waves, the next fifth, ...
             const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
             if (w * RS_PRIO_A < nw) __builtin_amdgcn_s_setprio(3);
@@ -792,96 +800,185 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             int rbs = 0, bits = 0;
             double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
-            // leader (first maximum) and runner-up of the group's metrics.  After a contested run only the
-            // leader's metric has changed and it ended below the runner-up, so the runner-up is the next leader
-            // and only the new runner-up needs a reduction; `need_full` (group-uniform) asks for both.
             bool need_full = true;
             double mx = 0.0;
             int idx = 0;
             SEC_MARK(8)
-            for (;;) {
-                const bool more = sched && r < n_prb;
-                if (!wave_any(more)) break;
-                if (more) pf_trips += 1;
+            if (grant_loop) {
+                // One trip per RB pair (the heaviest waves of the launch, see `grant_loop` above).  Every lane
+                // precomputes its own state *as if* it were granted the pair -- in SIMD that costs what the
+                // leader's update alone would cost -- so the f64 divide of the update does not depend on the
+                // cross-lane reduction of the same trip and the two chains overlap; the leader just selects.
+                bool need_second = true;
+                double m2 = 0.0;
+                int idx2 = 0;
+                for (;;) {
+                    const bool more = sched && r < n_prb;
+                    if (!wave_any(more)) break;
+                    if (more) pf_trips += 1;
 #ifdef RS_SECTION_PROFILE
-                sec_acc[15] += 1;  // PF loop trips (not cycles)
+                    sec_acc[15] += 1;
 #endif
-                if (wave_any(more && need_full)) {
-                    const double fm = group_max<G>(m);
-                    const unsigned eq = group_ballot<G>(m == fm, gbase);
-                    if (need_full) {
-                        mx = fm;
-                        idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                    // candidate state after one more RB pair at position r (schedulers.py:52-63)
+                    const int c_prbs = n_prb - r < gran ? n_prb - r : gran;
+                    const int c_tx = c_prbs * rate < q ? c_prbs * rate : q;
+                    const int c_q = q - c_tx, c_bits = bits + c_tx;
+                    const double c_thl = pf_a * thl + pf_share(c_bits);
+                    const double c_m = c_q > 0 ? rate_d / c_thl : 0.0;  // a drained UE's metric is 0
+                    if (wave_any(more && need_full)) {
+                        const double fm = group_max<G>(m);
+                        const unsigned eq = group_ballot<G>(m == fm, gbase);
+                        if (need_full) {
+                            mx = fm;
+                            idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                        }
                     }
-                }
-                const double m_rest = gl == idx ? -2.0 : m;
-                const double m2 = group_max<G>(m_rest);
-                const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
-                const int idx2 = __ffs((int)eq2) - 1;
-                int take = 0;
-                SEC_MARK(11)
-                if (more) {
-                    if (mx == 0.0) {
-                        // every queue is empty: argmax of an all-zero metric is UE 0 for all the
-                        // remaining RB pairs (Q4); its local th is discarded afterwards
-                        if (gl == 0) rbs += n_prb - r;
-                    } else if (gl == idx) {
-                        // Only the leader's metric changes while it keeps winning, so the leader's lane
-                        // runs the reference loop alone until it stops being the argmax.
-                        if (m2 <= 0.0) {
-                            // nobody else has data: it wins every RB pair until drained -> closed form
-                            const int R = n_prb - r;
-                            const int per_it = gran * rate;
-                            // ceil divisions through one IEEE f64 divide each (exact: operands < 2^31 and the
-                            // quotient of two integers is never within rounding distance of the next integer);
-                            // the 32-bit integer divide costs ~40 VALU instructions on this ISA
-                            const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
-                            const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
-                            const bool all = k_full >= K;
-                            const int cap_bits = R * rate;
-                            const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
-                            take = all ? K * gran : k_full * gran;
-                            rbs += all ? R : take;
-                            q -= tx;
-                            bits += tx;
-                            m = 0.0;  // drained, or no RBs left
-                        } else {
-                            int rr = r;
-                            bool keep;
-                            do {
-#ifdef RS_SECTION_PROFILE
-                                sec_acc[13] += 1;  // leader-run iterations (all lanes are summed)
-#endif
-                                const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
-                                rbs += prbs;
-                                const int tx = prbs * rate < q ? prbs * rate : q;
+                    if (wave_any(more && need_second)) {  // a leader that stays keeps its runner-up
+                        const double m_rest = gl == idx ? -2.0 : m;
+                        const double f2 = group_max<G>(m_rest);
+                        const unsigned eq2 = group_ballot<G>(m_rest == f2, gbase);
+                        if (need_second) {
+                            m2 = f2;
+                            idx2 = __ffs((int)eq2) - 1;
+                        }
+                    }
+                    const bool contested = more && mx != 0.0 && m2 > 0.0;
+                    const bool lead = contested && gl == idx;
+                    if (lead) {
+                        rbs += c_prbs;
+                        q = c_q;
+                        bits = c_bits;
+                        thl = c_q > 0 ? c_thl : thl;  // a drained UE keeps its (discarded) local th
+                        m = c_m;
+                    }
+                    // the leader stays while it is still the first maximum
+                    const bool stays = group_ballot<G>(lead && (c_m > m2 || (c_m == m2 && gl < idx2)), gbase) != 0u;
+                    if (contested) {
+                        r += gran;
+                        need_full = false;
+                        need_second = !stays;
+                        if (!stays) {  // the runner-up's metric is the group's maximum now
+                            mx = m2;
+                            idx = idx2;
+                        }
+                    }
+                    // every queue empty, or only the leader has data (closed form)
+                    if (wave_any(more && !contested)) {
+                        int take = 0;
+                        if (more && !contested) {
+                            if (mx == 0.0) {
+                                if (gl == 0) rbs += n_prb - r;  // Q4: the remaining RB pairs go to UE 0
+                            } else if (gl == idx) {
+                                const int R = n_prb - r;
+                                const int per_it = gran * rate;
+                                const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
+                                const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
+                                const bool all = k_full >= K;
+                                const int cap_bits = R * rate;
+                                const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
+                                take = all ? K * gran : k_full * gran;
+                                rbs += all ? R : take;
                                 q -= tx;
                                 bits += tx;
-                                rr += gran;
-                                if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
-                                    thl = pf_a * thl + pf_share(bits);
-                                    m = rate_d / thl;
-                                    keep = m > m2 || (m == m2 && gl < idx2);
-                                } else {
-                                    m = 0.0;
-                                    keep = false;  // m2 > 0 here
-                                }
-                            } while (keep && rr < n_prb);
-                            take = rr - r;
+                                m = 0.0;  // drained, or no RBs left
+                            }
+                        }
+                        const int tk = bperm(take, gbase + idx);
+                        if (more && !contested) {
+                            r = mx == 0.0 ? n_prb : r + tk;
+                            need_full = true;
+                            need_second = true;
                         }
                     }
                 }
-                SEC_MARK(12)
-                const int tk = bperm(take, gbase + idx);
-                if (more) {
-                    r = mx == 0.0 ? n_prb : r + tk;
-                    if (mx != 0.0 && m2 > 0.0) {
-                        // the run ended below the runner-up (or the RBs ran out): next leader is known
-                        need_full = false;
-                        mx = m2;
-                        idx = idx2;
-                    } else {
-                        need_full = true;
+            } else {
+                // leader (first maximum) and runner-up of the group's metrics.  After a contested run only the
+                // leader's metric has changed and it ended below the runner-up, so the runner-up is the next leader
+                // and only the new runner-up needs a reduction; `need_full` (group-uniform) asks for both.
+                for (;;) {
+                    const bool more = sched && r < n_prb;
+                    if (!wave_any(more)) break;
+                    if (more) pf_trips += 1;
+    #ifdef RS_SECTION_PROFILE
+                    sec_acc[15] += 1;  // PF loop trips (not cycles)
+    #endif
+                    if (wave_any(more && need_full)) {
+                        const double fm = group_max<G>(m);
+                        const unsigned eq = group_ballot<G>(m == fm, gbase);
+                        if (need_full) {
+                            mx = fm;
+                            idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                        }
+                    }
+                    const double m_rest = gl == idx ? -2.0 : m;
+                    const double m2 = group_max<G>(m_rest);
+                    const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
+                    const int idx2 = __ffs((int)eq2) - 1;
+                    int take = 0;
+                    SEC_MARK(11)
+                    if (more) {
+                        if (mx == 0.0) {
+                            // every queue is empty: argmax of an all-zero metric is UE 0 for all the
+                            // remaining RB pairs (Q4); its local th is discarded afterwards
+                            if (gl == 0) rbs += n_prb - r;
+                        } else if (gl == idx) {
+                            // Only the leader's metric changes while it keeps winning, so the leader's lane
+                            // runs the reference loop alone until it stops being the argmax.
+                            if (m2 <= 0.0) {
+                                // nobody else has data: it wins every RB pair until drained -> closed form
+                                const int R = n_prb - r;
+                                const int per_it = gran * rate;
+                                // ceil divisions through one IEEE f64 divide each (exact: operands < 2^31 and the
+                                // quotient of two integers is never within rounding distance of the next integer);
+                                // the 32-bit integer divide costs ~40 VALU instructions on this ISA
+                                const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
+                                const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
+                                const bool all = k_full >= K;
+                                const int cap_bits = R * rate;
+                                const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
+                                take = all ? K * gran : k_full * gran;
+                                rbs += all ? R : take;
+                                q -= tx;
+                                bits += tx;
+                                m = 0.0;  // drained, or no RBs left
+                            } else {
+                                int rr = r;
+                                bool keep;
+                                do {
+    #ifdef RS_SECTION_PROFILE
+                                    sec_acc[13] += 1;  // leader-run iterations (all lanes are summed)
+    #endif
+                                    const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
+                                    rbs += prbs;
+                                    const int tx = prbs * rate < q ? prbs * rate : q;
+                                    q -= tx;
+                                    bits += tx;
+                                    rr += gran;
+                                    if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
+                                        thl = pf_a * thl + pf_share(bits);
+                                        m = rate_d / thl;
+                                        keep = m > m2 || (m == m2 && gl < idx2);
+                                    } else {
+                                        m = 0.0;
+                                        keep = false;  // m2 > 0 here
+                                    }
+                                } while (keep && rr < n_prb);
+                                take = rr - r;
+                            }
+                        }
+                    }
+                    SEC_MARK(12)
+                    const int tk = bperm(take, gbase + idx);
+                    if (more) {
+                        r = mx == 0.0 ? n_prb : r + tk;
+                        if (mx != 0.0 && m2 > 0.0) {
+                            // the run ended below the runner-up (or the RBs ran out): next leader is known
+                            need_full = false;
+                            mx = m2;
+                            idx = idx2;
+                        } else {
+                            need_full = true;
+                        }
                     }
                 }
             }
