@@ -48,7 +48,7 @@ namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
 #ifndef RS_GRANT_FRAC
-#define RS_GRANT_FRAC 4u
+#define RS_GRANT_FRAC 8u
 #endif
 #ifndef RS_PRIO_A
 #define RS_PRIO_A 10u
