@@ -305,7 +305,7 @@ struct CtlArgs {
 };
 
 // KBRL_Control.update_control for one learner (kbrl_control.py:83-112)
-__global__ __launch_bounds__(256) void update_control_kernel(CtlArgs A) {
+__global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
     const KbDev& D = A.D;
     Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
