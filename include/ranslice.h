@@ -150,6 +150,12 @@ int rs_set_kernel_timing(rs_handle* h, int enable);
  * more UE lanes are replayed by the 32-lane instance; results are identical for every setting. */
 int rs_set_group_size(rs_handle* h, int lanes);
 
+/* Scheduling hint.  mode 1: allocations come from a learning agent (the carrier is concentrated on few slices);
+ * the step launches the kernel instance tuned for long contested PF loops.  mode 0: the plain instance.
+ * mode < 0 (default): automatic -- by batch size, and kb_step_resident switches it on for the environment it
+ * drives.  Results do not depend on it. */
+int rs_set_schedule_hint(rs_handle* h, int mode);
+
 /* Developer aid: cycle sums per code section of the eMBB step kernel (zeros in normal builds). */
 int rs_get_section_profile(rs_handle* h, uint64_t out[16]);
 /* Developer aid (profile builds): per eMBB task [n_envs * n_embb][4] = cycles of the task's wave in the last step,

@@ -272,6 +272,10 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
         return RS_EINVAL;
     }
     HIPCHK(k, hipSetDevice(k->device));
+    if (env->grant_auto && !env->grant_mode) {  // the next steps take agent-made allocations
+        rs_set_schedule_hint(env, 1);
+        env->grant_auto = true;
+    }
     // order after the simulator's step on its own stream
     hipEvent_t done;
     HIPCHK(k, hipEventCreateWithFlags(&done, hipEventDisableTiming));

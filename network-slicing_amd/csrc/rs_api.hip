@@ -49,6 +49,8 @@ struct rs_handle {
     int* d_ohist = nullptr;      // [2][RS_ORDER_BINS] bin counters, alternating between steps
     int order_par = 0;           // which half of d_ohist the next step counts into
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
+    int grant_mode = 0;          // 1: the heaviest waves schedule one RB pair per trip (rs_set_schedule_hint)
+    bool grant_auto = true;      // grant_mode follows the batch size / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;
@@ -412,6 +414,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
     // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
     h->group = h->n_tasks <= 6144 ? 32 : 16;
+    h->grant_mode = h->n_tasks <= 6144 ? 1 : 0;  // latency-bound batches: the shorter PF chain wins
     DA(h->d_st, 1);
     DA(h->d_run, 4);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
@@ -600,15 +603,18 @@ static int launch_step(rs_handle* h) {
             const int per_block = 256 / g;
             dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
+            const bool gr = h->grant_mode && !tr && !a.replay;
             if (g == 8) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<8, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true, false>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<8, false, false>), grid, block, 0, h->stream, a);
             } else if (g == 16) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<16, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, false>), grid, block, 0, h->stream, a);
+                else if (gr) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
             } else {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<32, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, false>), grid, block, 0, h->stream, a);
+                else if (gr) hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<32, false, false>), grid, block, 0, h->stream, a);
             }
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
@@ -827,6 +833,18 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
 }
 
 // Lanes per task of the primary eMBB launch (8, 16 or 32).  Results do not depend on it.
+// mode 1: allocations come from a learning agent, which concentrates the carrier on few slices (long contested PF
+// loops in a few tasks): the step uses the instance whose heaviest waves schedule one RB pair per trip.  mode 0:
+// the plain instance.  mode < 0: automatic (by batch size; kb_step_resident switches it on for the environment it
+// drives).  A scheduling hint only: results are identical.
+extern "C" int rs_set_schedule_hint(rs_handle* h, int mode) {
+    if (!h) return RS_EINVAL;
+    h->grant_auto = mode < 0;
+    h->grant_mode = mode < 0 ? (h->n_tasks <= 6144 ? 1 : 0) : (mode ? 1 : 0);
+    drop_graph(h);
+    return RS_OK;
+}
+
 extern "C" int rs_set_group_size(rs_handle* h, int lanes) {
     if (!h || (lanes != 8 && lanes != 16 && lanes != 32)) return RS_EINVAL;
     h->group = lanes;

@@ -372,7 +372,7 @@ struct MiHbm {
 
 // 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
 // instances are test tooling: they keep the register budget of 3 waves per SIMD, which needs no spills.
-template <int G, bool TRACE>
+template <int G, bool TRACE, bool GRANT>
 __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_kernel(StepArgs A) {
     constexpr int LPU = RS_LPU;                      // lanes that share one UE's pairwise sums
     constexpr int LOG_LPU = LPU == 8 ? 3 : (LPU == 4 ? 2 : 1);
@@ -490,15 +490,17 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     unsigned cnt_samples = 0u, cnt_pf = 0u, cnt_ue = 0u;  // per step: < 2^32
     int pf_trips = 0;  // contested PF trips of this task in this step
     // The heaviest waves of the launch (by cost rank) set its duration through their dependent chains, the others
-    // through their instruction count: the former schedule with one trip per RB pair and overlapped chains, the
-    // latter with the leader-run loop (fewer instructions per task).  Wave-uniform.
+    // through their instruction count: in a GRANT instance the former schedule with one trip per RB pair and
+    // overlapped chains, the latter with the leader-run loop (fewer instructions per task).  Wave-uniform.  The
+    // second loop costs the plain instance ~1 % just by being there, so it is a template parameter, chosen per
+    // launch (rs_api.hip: agent-driven allocations and latency-bound small batches take the GRANT instance).
     bool grant_loop = false;
     {
         // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
         // get issue priority over their lighter neighbours on the SIMD for the whole step.
         if (A.order) {
-            grant_loop = (blockIdx.x * 4u + (threadIdx.x >> 6)) * RS_GRANT_FRAC < gridDim.x * 4u;
+            grant_loop = GRANT && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RS_GRANT_FRAC < gridDim.x * 4u;
             // launch order = cost rank (rs_order.hip): the heaviest tenth of the waves, the next fifth, ...
             const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
             if (w * RS_PRIO_A < nw) __builtin_amdgcn_s_setprio(3);

@@ -18,7 +18,7 @@ KB_EXPORTS = (
 
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
-    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
+    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
     'rs_set_kernel_timing', 'rs_synchronize', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
 ) + KB_EXPORTS
 
@@ -58,6 +58,7 @@ def load():
     L.rs_get_section_profile.argtypes = [vp, up]
     L.rs_get_task_profile.argtypes = [vp, up]
     L.rs_set_group_size.argtypes = [vp, C.c_int]
+    L.rs_set_schedule_hint.argtypes = [vp, C.c_int]
     L.rs_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
     L.rs_set_kernel_timing.argtypes = [vp, C.c_int]
     L.rs_synchronize.argtypes = [vp]

@@ -118,6 +118,10 @@ class VecRanSlice:
         """lanes per task of the primary step launch (8, 16, 32); results do not depend on it"""
         self._check(self.L.rs_set_group_size(self.h, int(lanes)))
 
+    def set_schedule_hint(self, mode):
+        """1: allocations are agent-made (few wide slices), 0: plain instance, -1: automatic; same results"""
+        self._check(self.L.rs_set_schedule_hint(self.h, int(mode)))
+
     def set_alloc_trace(self, enable=True):
         self._check(self.L.rs_set_alloc_trace(self.h, int(bool(enable))))
 
