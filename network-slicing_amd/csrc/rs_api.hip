@@ -50,6 +50,7 @@ struct rs_handle {
     int order_par = 0;           // which half of d_ohist the next step counts into
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
     int grant_mode = 0;          // 1: the heaviest waves schedule one RB pair per trip (rs_set_schedule_hint)
+    uint32_t grant_div = 8;      // share of the waves that take the one-trip-per-pair loop (RANSLICE_GRANT_DIV, tests)
     bool grant_auto = true;      // grant_mode follows the batch size / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
@@ -415,6 +416,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
     h->group = h->n_tasks <= 6144 ? 32 : 16;
     h->grant_mode = h->n_tasks <= 6144 ? 1 : 0;  // latency-bound batches: the shorter PF chain wins
+    if (const char* e = getenv("RANSLICE_GRANT_DIV")) h->grant_div = atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
     DA(h->d_st, 1);
     DA(h->d_run, 4);
     DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
@@ -587,6 +589,7 @@ static int launch_step(rs_handle* h) {
         a.mi_wide = h->d_mi_wide;
         a.replay = 0;
         a.order = nullptr;
+        a.grant_div = h->grant_div;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -603,16 +606,18 @@ static int launch_step(rs_handle* h) {
             const int per_block = 256 / g;
             dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
-            const bool gr = h->grant_mode && !tr && !a.replay;
+            const bool gr = h->grant_mode && !a.replay;
             if (g == 8) {
                 if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true, false>), grid, block, 0, h->stream, a);
                 else hipLaunchKernelGGL((embb_step_kernel<8, false, false>), grid, block, 0, h->stream, a);
             } else if (g == 16) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, false>), grid, block, 0, h->stream, a);
+                if (tr && gr) hipLaunchKernelGGL((embb_step_kernel<16, true, true>), grid, block, 0, h->stream, a);
+                else if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, false>), grid, block, 0, h->stream, a);
                 else if (gr) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
                 else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
             } else {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, false>), grid, block, 0, h->stream, a);
+                if (tr && gr) hipLaunchKernelGGL((embb_step_kernel<32, true, true>), grid, block, 0, h->stream, a);
+                else if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, false>), grid, block, 0, h->stream, a);
                 else if (gr) hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
                 else hipLaunchKernelGGL((embb_step_kernel<32, false, false>), grid, block, 0, h->stream, a);
             }

@@ -47,9 +47,6 @@ __device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
 namespace rs {
 
 // Optional per-section cycle accounting (build with -DRS_SECTION_PROFILE; tools/section_profile.py).
-#ifndef RS_GRANT_FRAC
-#define RS_GRANT_FRAC 8u
-#endif
 #ifndef RS_PRIO_A
 #define RS_PRIO_A 10u
 #define RS_PRIO_B 4u
@@ -352,6 +349,7 @@ struct StepArgs {
     int32_t replay;           // 1: process only tasks whose redo flag is set
     double* mi_wide;          // [n_tasks][RS_MAX_PRBS] scratch rows for slices wider than the LDS slice
     const int32_t* order;     // [n_tasks] launch order of the tasks (rs_order.hip) or null = task index order
+    uint32_t grant_div;       // GRANT instances: the heaviest 1/grant_div of the waves take the one-trip-per-pair loop
 };
 
 // where R1 parks the per-RB mutual information for R2
@@ -500,7 +498,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
         // get issue priority over their lighter neighbours on the SIMD for the whole step.
         if (A.order) {
-            grant_loop = GRANT && (blockIdx.x * 4u + (threadIdx.x >> 6)) * RS_GRANT_FRAC < gridDim.x * 4u;
+            grant_loop = GRANT && (blockIdx.x * 4u + (threadIdx.x >> 6)) * A.grant_div < gridDim.x * 4u;
             // launch order = cost rank (rs_order.hip): the heaviest tenth of the waves, the next fifth, ...
             const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
             if (w * RS_PRIO_A < nw) __builtin_amdgcn_s_setprio(3);

@@ -98,6 +98,17 @@ def test_scenario0_small_trace(golden_dir):
     _compare(0, n_envs=24, steps=8, fading=_small_fading(golden_dir), churn=False, seed0=1)
 
 
+@pytest.mark.parametrize('share', [1, 8])
+def test_grant_loop_allocations(golden_dir, share, monkeypatch):
+    """per-slot allocations of the one-trip-per-RB-pair PF loop (GRANT instances; small batches select them by
+    default) against the oracle, for 16 and 32 lanes per task; share 1 puts every wave on that loop, 8 is the
+    production split between the two loops"""
+    monkeypatch.setenv('RANSLICE_GRANT_DIV', str(share))
+    for group in (16, 32):
+        _compare(0, n_envs=64, steps=20, fading=_small_fading(golden_dir), churn=True, seed0=4000 + share,
+                 group=group, hint=1)
+
+
 @pytest.mark.parametrize('group', [8, 16, 32])
 def test_scenario0_churn(golden_dir, group):
     """arrivals, admission control, departures, compaction, VBR bursts all fire within a few steps;
