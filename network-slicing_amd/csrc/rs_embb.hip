@@ -995,8 +995,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             // slice wider than that slice (n_prb > MI_CAP, rare), to a per-task HBM scratch row read back with
             // L1-bypassing loads.  R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup.
             const bool wide = n_prb > MI_CAP;  // group-uniform
-            auto r1r2 = [&](auto mip, const bool sel) -> double {
-                for (int pass = 0; wave_any(sched && sel && pass * G < n_prb); ++pass) {
+            auto r1r2 = [&](auto mip, const bool sel, const bool r1_done) -> double {
+                for (int pass = 0; wave_any(sched && sel && !r1_done && pass * G < n_prb); ++pass) {
                     int o_col = 0, o_mcs = 0, o_rbs = 0;
                     double o_nom = 0.0;
                     const int k = pass * G + gl;
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                         }
                         mm &= mm - 1u;
                     }
-                    if (sched && sel && k < n_prb) {
+                    if (sched && sel && !r1_done && k < n_prb) {
                         const double x = A.fad[o_col + prb_lo + k] + o_nom;
                         // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
                         mip.st(k, o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x);
@@ -1035,9 +1035,46 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 }
                 return acc_rx;
             };
-            double sum_rx = r1r2(MiLds{mi}, !wide);
+            double sum_rx = r1r2(MiLds{mi}, !wide, false);
             if (wave_any(sched && wide)) {
-                const double s2 = r1r2(MiHbm{A.mi_wide + (size_t)task * RS_MAX_PRBS}, wide);
+                bool r1_done = false;
+                if (GRANT && G < 32) {
+                    // A wide slice is what an agent-made allocation looks like: ~180 RBs in one task, a handful in
+                    // its three wave-mates.  All 64 lanes of the wave then work through the wide task's RBs (its
+                    // per-UE ranges come over v_readlane, the group index being wave-uniform): 3 passes, not 12.
+                    unsigned long long wmask = __builtin_amdgcn_ballot_w64(sched && wide && gl == 0);
+                    while (wmask != 0ull) {
+                        const int wl = __builtin_ctzll(wmask);  // first lane of the wide group
+                        wmask &= wmask - 1ull;
+                        const int w_nprb = __builtin_amdgcn_readlane(n_prb, wl);
+                        const int w_lo = __builtin_amdgcn_readlane(prb_lo, wl);
+                        const int w_task = __builtin_amdgcn_readlane(task, wl);
+                        const unsigned w_smask = (unsigned)__builtin_amdgcn_readlane((int)smask, wl);
+                        double* const row = A.mi_wide + (size_t)w_task * RS_MAX_PRBS;
+                        for (int k0 = 0; k0 < w_nprb; k0 += 64) {
+                            const int k = k0 + lane;
+                            int o_col = 0, o_mcs = 0, o_rbs = 0;
+                            double o_nom = 0.0;
+                            for (unsigned mm = w_smask; mm != 0u; mm &= mm - 1u) {
+                                const int ul = wl + __ffs((int)mm) - 1;  // lane of the scheduled UE (uniform)
+                                const int s_u = __builtin_amdgcn_readlane(prb_i, ul);
+                                const int e_u = __builtin_amdgcn_readlane(prb_end, ul);
+                                if (k >= s_u && k < e_u) {
+                                    o_col = __builtin_amdgcn_readlane(col, ul);
+                                    o_mcs = __builtin_amdgcn_readlane(mcs, ul);
+                                    o_rbs = e_u - s_u;
+                                    o_nom = L_nom[(tid & ~63) + ul];
+                                }
+                            }
+                            if (k < w_nprb) {
+                                const double x = A.fad[o_col + w_lo + k] + o_nom;
+                                row[k] = o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x;
+                            }
+                        }
+                    }
+                    r1_done = true;
+                }
+                const double s2 = r1r2(MiHbm{A.mi_wide + (size_t)task * RS_MAX_PRBS}, wide, r1_done);
                 if (wide) sum_rx = s2;
             }
             SEC_MARK(10)
