@@ -1046,12 +1046,13 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                     while (wmask != 0ull) {
                         const int wl = __builtin_ctzll(wmask);  // first lane of the wide group
                         wmask &= wmask - 1ull;
-                        const int w_nprb = __builtin_amdgcn_readlane(n_prb, wl);
-                        const int w_lo = __builtin_amdgcn_readlane(prb_lo, wl);
-                        const int w_task = __builtin_amdgcn_readlane(task, wl);
+                        // (fetched into VGPRs: keeps the scalar register file, which already spills, out of it)
+                        const int w_nprb = bperm(n_prb, wl);
+                        const int w_lo = bperm(prb_lo, wl);
+                        const int w_task = bperm(task, wl);
                         const unsigned w_smask = (unsigned)__builtin_amdgcn_readlane((int)smask, wl);
                         double* const row = A.mi_wide + (size_t)w_task * RS_MAX_PRBS;
-                        for (int k0 = 0; k0 < w_nprb; k0 += 64) {
+                        for (int k0 = 0; wave_any(k0 < w_nprb); k0 += 64) {
                             const int k = k0 + lane;
                             int o_col = 0, o_mcs = 0, o_rbs = 0;
                             double o_nom = 0.0;

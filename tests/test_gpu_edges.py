@@ -183,3 +183,45 @@ def test_graph_captured_loop_equals_step_by_step(golden_dir, scenario):
     a, c = ref.fetch(), graph.fetch()
     for k in ('actions', 'obs', 'reward', 'labels', 'violations'):
         assert np.array_equal(a[k], c[k]), k
+
+
+@pytest.mark.parametrize('group', [16, 32])
+def test_schedule_hint_does_not_change_results(golden_dir, group):
+    """agent-like allocations (most of the carrier on one or two slices, so that slices wider than the LDS row
+    and long contested PF loops occur): the plain instance, the GRANT instance (one-trip-per-pair PF loop on its
+    heaviest waves, whole-wave R1 for wide slices) and the GRANT instance with every wave on that loop leave
+    identical observations, rewards, labels and info sums behind"""
+    import os
+    from ranslice.vec_env import VecRanSlice
+    fading = _fading(golden_dir)
+    N = 640
+
+    def make(hint, div=None):
+        if div is not None:
+            os.environ['RANSLICE_GRANT_DIV'] = str(div)
+        try:
+            e = VecRanSlice(n_envs=N, cfg=_churn(make_config(0, n_envs=N)), fading=fading, seed=21)
+        finally:
+            os.environ.pop('RANSLICE_GRANT_DIV', None)
+        e.set_group_size(group)
+        e.set_schedule_hint(hint)
+        e.reset()
+        return e
+
+    envs = [make(0), make(1), make(1, div=1)]
+    rng = np.random.default_rng(5)
+    for i in range(25):
+        a = rng.integers(0, 6, size=(N, 5))
+        big = rng.integers(0, 5, size=N)
+        a[np.arange(N), big] = rng.integers(115, 171, size=N)  # sum <= 170 + 4 * 5 + 9 < 200
+        second = (big + 1 + rng.integers(0, 4, size=N)) % 5
+        a[np.arange(N), second] += rng.integers(0, 2, size=N) * rng.integers(0, 10, size=N)
+        a = a.astype(np.int32)
+        outs = [e.step(a) for e in envs]
+        infos = [e.l1_info() for e in envs]
+        for o, inf in zip(outs[1:], infos[1:]):
+            assert o[0].tobytes() == outs[0][0].tobytes(), 'obs differ at step %d' % i
+            assert (o[1] == outs[0][1]).all()
+            assert (o[3]['SLA_labels'] == outs[0][3]['SLA_labels']).all()
+            assert (o[3]['violations'] == outs[0][3]['violations']).all()
+            assert inf.tobytes() == infos[0].tobytes()
