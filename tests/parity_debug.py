@@ -1,9 +1,12 @@
+"""First diverging slot between the HIP step and the oracle, with the per-UE records around it (developer aid;
+DBG_CHURN=1 high-churn traffic, DBG_TRACE=1 compare per-slot allocations).  usage: python tests/parity_debug.py"""
 import os, sys, numpy as np
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/network-slicing_amd')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
 from oracle import pyoracle as po
 from ranslice.config import make_config
 from ranslice.vec_env import VecRanSlice
-g = np.load('/root/repo/tests/golden/fading_small.npz'); fading = [g['t0'], g['t1'], g['t2']]
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 'fading_small.npz')); fading = [g['t0'], g['t1'], g['t2']]
 N = 8
 def mk(n):
     c = make_config(0, n_envs=n)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large oracle-vs-HIP comparison of the production step instance (no trace): every replica, bit for bit.
-usage: python tools/soak.py [scenario] [n_envs] [steps] [seed]   (needs a GPU; developer tool)"""
+usage: python tests/soak_check.py [scenario] [n_envs] [steps] [seed]   (needs a GPU; developer tool)"""
 import os
 import sys
 import time
