@@ -7,6 +7,7 @@ struct kb_handle {
     kb_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipEvent_t ev_order = nullptr;  // orders the agent's stream against the simulator's (kb_step_resident)
     kb::KbDev D;
     kb::KbState K;
     std::vector<void*> allocs;
@@ -132,6 +133,7 @@ extern "C" void kb_destroy(kb_handle* k) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (k->ev_order) (void)hipEventDestroy(k->ev_order);
     if (k->stream) (void)hipStreamDestroy(k->stream);
     delete k;
 }
@@ -277,8 +279,8 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
         env->grant_auto = true;
     }
     // order after the simulator's step on its own stream
-    hipEvent_t done;
-    HIPCHK(k, hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    if (!k->ev_order) HIPCHK(k, hipEventCreateWithFlags(&k->ev_order, hipEventDisableTiming));
+    hipEvent_t done = k->ev_order;
     HIPCHK(k, hipEventRecord(done, env->stream));
     HIPCHK(k, hipStreamWaitEvent(k->stream, done, 0));
     int rc = launch_update_control(k, k->d_prev_state, env->d_actions, env->d_labels);
@@ -289,7 +291,6 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
                              hipMemcpyDeviceToDevice, k->stream));
     HIPCHK(k, hipEventRecord(done, k->stream));
     HIPCHK(k, hipStreamWaitEvent(env->stream, done, 0));
-    HIPCHK(k, hipEventDestroy(done));
     HIPCHK(k, hipGetLastError());
     return RS_OK;
 }
