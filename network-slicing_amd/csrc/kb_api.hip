@@ -497,7 +497,7 @@ extern "C" int kb_shared_apply(kb_handle* k, const int32_t* counts, const double
     const size_t S = (size_t)k->cfg.n_slices;
     HIPCHK(k, hipMemcpyAsync(k->d_counts, counts, sizeof(int32_t) * S, hipMemcpyHostToDevice, k->stream));
     HIPCHK(k, hipMemcpyAsync(k->d_props, props, sizeof(double) * S * budget * KB_PROP_W, hipMemcpyHostToDevice, k->stream));
-    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3((unsigned)S), dim3(256), kb::kb_lds_bytes(k->cfg.capacity), k->stream, k->D, k->K, k->d_props,
+    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3((unsigned)S), dim3(1024), kb::kb_lds_bytes(k->cfg.capacity), k->stream, k->D, k->K, k->d_props,
                        k->d_counts, (int)budget, k->d_gstats);
     HIPCHK(k, hipGetLastError());
     return kb_check(k);

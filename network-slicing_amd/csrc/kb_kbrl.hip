@@ -80,14 +80,14 @@ struct Lds {
     double* ds;   // d* = Kinv k_f
     double* f;    // [KB_CAND_MAX]
     double* x;    // [KB_DMAX]
-    double* red;  // [8]
+    double* red;  // [16]
     int* ired;    // [8]
     int capr;     // column length (capacity rounded up to 16)
 };
 
 __host__ __device__ inline int kb_capr(int cap) { return (cap + 15) & ~15; }
 __host__ __device__ inline size_t kb_lds_bytes(int cap) {
-    return ((size_t)7 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 8) * sizeof(double) + 8 * sizeof(int);
+    return ((size_t)7 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 16) * sizeof(double) + 8 * sizeof(int);
 }
 
 __device__ __forceinline__ Lds carve_lds(int cap) {
@@ -104,7 +104,7 @@ __device__ __forceinline__ Lds carve_lds(int cap) {
     sm.ds = p; p += c;
     sm.f = p; p += KB_CAND_MAX;
     sm.x = p; p += KB_DMAX;
-    sm.red = p; p += 8;
+    sm.red = p; p += 16;
     sm.ired = (int*)p;
     sm.capr = c;
     return sm;
@@ -233,8 +233,11 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
             if (lane == 0) sm.ds[i] = a;
         }
         __syncthreads();
+        // 256 strided partial sums whatever the block size (the shared-dictionary kernel runs 1024 threads and must
+        // produce the bits of the 256-thread per-replica kernels); waves beyond the fourth add exact zeros
         double p = 0.0;
-        for (int j = threadIdx.x; j < m; j += blockDim.x) p += sm.ds[j] * sm.kf[j];
+        if (threadIdx.x < 256)
+            for (int j = threadIdx.x; j < m; j += 256) p += sm.ds[j] * sm.kf[j];
         dot = block_sum(p, sm);
     }
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
@@ -648,7 +651,7 @@ __global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_
 }
 
 // apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
-__global__ __launch_bounds__(256) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
+__global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                          int budget, uint64_t* gstats) {
     Lds sm = carve_lds(D.cap);
     const int s = blockIdx.x;
@@ -667,7 +670,8 @@ __global__ __launch_bounds__(256) void shared_apply_kernel(KbDev D, KbState K, c
         // Projectron.predict on (state, c/n): f = k . coeff (float32 while a single landmark is held)
         kernel_column(D, m, c, sm);
         double part = 0.0;
-        for (int j = threadIdx.x; j < m; j += blockDim.x) part += sm.kf[j] * sm.co[j];
+        if (threadIdx.x < 256)  // same 256 strided partial sums as the 256-thread kernels
+            for (int j = threadIdx.x; j < m; j += 256) part += sm.kf[j] * sm.co[j];
         double f = block_sum(part, sm);
         if (m == 1) f = (double)(float)((float)sm.kf[0] * (float)sm.co[0]);
         if (m == 0) f = 0.0;
@@ -835,8 +839,8 @@ __global__ void kb_reset_kernel(KbDev D, KbState K, const int32_t* init_action, 
                                 const uint64_t* seeds) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int T = D.n_envs * D.S;
-    if (i < T) {
-        K.m[i] = 0;
+    if (i < T) {  // per-learner state; the dictionaries (K.m: one per learner, or one per slice when shared) are
+                  // cleared by kb_reset with their own count
         K.f_last[i] = 0.0;
         K.tie_ctr[i] = 0;
         K.action[i] = init_action[i];

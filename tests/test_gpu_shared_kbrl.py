@@ -119,3 +119,17 @@ def test_dictionaries_do_not_depend_on_sharding():
     whole.close()
     for p in parts:
         p.close()
+
+
+def test_two_shared_agents_in_one_process_agree():
+    """two identical shared-dictionary loops side by side (two environments, two agents, one process): the same
+    observations, hits, dictionaries and actions at every step.  Guards the per-handle memory layout: a reset
+    that wrote one dictionary counter per learner into the per-slice array used to corrupt neighbouring
+    allocations, which showed up as run-to-run differences at 4096 replicas."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'shared_determinism_check.py'), '1536', '15'],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert 'no difference' in out.stdout
