@@ -11,6 +11,7 @@ struct kb_handle {
     kb::KbDev D;
     kb::KbState K;
     std::vector<void*> allocs;
+    std::vector<GuardedAlloc> guarded;
     float* d_state = nullptr;      // staging for host-provided states
     float* d_prev_state = nullptr; // resident loop: obs the executed action was chosen in
     int32_t* d_action = nullptr;
@@ -36,9 +37,9 @@ template <class Tp>
 static int kalloc(kb_handle* k, Tp** p, size_t n, bool zero = true) {
     void* q = nullptr;
     size_t bytes = sizeof(Tp) * (n ? n : 1);
-    HIPCHK(k, hipMalloc(&q, bytes));
+    HIPCHK(k, guarded_malloc(&q, bytes, &k->guarded));
     if (zero) HIPCHK(k, hipMemsetAsync(q, 0, bytes, k->stream));
-    k->allocs.push_back(q);
+    if (!guards_on()) k->allocs.push_back(q);
     *p = (Tp*)q;
     return RS_OK;
 }
@@ -128,6 +129,8 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
 extern "C" void kb_destroy(kb_handle* k) {
     if (!k) return;
     if (k->stream) (void)hipStreamSynchronize(k->stream);
+    if (guards_on()) check_guards(k->guarded, "kb");
+    for (auto& g : k->guarded) (void)hipFree(g.base);
     for (void* p : k->allocs) (void)hipFree(p);
     for (auto& e : k->ev) {
         (void)hipEventDestroy(e.first);

@@ -17,6 +17,44 @@
 
 using namespace rs;
 
+// ---- guard bands (RANSLICE_GUARD=1, developer knob): every handle-owned device buffer gets 64 KB of 0xA5 on both
+// sides; rs_destroy / kb_destroy read them back and abort with the buffer's index if a kernel wrote outside.
+struct GuardedAlloc {
+    void* base;
+    size_t bytes;
+};
+static const size_t kGuard = 64 * 1024;
+static bool guards_on() {
+    static const bool on = getenv("RANSLICE_GUARD") != nullptr;
+    return on;
+}
+static hipError_t guarded_malloc(void** q, size_t bytes, std::vector<GuardedAlloc>* reg) {
+    if (!guards_on()) return hipMalloc(q, bytes);
+    void* b = nullptr;
+    const size_t padded = (bytes + 255) / 256 * 256;
+    hipError_t e = hipMalloc(&b, padded + 2 * kGuard);
+    if (e != hipSuccess) return e;
+    e = hipMemset(b, 0xA5, padded + 2 * kGuard);
+    if (e != hipSuccess) return e;
+    reg->push_back({b, padded});
+    *q = (char*)b + kGuard;
+    return hipSuccess;
+}
+static void check_guards(const std::vector<GuardedAlloc>& reg, const char* who) {
+    std::vector<unsigned char> buf(kGuard);
+    for (size_t i = 0; i < reg.size(); ++i)
+        for (int side = 0; side < 2; ++side) {
+            const char* src = (const char*)reg[i].base + (side ? kGuard + reg[i].bytes : 0);
+            if (hipMemcpy(buf.data(), src, kGuard, hipMemcpyDeviceToHost) != hipSuccess) continue;
+            for (size_t k = 0; k < kGuard; ++k)
+                if (buf[k] != 0xA5) {
+                    fprintf(stderr, "RANSLICE_GUARD: %s buffer #%zu (%zu bytes): %s guard overwritten at offset %zu\n", who, i,
+                            reg[i].bytes, side ? "upper" : "lower", k);
+                    abort();
+                }
+        }
+}
+
 struct rs_handle {
     rs_config cfg;
     int device = 0;
@@ -27,6 +65,7 @@ struct rs_handle {
     RsState* d_st = nullptr;  // device copy of `st`
     MtcState mst;
     std::vector<void*> allocs;
+    std::vector<GuardedAlloc> guarded;
     double* fad = nullptr;
     uint8_t* fad_valid = nullptr;
     bool fad_loaded[RS_N_TRACES] = {false, false, false};
@@ -85,9 +124,9 @@ template <class T>
 static int dalloc(rs_handle* h, T** p, size_t n) {
     void* q = nullptr;
     size_t bytes = sizeof(T) * (n ? n : 1);
-    HIPCHK(h, hipMalloc(&q, bytes));
+    HIPCHK(h, guarded_malloc(&q, bytes, &h->guarded));
     HIPCHK(h, hipMemsetAsync(q, 0, bytes, h->stream));
-    h->allocs.push_back(q);
+    if (!guards_on()) h->allocs.push_back(q);
     *p = (T*)q;
     return RS_OK;
 }
@@ -431,6 +470,8 @@ extern "C" void rs_destroy(rs_handle* h) {
     if (!h) return;
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     drop_graph(h);
+    if (guards_on()) check_guards(h->guarded, "rs");
+    for (auto& g : h->guarded) (void)hipFree(g.base);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fad) (void)hipFree(h->fad);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
