@@ -38,6 +38,8 @@ static hipError_t guarded_malloc(void** q, size_t bytes, std::vector<GuardedAllo
     if (e != hipSuccess) return e;
     reg->push_back({b, padded});
     *q = (char*)b + kGuard;
+    if (const char* v = getenv("RANSLICE_GUARD"))
+        if (v[0] == '2') fprintf(stderr, "RANSLICE_GUARD: buffer #%zu at %p, %zu bytes\n", reg->size() - 1, *q, bytes);
     return hipSuccess;
 }
 static void check_guards(const std::vector<GuardedAlloc>& reg, const char* who) {
@@ -518,6 +520,8 @@ static int upload_fading(rs_handle* h) {
     // tail padding so that a subgroup's strided reads never leave the allocation
     HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
     HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
+    if (const char* v = getenv("RANSLICE_GUARD"))
+        if (v[0] == '2') fprintf(stderr, "RANSLICE_GUARD: fading table at %p, %zu bytes\n", (void*)h->fad, sizeof(double) * (elems + 16));
     for (int f = 0; f < RS_N_TRACES; ++f) {
         HIPCHK(h, hipMemcpyAsync(h->fad + d.fad_off[f], h->fad_host[f].data(), sizeof(double) * h->fad_host[f].size(),
                                  hipMemcpyHostToDevice, h->stream));
