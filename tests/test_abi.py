@@ -59,3 +59,18 @@ def test_product_has_no_oracle_dependency():
             if f.endswith(('.py', '.hip', '.h')):
                 src = open(os.path.join(dp, f)).read()
                 assert 'pyoracle' not in src and 'rs_oracle' not in src and 'kb_oracle' not in src, f
+
+
+def test_production_instances_keep_their_register_budget():
+    """the two 16-lane production instances of the step kernel must stay at 5 waves per SIMD and below 240 B of
+    spills per lane (tools/check_resources.py reads the remarks of the last build)"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    log = os.path.join(root, 'network-slicing_amd', 'csrc', 'build', 'resources.log')
+    if not os.path.exists(log):
+        import pytest
+        pytest.skip('no build log (library built without the Makefile)')
+    spec = importlib.util.spec_from_file_location('check_resources', os.path.join(root, 'tools', 'check_resources.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    assert mod.check(log) == []
