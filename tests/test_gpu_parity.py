@@ -188,6 +188,42 @@ def test_full_size_sampled():
     _compare(0, n_envs=4096, steps=12, fading=fading, churn=False, seed0=0, check_trace=False, sample=sample)
 
 
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_full_size_invariants(scenario):
+    """size-independent properties on every one of 4096 replicas at the bench's table size: the reward formula
+    (ran_slice.py:45-52), labels in {-1, +1} and consistent with the violation counts (slice_l1.py:160-171), the
+    observation being the float32 of info / normalisation constant (slice_ran.py:321-325), and a second handle with a different batch split giving the same
+    replicas the same trajectories."""
+    from ranslice.vec_env import VecRanSlice
+    fading = [synth_fading(t, 10000) for t in range(3)]
+    N = 4096
+    cfg = make_config(scenario, n_envs=N)
+    env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading, seed=123)
+    half = VecRanSlice(n_envs=N // 8, cfg=make_config(scenario, n_envs=N // 8), fading=fading, seed=123 + 1024)
+    env.reset()
+    half.reset()
+    rng = np.random.default_rng(8)
+    S = cfg.n_embb + cfg.n_mmtc
+    for i in range(30):
+        acts = _actions(rng, N, S, cfg.n_prbs, i)
+        obs, rew, done, info = env.step(acts)
+        o2, r2, _, i2 = half.step(acts[1024:1024 + N // 8])
+        viol, lab = info['violations'], info['SLA_labels']
+        tv = viol.sum(axis=1)
+        expect = np.where(tv > 0, -cfg.penalty * tv, np.maximum(0, cfg.n_prbs - acts.sum(axis=1)))
+        assert (rew == expect).all()
+        assert np.isin(lab, (-1, 1)).all() and ((lab == 1) == (viol == 0)).all()
+        assert not done.any()
+        l1 = env.l1_info()
+        # eMBB: obs[k] = f32(info[k] / norm[k]) for the ten accumulators of every slice
+        for s in range(cfg.n_embb):
+            want = (l1[:, s, :] / np.asarray(list(cfg.norm_embb))).astype(np.float32)
+            assert obs[:, s * 10:(s + 1) * 10].tobytes() == want.tobytes()
+        # same replicas (global ids 1024..1535) in a smaller batch: identical trajectories
+        assert o2.tobytes() == obs[1024:1024 + N // 8].tobytes()
+        assert (r2 == rew[1024:1024 + N // 8]).all()
+
+
 def test_determinism_and_independence(golden_dir):
     """same seeds -> identical results; a replica's trajectory does not depend on its batch"""
     from ranslice.vec_env import VecRanSlice
