@@ -81,7 +81,7 @@ namespace rs {
         (buf)[16 + task * 4 + 0] = tot_;                                                                \
         (buf)[16 + task * 4 + 1] = (unsigned long long)S.t_n_ue[task];                                  \
         (buf)[16 + task * 4 + 2] = (unsigned long long)A.actions[rep * n_slices + sl];                  \
-        (buf)[16 + task * 4 + 3] = (unsigned long long)pf_trips;                                        \
+        (buf)[16 + task * 4 + 3] = (unsigned long long)(stat >> 18);                                        \
     }
 #else
 #define SEC_DECL
@@ -485,8 +485,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     double infok = 0.0;
     double infok_hi = 0.0;  // G = 8 only: info[8], info[9] in lanes 0, 1
     // per-UE running sums (traffic, th(bits), prb) live in L_acc_*; flush() folds them into info[] by class
-    unsigned cnt_samples = 0u, cnt_pf = 0u, cnt_ue = 0u;  // per step: < 2^32
-    int pf_trips = 0;  // contested PF trips of this task in this step
+    // per-step statistics of the task in one register: UE-slots (bits 0-11, <= 50 x 32), scheduled slots (bits
+    // 12-17, <= 50), PF trips (bits 18-31, <= 50 x 128); the fading-sample and RB-pair counters follow from them
+    unsigned stat = 0u;
     // The heaviest waves of the launch (by cost rank) set its duration through their dependent chains, the others
     // through their instruction count: in a GRANT instance the former schedule with one trip per RB pair and
     // overlapped chains, the latter with the leader-run loop (fewer instructions per task).  Wave-uniform.  The
@@ -551,7 +552,6 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
         }
         return xb / slot_len;
     };
-    const unsigned pf_pairs = (unsigned)((double)(n_prb + gran - 1) / (double)gran);  // RB pairs per scheduled slot
 
     const int slots = D->slots;
     SEC_DECL
@@ -780,9 +780,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << LOG_LPU));
                 if (active && (gl >> LOG_NSUB) == rho) e_snr = got;
             }
-            cnt_samples += (unsigned)(n_ue * n_prb);
         }
-        cnt_ue += (unsigned)n_ue;
+        stat += (unsigned)n_ue;
 
         SEC_MARK(2)
         // ================= scheduling (slice_l1.py:215-224)
@@ -815,7 +814,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 for (;;) {
                     const bool more = sched && r < n_prb;
                     if (!wave_any(more)) break;
-                    if (more) pf_trips += 1;
+                    if (more) stat += 1u << 18;
 #ifdef RS_SECTION_PROFILE
                     sec_acc[15] += 1;
 #endif
@@ -898,7 +897,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 for (;;) {
                     const bool more = sched && r < n_prb;
                     if (!wave_any(more)) break;
-                    if (more) pf_trips += 1;
+                    if (more) stat += 1u << 18;
     #ifdef RS_SECTION_PROFILE
                     sec_acc[15] += 1;  // PF loop trips (not cycles)
     #endif
@@ -1103,7 +1102,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 ue_bits = bits;
                 ue_prbs = rbs;
             }
-            if (sched) cnt_pf += pf_pairs;
+            if (sched) stat += 1u << 12;
         }
 
         SEC_MARK(5)
@@ -1203,10 +1202,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             S.t_vbr_at[task] = vbr_at;
             S.t_ctr[task] = sl_ctr;
             S.t_serial[task] = next_serial;
-            S.t_cost[task] = pf_trips;
+            S.t_cost[task] = (int)(stat >> 18);
             uint64_t* c = A.counters + (size_t)task * 4;
-            c[0] += cnt_samples;
-            c[2] += cnt_pf;
+            const unsigned cnt_ue = stat & 0xfffu, n_sched = (stat >> 12) & 0x3fu;
+            c[0] += cnt_ue * (unsigned)n_prb;  // every UE reads n_prb fading samples per slot (n_prb is fixed for the step)
+            c[2] += n_sched * (unsigned)((n_prb + gran - 1) / gran);  // RB pairs per scheduled slot
             c[3] += cnt_ue;
             if (e_any != 0u) atomicOr(&S.err[rep], 1);
         }
