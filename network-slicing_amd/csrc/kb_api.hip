@@ -430,11 +430,13 @@ extern "C" int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches
     return RS_OK;
 }
 
+// Waits for the agent's stream and reports a dictionary overflow raised by any kernel since kb_reset -- the resident
+// loop (kb_step_resident) never reads the flag itself, so this is where a device-driven run learns about it.
 extern "C" int kb_synchronize(kb_handle* k) {
     if (!k) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));
-    return RS_OK;
+    return kb_check(k);
 }
 
 

@@ -1,0 +1,198 @@
+"""GPU parity at BASELINE size: the path bench.py times (device-generated action script + resident step, 4096
+replicas, 10,000-sample traces, default task order and kernel instance) against the CPU oracle, and the large
+checks that used to be developer scripts (soak, run-to-run determinism).  Bit-exact, no tolerance.
+"""
+import hashlib
+import os
+from concurrent.futures import ProcessPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from ranslice.config import make_config
+from ranslice.fading import synth_fading
+
+pytestmark = pytest.mark.gpu
+
+ACTION_SEED = 2024  # bench.py's script seed
+N_FULL = 4096
+COLS = 10000
+
+_FADING = {}
+
+
+def _fading(cols=COLS):
+    if cols not in _FADING:
+        _FADING[cols] = [synth_fading(t, cols) for t in range(3)]
+    return _FADING[cols]
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_random_actions_script_matches_oracle(scenario):
+    """rs_random_actions == rso_random_actions for every replica (bench.py's cpu_baseline claims the same script):
+    the multinomial over S slices + "unused", sum <= n_prbs."""
+    from ranslice.vec_env import VecRanSlice
+    cfg = make_config(scenario, n_envs=N_FULL)
+    env = VecRanSlice(n_envs=N_FULL, cfg=cfg, fading=_fading(512))
+    env.reset()
+    ocfg = make_config(scenario, n_envs=1)
+    for step in (0, 1, 2, 1000, 123456789, 2 ** 33 + 5):
+        env.random_actions(ACTION_SEED, step)
+        got = env.fetch()['actions']
+        assert (got >= 0).all() and (got.sum(axis=1) <= cfg.n_prbs).all()
+        for r in range(N_FULL):
+            want = po.random_actions(ocfg, ACTION_SEED, step, r)
+            assert (got[r] == want).all(), (step, r, got[r], want)
+    # a different seed gives a different script
+    env.random_actions(ACTION_SEED + 1, 0)
+    other = env.fetch()['actions']
+    env.random_actions(ACTION_SEED, 0)
+    assert (other != env.fetch()['actions']).any()
+    env.close()
+
+
+def _oracle_script_run(args):
+    """one oracle replica driven by the bench action script; returns per-step outputs"""
+    scenario, seed, replica, steps, cols = args
+    cfg = make_config(scenario, n_envs=1)
+    o = po.OracleEnv(cfg, [synth_fading(t, cols) for t in range(3)])
+    o.set_seed(seed)
+    o.reset()
+    out = []
+    for i in range(steps):
+        a = po.random_actions(cfg, ACTION_SEED, i, replica)
+        r = o.step(a)
+        out.append((a, r['obs'].copy(), r['reward'], r['labels'].copy(), r['violations'].copy(), r['info'].copy()))
+    return out
+
+
+SAMPLE = [0, 1, 2, 3, 4, 5, 6, 7, 8, 15, 16, 17, 63, 64, 65, 255, 256, 511, 512, 1000, 1023, 1024, 1500, 2047, 2048,
+          2049, 3000, 3071, 3072, 4000, 4094, 4095]
+
+
+def test_bench_path_steady_state_vs_oracle():
+    """The timed path of bench.py, oracle-checked: random_actions + step_resident on 4096 replicas of scenario_0 with
+    the 10,000-column traces, default order and instance, 500 device steps (25 s of simulated time: arrivals,
+    departures, VBR bursts, walker wraps, steady-state population); 32 sampled replicas are followed by oracle
+    replicas stepped by the same script and compared at EVERY step: actions, observations (f32 bits), rewards,
+    labels, violations and the ten info sums per slice (f64 bits)."""
+    from ranslice.vec_env import VecRanSlice
+    steps = 500
+    cfg = make_config(0, n_envs=N_FULL)
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        fut = ex.map(_oracle_script_run, [(0, r, r, steps, COLS) for r in SAMPLE], chunksize=1)
+        env = VecRanSlice(n_envs=N_FULL, cfg=cfg, fading=_fading())
+        env.reset()
+        hip = []
+        for i in range(steps):
+            env.random_actions(ACTION_SEED, i)
+            env.step_resident()
+            f = env.fetch()
+            l1 = env.l1_info()
+            hip.append((f['actions'][SAMPLE].copy(), f['obs'][SAMPLE].copy(), f['reward'][SAMPLE].copy(),
+                        f['labels'][SAMPLE].copy(), f['violations'][SAMPLE].copy(), l1[SAMPLE].copy()))
+        c = env.counters()
+        env.close()
+        ref = list(fut)
+    mean_ue = c[3] / (steps * cfg.slots_per_step * N_FULL * cfg.n_embb)
+    assert mean_ue > 1.5, 'population should have grown past the post-reset state (%.2f UEs/slice)' % mean_ue
+    for k, r in enumerate(SAMPLE):
+        for i in range(steps):
+            a, obs, rew, lab, viol, info = ref[k][i]
+            h = hip[i]
+            assert (h[0][k] == a).all(), ('actions', r, i)
+            assert h[1][k].tobytes() == obs.tobytes(), ('obs', r, i)
+            assert h[2][k] == rew, ('reward', r, i)
+            assert (h[3][k] == lab).all() and (h[4][k] == viol).all(), ('labels', r, i)
+            assert h[5][k].tobytes() == info.tobytes(), ('info', r, i)
+
+
+def _oracle_acts_run(args):
+    scenario, seed, acts, churn = args
+    cfg = make_config(scenario, n_envs=1)
+    if churn:
+        from test_gpu_parity import _churn
+        _churn(cfg)
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fading_small.npz'))
+    o = po.OracleEnv(cfg, [g['t0'], g['t1'], g['t2']])
+    o.set_seed(seed)
+    o.reset()
+    out = []
+    for a in acts:
+        r = o.step(a)
+        out.append((r['obs'].copy(), r['reward'], r['labels'].copy(), r['violations'].copy(), r['info'].copy()))
+    return out
+
+
+@pytest.mark.parametrize('scenario,n,steps', [(0, 1024, 40), (1, 512, 30)])
+def test_soak_every_replica(golden_dir, scenario, n, steps):
+    """(was tests/soak_check.py) production instance, high-churn traffic, NaN-column trace: EVERY replica of a
+    batch large enough for the 16-lane instance and the cost-ranked task order, bit for bit against the oracle"""
+    from ranslice.vec_env import VecRanSlice
+    from test_gpu_parity import _actions, _churn
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    cfg = _churn(make_config(scenario, n_envs=n))
+    seed0 = 9000 + scenario
+    rng = np.random.default_rng(seed0)
+    ns = cfg.n_embb + cfg.n_mmtc
+    acts = [_actions(rng, n, ns, cfg.n_prbs, i) for i in range(steps)]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        fut = ex.map(_oracle_acts_run, [(scenario, seed0 + r, [a[r] for a in acts], True) for r in range(n)],
+                     chunksize=8)
+        env = VecRanSlice(n_envs=n, cfg=cfg, fading=[g['t0'], g['t1'], g['t2']], seed=seed0)
+        env.set_group_size(16)
+        env.set_schedule_hint(0)
+        env.reset()
+        hip = []
+        for a in acts:
+            obs, rew, done, info = env.step(a)
+            hip.append((obs, rew, info['SLA_labels'], info['violations'], env.l1_info()))
+        env.close()
+        bad = []
+        for r, ref in enumerate(fut):
+            for i in range(steps):
+                o, w, lab, v, inf = ref[i]
+                h = hip[i]
+                if (h[0][r].tobytes() != o.tobytes() or h[1][r] != w or (h[2][r] != lab).any() or
+                        (h[3][r] != v).any() or h[4][r].tobytes() != inf.tobytes()):
+                    bad.append((r, i))
+                    break
+    assert not bad, 'mismatching (replica, first step): %s' % bad[:10]
+
+
+@pytest.mark.parametrize('scenario', [0, 2])
+def test_run_to_run_determinism_full_size(scenario):
+    """(was tests/determinism_check.py) the resident loop at 4096 replicas twice from the same seeds: identical
+    observations, rewards, labels, violations and info sums (a hash over 150 steps)."""
+    from ranslice.vec_env import VecRanSlice
+    hs = []
+    for rep in range(2):
+        env = VecRanSlice(n_envs=N_FULL, cfg=make_config(scenario, n_envs=N_FULL), fading=_fading())
+        env.reset()
+        h = hashlib.sha256()
+        for i in range(150):
+            env.random_actions(ACTION_SEED, i)
+            env.step_resident()
+            if i % 10 == 9:
+                f = env.fetch()
+                for k in ('obs', 'reward', 'labels', 'violations'):
+                    h.update(f[k].tobytes())
+                h.update(env.l1_info().tobytes())
+        hs.append(h.hexdigest())
+        env.close()
+    assert hs[0] == hs[1]
+
+
+def test_graph_replay_equals_stepwise_full_size():
+    """hipGraph replay of the scripted loop (BASELINE config 5's loop form) at 4096 replicas == step by step"""
+    from ranslice.vec_env import VecRanSlice
+    outs = []
+    for graph in (False, True):
+        env = VecRanSlice(n_envs=N_FULL, cfg=make_config(0, n_envs=N_FULL), fading=_fading())
+        env.reset()
+        env.run_random(ACTION_SEED, 0, 41, graph=graph)
+        f = env.fetch()
+        outs.append((f['obs'].tobytes(), f['reward'].tobytes(), f['violations'].tobytes(), env.l1_info().tobytes()))
+        env.close()
+    assert outs[0] == outs[1]

@@ -22,13 +22,14 @@ def _load(golden_dir, name):
 
 @pytest.mark.parametrize('tag,d', [('d11', 11), ('d4', 4)])
 def test_projectron_teacher_forced(golden_dir, tag, d):
-    """Projectron.predict/update through kb_predict/kb_update vs the reference's recorded sequence"""
+    """Projectron.predict/update through kb_predict/kb_update vs the reference's recorded sequence: ALL samples
+    (1,500 / 1,200), then the final dictionary: landmarks exact, coeff and Kinv within 1e-8 relative"""
     from ranslice.kbrl_dev import VecKBRL
     g = _load(golden_dir, 'g9_projectron')
     ag = VecKBRL(1, [d - 1], 200, capacity=1024)
     ag.reset([[10]], [[3]])
     xs, ys = g[tag + '_x'], g[tag + '_y']
-    n = min(len(xs), 700)
+    n = len(xs)
     for i in range(n):
         yp, f = ag.predict(0, 0, xs[i])
         fr = g[tag + '_f'][i]
@@ -42,7 +43,11 @@ def test_projectron_teacher_forced(golden_dir, tag, d):
         assert ag.learner(0, 0)['m'] == g[tag + '_m'][i]
     L = ag.learner(0, 0, with_kinv=True)
     m = L['m']
-    np.testing.assert_array_equal(L['landmarks'], np.atleast_2d(g[tag + '_landmarks'])[:m]) if n == len(xs) else None
+    assert m == len(np.atleast_2d(g[tag + '_landmarks']))
+    np.testing.assert_array_equal(L['landmarks'], np.atleast_2d(g[tag + '_landmarks']))
+    np.testing.assert_allclose(L['coeff'], g[tag + '_coeff'], rtol=1e-8, atol=1e-9)
+    kinv = g[tag + '_kinv']
+    np.testing.assert_allclose(L['kinv'], kinv, rtol=1e-8, atol=1e-8 * np.abs(kinv).max())
     ag.close()
 
 
@@ -206,3 +211,81 @@ def test_drop_in_experiment_plumbing(golden_dir):
     assert st.dtype == np.float32 and isinstance(r, float) and done is False
     assert set(info) == {'l1_info', 'SLA_labels', 'violations', 'n_prbs', 'total_violations'}
     assert set(info['l1_info'][0][0]) == set(sc.state_variables_embb)
+
+
+def _oracle_closed_loop(args):
+    """oracle env + oracle agent of one replica, closed loop (KBRL_Control.run body, kbrl_control.py:128-141)"""
+    scenario, env_seed, ag_seed, ia, sf, steps, cols, capacity = args
+    from ranslice.fading import synth_fading
+    dims, n_prbs = _dims(scenario)
+    e = po.OracleEnv(make_config(scenario), [synth_fading(t, cols) for t in range(3)])
+    e.set_seed(env_seed)
+    e.reset()
+    a = po.OracleKBRL(dims, n_prbs, ia, sf, capacity=capacity)
+    a.set_seed(ag_seed)
+    state = np.zeros(e.n_vars, dtype=np.float32)
+    action = np.asarray(ia, dtype=np.int32).copy()
+    out = []
+    for i in range(steps):
+        r = e.step(action)
+        hits = a.update_control(state, action, r['labels'])
+        na, adj = a.select_action(r['obs'])
+        a.adjusted = adj
+        out.append((action.copy(), r['obs'].copy(), r['labels'].copy(), np.asarray(hits).copy(), na.copy(), int(adj)))
+        state, action = r['obs'], na
+    return out, [a.m(s) for s in range(len(dims))]
+
+
+def test_full_size_closed_loop_vs_oracle():
+    """BASELINE config 3's loop at its size: 4096 replicas of scenario_0 with one KBRL agent each, closed on the
+    device (kb_step_resident: update_control + select_action write the next action into the simulator's buffer),
+    10,000-column traces; 24 sampled replicas against oracle env + oracle agent on the same streams: executed
+    actions, observations (bits), labels and the selected actions, every step; dictionary sizes at the end."""
+    import ctypes as C
+    from concurrent.futures import ProcessPoolExecutor
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps, cols, cap = 4096, 120, 10000, 256
+    scenario = 0
+    dims, n_prbs = _dims(scenario)
+    rng = np.random.default_rng(11)
+    ia = rng.integers(10, 35, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    sample = [0, 1, 2, 3, 15, 16, 63, 64, 100, 255, 256, 777, 1023, 1024, 2000, 2047, 2048, 3000, 3333, 4000, 4093,
+              4094, 4095, 1234]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+        fut = ex.map(_oracle_closed_loop, [(scenario, 300 + r, 7 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
+                     chunksize=1)
+        env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)],
+                          seed=300)
+        ag = VecKBRL(N, dims, n_prbs, capacity=cap)
+        ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 7)
+        env.reset()
+        a0 = np.ascontiguousarray(ia)
+        env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        hip = []
+        executed = ia.copy()
+        for i in range(steps):
+            f = env.fetch()     # results of the step that executed `executed`
+            ag.step_resident(env)
+            nxt = env.fetch()['actions']
+            hip.append((executed[sample].copy(), f['obs'][sample].copy(), f['labels'][sample].copy(), nxt[sample].copy()))
+            executed = nxt
+            if i + 1 < steps:
+                env.step_resident()
+        ag.synchronize()
+        sizes = [[ag.learner(r, s)['m'] for s in range(len(dims))] for r in sample]
+        env.close()
+        ag.close()
+        ref = list(fut)
+    for k, r in enumerate(sample):
+        steps_ref, m_ref = ref[k]
+        for i in range(steps):
+            act, obs, lab, hits, na, adj = steps_ref[i]
+            h = hip[i]
+            assert (h[0][k] == act).all(), ('executed action', r, i)
+            assert h[1][k].tobytes() == obs.tobytes(), ('obs', r, i)
+            assert (h[2][k] == lab).all(), ('labels', r, i)
+            assert (h[3][k] == na).all(), ('selected action', r, i, h[3][k], na)
+        assert sizes[k] == m_ref, (r, sizes[k], m_ref)

@@ -133,3 +133,49 @@ def test_two_shared_agents_in_one_process_agree():
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert 'no difference' in out.stdout
+
+
+def test_shared_loop_run_to_run_determinism():
+    """(was tests/shared_determinism_check.py) two identical shared-dictionary closed loops at 2048 replicas of
+    scenario_2 (BASELINE config 4's per-GPU workload shape): observations, hits, dictionary sizes, coefficients
+    and actions identical at every step.  Caught the kb_reset overrun of round 1 (commit 9726634)."""
+    from ranslice.config import EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import SharedVecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps = 2048, 25
+    cfg = make_config(2, n_envs=N)
+    fading = [synth_fading(t, 10000) for t in range(3)]
+    dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
+
+    def make():
+        env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading)
+        agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=256)
+        rng = np.random.default_rng(1000)
+        ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
+                             rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+        sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)),
+                             rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+        state = env.reset()
+        agent.reset(ia, sf)
+        return dict(env=env, agent=agent, state=state, action=ia.copy())
+    A, B = make(), make()
+    for i in range(steps):
+        res = []
+        for R in (A, B):
+            obs, rew, _, info = R['env'].step(R['action'])
+            hits = R['agent'].update_control(R['state'], R['action'], info['SLA_labels'])
+            learners = [R['agent'].learner(0, s) for s in range(len(dims))]
+            action, adj = R['agent'].select_action(obs)
+            R['state'], R['action'] = obs, action
+            res.append((obs, hits, [l['m'] for l in learners], [l['coeff'].tobytes() for l in learners], action))
+        a, b = res
+        assert a[0].tobytes() == b[0].tobytes(), ('obs', i)
+        assert (a[1] == b[1]).all(), ('hits', i)
+        assert a[2] == b[2], ('sizes', i, a[2], b[2])
+        assert a[3] == b[3], ('coeff', i)
+        assert (a[4] == b[4]).all(), ('action', i)
+    assert max(a[2]) > 1, 'the loop should have learned something'
+    for R in (A, B):
+        R['env'].close()
+        R['agent'].close()

@@ -162,7 +162,6 @@ def test_g7_full_step(path, golden_dir):
                 # the reference attribute is sticky, so compare where an allocation happened
                 hit = r['p'] != 0
                 np.testing.assert_allclose(r['p'][hit], gf[hit, 2], rtol=PROB_RTOL, atol=0)
-                assert (gi[~hit, 2] == 0).all() or True
                 # G5: arrivals = serials first seen in this slot, departures = serials gone since the last slot
                 now = {int(x['serial']): int(x['type']) for x in r}
                 gslot = i * cfg.slots_per_step + t
