@@ -7,7 +7,11 @@
  *     key     = 64-bit replica seed
  *     counter = (draw index, 0, UE serial within the slice [0 = the slice itself], slice id)
  * so that every (replica, slice, UE) draws independently of all others and a wavefront
- * can advance many UEs at once.  The distribution of every draw equals the reference's
+ * can advance many UEs at once.  The fading walker's redraws (channel_models.py:179-183) are
+ * addressed by TIME instead of by draw index,
+ *     counter = (absolute slot, 1 + attempt within the slot, UE serial, slice id),
+ * so that a UE's fading trajectory -- hence every channel estimate of a step -- is a function of
+ * its arrival state alone and can be evaluated ahead of the scheduling loop (rs_walker_redraw).  The distribution of every draw equals the reference's
  * (uniform, exponential, uniform integer, +-1, normal); the bit patterns do not, which is
  * why parity is argued in two hops: reference == oracle on a recorded tape,
  * oracle == HIP on these streams.
@@ -56,7 +60,7 @@ RS_HD double rs_stream_uniform(rs_stream* s) {
 /* exponential with the given scale (mean): -log(1-u)*scale, u in [0,1) */
 RS_HD double rs_stream_exponential(rs_stream* s, double scale) {
     double u = rs_stream_uniform(s);
-    return (-rs_log(1.0 - u)) * scale;
+    return (-RS_LOG_CALL(1.0 - u)) * scale;
 }
 
 /* uniform integer in [0,n) */
@@ -69,6 +73,16 @@ RS_HD int64_t rs_stream_integers(rs_stream* s, int64_t n) {
 /* -1 or +1 with probability 1/2 */
 RS_HD int rs_stream_pm1(rs_stream* s) { return rs_stream_uniform(s) < 0.5 ? -1 : 1; }
 
+/* SINRSelectiveFading.get_snr leaving [0, T) (channel_models.py:179-183): new index uniform in [0, T) and a new
+ * direction, both from ONE Philox block addressed by (absolute slot, attempt) -- stateless, see the header. */
+RS_HD void rs_walker_redraw(uint32_t key0, uint32_t key1, uint32_t slice, uint32_t serial, uint32_t now,
+                            uint32_t attempt, int T, int* findex, int* fstep) {
+    uint32_t a, b;
+    rs_philox4x32_10(now, 1u + attempt, serial, slice, key0, key1, &a, &b);
+    *findex = (int)(((uint64_t)a * (uint64_t)(uint32_t)T) >> 32);
+    *fstep = (b >> 31) ? 1 : -1;
+}
+
 /* normal(loc, scale): Marsaglia polar method (log, sqrt, / only -> deterministic) */
 RS_HD double rs_stream_normal(rs_stream* s, double loc, double scale) {
     double v1, v2, r2;
@@ -77,7 +91,7 @@ RS_HD double rs_stream_normal(rs_stream* s, double loc, double scale) {
         v2 = 2.0 * rs_stream_uniform(s) - 1.0;
         r2 = v1 * v1 + v2 * v2;
     } while (r2 >= 1.0 || r2 == 0.0);
-    double z = v1 * RS_SQRT((-2.0 * rs_log(r2)) / r2);
+    double z = v1 * RS_SQRT((-2.0 * RS_LOG_CALL(r2)) / r2);
     return loc + scale * z;
 }
 

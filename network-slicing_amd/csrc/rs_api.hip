@@ -397,6 +397,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         // compared with the true divide here, and the kernel uses the short form only if all of them agree.
         int max_rate = 0;
         for (int i = 0; i < d.lut_n; ++i) max_rate = d.lut_rate[i] > max_rate ? d.lut_rate[i] : max_rate;
+        if (max_rate >= 65536) {
+            h->err = "rs_create: bits per PRB do not fit the packed MCS lookup";
+            return RS_EINVAL;
+        }
         const double dl = cfg->slot_length, rc = 1.0 / dl;
         bool same = std::isfinite(rc) && dl > 0.0;
         const long long top = (long long)cfg->n_prbs * max_rate;
@@ -411,8 +415,15 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     }
     for (int m = 0; m < cfg->n_mcs; ++m) {
         d.mcs_ref[m] = cfg->mcs_snr[m];
-        d.mcs_x0[m] = cfg->mi_x0[cfg->mcs_mod[m]];
-        d.mcs_k[m] = cfg->mi_k[cfg->mcs_mod[m]];
+        if (cfg->mcs_mod[m] < 0 || cfg->mcs_mod[m] > 2) {
+            h->err = "rs_create: modulation index out of range";
+            return RS_EINVAL;
+        }
+        d.mcs_mod[m] = cfg->mcs_mod[m];
+    }
+    for (int m = 0; m < 3; ++m) {
+        d.mi_x0[m] = cfg->mi_x0[m];
+        d.mi_k[m] = cfg->mi_k[m];
     }
     d.mtc_n_dev = cfg->mtc_n_devices;
     d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
@@ -456,6 +467,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
     // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
     h->group = h->n_tasks <= 6144 ? 32 : 16;
+    if (const char* e = getenv("RANSLICE_GROUP")) {  // developer knob (tools/group_sweep.py)
+        const int g = atoi(e);
+        if (g == 8 || g == 16 || g == 32) h->group = g;
+    }
     h->grant_mode = h->n_tasks <= 6144 ? 1 : 0;  // latency-bound batches: the shorter PF chain wins
     if (const char* e = getenv("RANSLICE_GRANT_DIV")) h->grant_div = atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
     DA(h->d_st, 1);
@@ -634,7 +649,6 @@ static int launch_step(rs_handle* h) {
         a.mi_wide = h->d_mi_wide;
         a.replay = 0;
         a.order = nullptr;
-        a.grant_div = h->grant_div;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -651,20 +665,15 @@ static int launch_step(rs_handle* h) {
             const int per_block = 256 / g;
             dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
-            const bool gr = h->grant_mode && !a.replay;
             if (g == 8) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true, false>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<8, false, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<8, false>), grid, block, 0, h->stream, a);
             } else if (g == 16) {
-                if (tr && gr) hipLaunchKernelGGL((embb_step_kernel<16, true, true>), grid, block, 0, h->stream, a);
-                else if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, false>), grid, block, 0, h->stream, a);
-                else if (gr) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<16, false>), grid, block, 0, h->stream, a);
             } else {
-                if (tr && gr) hipLaunchKernelGGL((embb_step_kernel<32, true, true>), grid, block, 0, h->stream, a);
-                else if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, false>), grid, block, 0, h->stream, a);
-                else if (gr) hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<32, false, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<32, false>), grid, block, 0, h->stream, a);
             }
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
@@ -882,7 +891,7 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
     return RS_OK;
 }
 
-// Lanes per task of the primary eMBB launch (8, 16 or 32).  Results do not depend on it.
+// Lanes per task of the primary eMBB launch (16 or 32).  Results do not depend on it.
 // mode 1: allocations come from a learning agent, which concentrates the carrier on few slices (long contested PF
 // loops in a few tasks): the step uses the instance whose heaviest waves schedule one RB pair per trip.  mode 0:
 // the plain instance.  mode < 0: automatic (by batch size; kb_step_resident switches it on for the environment it

@@ -1,7 +1,7 @@
 // rs_device.h -- device-side data layout of the batched RAN-slice simulator (gfx950).
 //
-// One "task" is one eMBB slice of one env replica.  A task is advanced by a 32-lane half
-// wavefront: lane u of the group owns UE u of the slice (UE list order = arrival order,
+// One "task" is one eMBB slice of one env replica.  A task is advanced by a group of 16 or 32
+// lanes: lane u of the group owns UE u of the slice (UE list order = arrival order,
 // reference slice_l1.py:183-191), so every per-UE quantity lives in a register and the
 // per-slot reductions the reference does with Python loops (argmax of the PF metric,
 // RB prefix sums, per-class sums) are cross-lane operations.  Persistent state is kept in HBM
@@ -39,7 +39,9 @@ struct RsDev {
     int32_t gran;           // PF granularity
     int32_t lut_lo, lut_n;  // e_snr -> (mcs, rate) lookup, clamped outside [lut_lo, lut_lo+lut_n)
     int32_t lut_mcs[RS_LUT_MAX], lut_rate[RS_LUT_MAX];
-    double mcs_ref[32], mcs_x0[32], mcs_k[32];
+    double mcs_ref[32];
+    int32_t mcs_mod[32];    // modulation of each MCS (0 qpsk, 1 16qam, 2 64qam)
+    double mi_x0[3], mi_k[3];  // mutual-information sigmoid per modulation (channel_models.py:268-270)
     double penalty;
     // mMTC
     int32_t mtc_n_dev, mtc_cap, mtc_n_rep, mtc_n_period;

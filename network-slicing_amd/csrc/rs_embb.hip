@@ -10,18 +10,25 @@
 //   SINRSelectiveFading / MCSCodeset / macro_cell   channel_models.py
 //   CbrSource / VbrSource      traffic_generators.py
 //
-// Mapping to the machine: a G-lane group (G = 8, 16 or 32; 64/G tasks per wavefront) owns one
-// (replica, slice) task for the whole step, lane u = UE u; state sits in VGPRs for all 50 slots and
-// touches HBM once in, once out.  The path is bound by the latency of dependent f64 chains (divide
-// ~125, exp ~550, log ~900 cycles; tools/ubench), so throughput scales with tasks per wave: the
-// primary launch uses G = 8 and a task that needs more than 8 UE lanes (about 1 % of task-steps at
-// the reference's load) leaves its state untouched, raises a redo flag and is replayed by the G = 32
-// instance of the same kernel -- identical arithmetic, so results do not depend on G.
-// The only HBM traffic inside the loop is the fading table: a UE's per-slot column
-// [time][PRB] is contiguous, and is summed by an 8-lane subgroup in numpy's pairwise order
-// (8 strided accumulators == 8 lanes), four UEs per group at a time.  The PF loop is the
-// serial part: one argmax per RB pair, done as a cross-lane f64 max + ballot; it exits in
-// closed form once every queue is drained (reference quirk Q4 gives the rest to UE 0).
+// Mapping to the machine: a G-lane group (G = 16 or 32; 64/G tasks per wavefront) owns one (replica, slice)
+// task for the whole step, lane u = UE u; hot per-UE state sits in VGPRs for all 50 slots, cold state (timers,
+// stream counters, accumulators) in LDS, HBM is touched once in and once out.  A task that needs more UE lanes
+// than the instance has leaves its state untouched, raises a redo flag and is replayed by the G = 32 instance of
+// the same kernel -- identical arithmetic, so results do not depend on G.
+//
+// Two kinds of work alternate inside a step:
+//   * CHANNEL ESTIMATES (get_snr + estimate_snr).  A UE's fading trajectory depends on nothing the scheduler
+//     does (the walker's redraws are addressed by time, include/rs_philox.h), so round(mean(column)) of every
+//     (UE, slot) of the next CH slots is evaluated AHEAD of the slot loop: every lane of the wave takes one
+//     (UE, slot) item and sums its column alone, in numpy's pairwise order (8 strided accumulators held by the
+//     lane), the items of the wave's 64/G tasks being dealt out to all 64 lanes.  Results go to an int16 table in
+//     LDS.  This is the only part with real HBM/L2 traffic, and here it runs with every lane busy and every load
+//     independent of the scheduling chain.
+//   * THE SLOT LOOP (traffic, PF, response, reception, SLA sums): serial from slot to slot through queue and
+//     throughput average.  PF is closed-form when the slot is under-loaded (order of service cannot matter, see
+//     below), otherwise the leader of the metric runs the reference loop alone until it loses the argmax.  The
+//     reception model (MI average -> effective SNR -> probability) is evaluated only for UEs that actually sent
+//     bits: for the others the Bernoulli draw is consumed (the stream counter advances) but cannot change state.
 // Compiled with -ffp-contract=off: all f64 arithmetic is IEEE and in the oracle's order.
 
 #include <hip/hip_runtime.h>
@@ -51,6 +58,9 @@ namespace rs {
 #define RS_PRIO_A 10u
 #define RS_PRIO_B 4u
 #define RS_PRIO_C 2u
+#endif
+#ifndef RS_OCC
+#define RS_OCC 5
 #endif
 #ifndef RS_LPU
 #define RS_LPU 4
@@ -194,6 +204,20 @@ __device__ __forceinline__ double group_max(double v) {
     return v;
 }
 
+// maximum of finite floats over the G lanes of a group (DPP moves fold into the v_max_f32)
+template <int G>
+__device__ __forceinline__ float group_max_f32(float v) {
+    v = __builtin_fmaxf(v, __builtin_bit_cast(float, dpp_i<DPP_XOR1>(__builtin_bit_cast(int, v))));
+    v = __builtin_fmaxf(v, __builtin_bit_cast(float, dpp_i<DPP_XOR2>(__builtin_bit_cast(int, v))));
+    v = __builtin_fmaxf(v, __builtin_bit_cast(float, dpp_i<DPP_HMIRROR>(__builtin_bit_cast(int, v))));
+    if (G >= 16) v = __builtin_fmaxf(v, __builtin_bit_cast(float, dpp_i<DPP_MIRROR>(__builtin_bit_cast(int, v))));
+    if (G == 32) {
+        auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v), __builtin_bit_cast(unsigned, v), false, false);
+        v = __builtin_fmaxf(__builtin_bit_cast(float, r[0]), __builtin_bit_cast(float, r[1]));
+    }
+    return v;
+}
+
 // exclusive prefix sum over the G lanes of a group: Hillis-Steele with row_shr (sources outside the
 // group masked by lane index), plus row_bcast:15 to carry row 0's total into row 1 when G = 32
 template <int G>
@@ -213,86 +237,134 @@ __device__ __forceinline__ int kth_set_bit(unsigned m, int k) {
     return m ? __ffs((int)m) - 1 : 0;
 }
 
-// numpy pairwise sum of f(0..n-1) evaluated cooperatively by the LPU lanes of a subgroup (LPU = 8, 4 or 2).
-// numpy's unrolled loop keeps 8 strided accumulators R_0..R_7; lane j of the subgroup owns R_(a*LPU + j),
-// a = 0..8/LPU-1, so a narrower subgroup carries more (independent) chains per lane and a group holds more
-// UEs per pass.  Every lane of the subgroup must call it with the same n.  The result is valid in lane 0 of
-// the subgroup (the tree part in all of its lanes; the sequential remainder is folded towards lane 0 with
-// row_shl:1).  n <= 128 per block.
-template <int LPU, class F>
-__device__ __forceinline__ double subl_block(int off, int n, int j, F f) {
-    constexpr int ACC = 8 / LPU;
+// numpy's pairwise sum (np.sum / np.mean of a contiguous f64 vector, n <= 256) splits a vector longer than 128 in
+// halves rounded down to a multiple of 8, recursively, and sums a block of <= 128 elements with 8 strided
+// accumulators R_0..R_7, the tree ((R0+R1)+(R2+R3))+((R4+R5)+(R6+R7)) and a sequential remainder.
+// Two evaluators of the same order follow: one lane alone (channel estimates), and the LPU = 4 lanes of a subgroup
+// together (MI averages of the response).
+struct PwSplit {
+    int n0, n1, n2;  // block lengths (n1, n2 may be 0): result = B(0, n0) + (B(n0, n1) + B(n0 + n1, n2))
+    __device__ __forceinline__ explicit PwSplit(int n) {
+        n0 = n;
+        n1 = 0;
+        n2 = 0;
+        if (n > 128) {  // pw(n) = pw(h) + pw(n - h), h = n/2 - (n/2) % 8  (<= 128 for n <= 256)
+            int h = n >> 1;
+            h -= h & 7;
+            n0 = h;
+            n1 = n - h;
+            if (n1 > 128) {  // 129..135: split once more
+                int h2 = n1 >> 1;
+                h2 -= h2 & 7;
+                n2 = n1 - h2;
+                n1 = h2;
+            }
+        }
+    }
+};
+
+// one block by ONE lane: ld(i) = element i; `on` masks lanes without work (loops are wave-uniform)
+template <class F>
+__device__ __forceinline__ double lane_block(int off, int n, bool on, F ld) {
+    const int lim = n >= 8 ? n - (n & 7) : 0;
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = 0.0;
+    if (on && n >= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = ld(off + j);
+    }
+    for (int i = 8; wave_any(on && i < lim); i += 8) {
+        if (on && i < lim) {
+#pragma unroll
+            for (int h = 0; h < 8; h += 4) {  // four loads in flight at a time (register budget)
+                double v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ld(off + i + h + j);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[h + j] += v[j];
+            }
+        }
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));  // n < 8: 0.0, as numpy starts
+    const int rem = n - lim;
+    if (wave_any(on && rem > 0)) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (on && j < rem) res += ld(off + lim + j);
+    }
+    return res;
+}
+
+template <class F>
+__device__ __forceinline__ double lane_pairwise(int n, bool on, F ld) {
+    const PwSplit s(n);
+    double a = lane_block(0, s.n0, on, ld);
+    if (wave_any(on && s.n1 > 0)) {
+        double b = lane_block(s.n0, s.n1, on && s.n1 > 0, ld);
+        if (wave_any(on && s.n2 > 0)) {
+            const double c = lane_block(s.n0 + s.n1, s.n2, on && s.n2 > 0, ld);
+            b = s.n2 > 0 ? b + c : b;
+        }
+        a = s.n1 > 0 ? a + b : a;
+    }
+    return a;
+}
+
+// one block by the 8 lanes of a TEAM: lane j owns R_j.  Every lane of the team must call it with the same (off, n).
+// f(i) may be expensive (the response evaluates a sigmoid per element), so every lane walks its own accumulator
+// serially and the team meets only for the tree and the remainder.  Loops are wave-uniform (`on` masks idle teams).
+// The result is valid in lane 0 of the team.
+template <class F>
+__device__ __forceinline__ double team_block(int off, int n, int j, bool on, F f) {
     double res = 0.0;
     const int lim = n >= 8 ? n - (n & 7) : 0;
     const int rem = n - lim;
-    // the sequential remainder's operands are independent of the tree: fetch them first
-    double v[ACC];
-#pragma unroll
-    for (int a = 0; a < ACC; ++a) v[a] = a * LPU + j < rem ? f(off + lim + a * LPU + j) : 0.0;
-    if (n >= 8) {
-        double r[ACC];
-#pragma unroll
-        for (int a = 0; a < ACC; ++a) r[a] = f(off + a * LPU + j);
-        if (LPU == 8) {
-            for (int i = 8; i < lim; i += 16) {  // two independent fetches in flight, adds in numpy's order
-                const bool p1 = i + 8 < lim;
-                double a0 = f(off + i + j);
-                double a1 = p1 ? f(off + i + 8 + j) : 0.0;
-                r[0] += a0;
-                if (p1) r[0] += a1;
-            }
-        } else {
-            for (int i = 8; i < lim; i += 8) {
-                double t[ACC];
-#pragma unroll
-                for (int a = 0; a < ACC; ++a) t[a] = f(off + i + a * LPU + j);
-#pragma unroll
-                for (int a = 0; a < ACC; ++a) r[a] += t[a];
-            }
-        }
+    // the sequential remainder's operands are independent of the tree: evaluate them first
+    double v = (on && j < rem) ? f(off + lim + j) : 0.0;
+    if (wave_any(on && n >= 8)) {
+        double r = (on && n >= 8) ? f(off + j) : 0.0;
+        for (int i = 8; wave_any(on && i < lim); i += 8)
+            if (on && i < lim) r += f(off + i + j);
         // ((R0+R1)+(R2+R3))+((R4+R5)+(R6+R7)): each pairing is commutative, so both partners agree
-        if (LPU == 8) {
-            r[0] += dpp_d<DPP_XOR1>(r[0]);
-            r[0] += dpp_d<DPP_XOR2>(r[0]);
-            r[0] += dpp_d<DPP_HMIRROR>(r[0]);
-            res = r[0];
-        } else if (LPU == 4) {
-            r[0] += dpp_d<DPP_XOR1>(r[0]);
-            r[ACC - 1] += dpp_d<DPP_XOR1>(r[ACC - 1]);
-            r[0] += dpp_d<DPP_XOR2>(r[0]);
-            r[ACC - 1] += dpp_d<DPP_XOR2>(r[ACC - 1]);
-            res = r[0] + r[ACC - 1];
-        } else {
-#pragma unroll
-            for (int a = 0; a < ACC; ++a) r[a] += dpp_d<DPP_XOR1>(r[a]);
-            res = (r[0] + r[1 % ACC]) + (r[2 % ACC] + r[3 % ACC]);
-        }
+        r += dpp_d<DPP_XOR1>(r);
+        r += dpp_d<DPP_XOR2>(r);
+        r += dpp_d<DPP_HMIRROR>(r);
+        res = n >= 8 ? r : 0.0;
     }
+    if (wave_any(on && rem > 0)) {
 #pragma unroll
-    for (int a = 0; a < ACC; ++a) {
-#pragma unroll
-        for (int s_ = 0; s_ < LPU; ++s_) {
-            if (a * LPU + s_ < rem) {
-                res += v[a];                 // lane 0: element a * LPU + s_ of the remainder
-                v[a] = dpp_d<0x101>(v[a]);   // row_shl:1: lane i <- lane i+1
-            }
+        for (int s_ = 0; s_ < 7; ++s_) {
+            if (s_ < rem) res += v;    // lane 0: element s_ of the remainder
+            v = dpp_d<0x101>(v);       // row_shl:1: lane i <- lane i+1 (lane 7 of a team may pull its neighbour's
+                                       // value: it never reaches lane 0 within the 7 shifts that are consumed)
         }
     }
     return res;
 }
 
-template <int LPU, class F>
-__device__ __forceinline__ double subl_pairwise(int n, int j, F f) {
-    if (n <= 128) return subl_block<LPU>(0, n, j, f);
-    int n2 = n >> 1;
-    n2 -= n2 & 7;
-    double a = subl_block<LPU>(0, n2, j, f);
-    double b = subl_block<LPU>(n2, n - n2, j, f);
-    return a + b;
+template <class F>
+__device__ __forceinline__ double team_pairwise(int n, int j, bool on, F f) {
+    const PwSplit s(n);
+    double a = team_block(0, s.n0, j, on, f);
+    if (wave_any(on && s.n1 > 0)) {
+        double b = team_block(s.n0, s.n1, j, on && s.n1 > 0, f);
+        if (wave_any(on && s.n2 > 0)) {
+            const double c = team_block(s.n0 + s.n1, s.n2, j, on && s.n2 > 0, f);
+            b = s.n2 > 0 ? b + c : b;
+        }
+        a = s.n1 > 0 ? a + b : a;
+    }
+    return a;
 }
 
-// macro_cell (channel_models.py:84-97) on the UE's own stream
-__device__ __noinline__ double macro_cell_draw(const RsDev* D, rs_stream* st) {
+// macro_cell (channel_models.py:84-97) on the UE's own stream.  The stream travels by value and the advanced draw
+// counter comes back beside the result: a pointer argument would put the caller's stream on the stack (scratch).
+// (a vector type, so that it is returned in registers: x = nominal SINR, y = the stream's draw counter afterwards)
+typedef double MacroCell __attribute__((ext_vector_type(2)));
+__device__ __noinline__ MacroCell macro_cell_draw(const RsDev* D, rs_stream st_in) {
+    rs_stream stv = st_in;
+    rs_stream* st = &stv;
     double x, y;
     for (;;) {
         x = rs_stream_uniform(st);
@@ -305,7 +377,19 @@ __device__ __noinline__ double macro_cell_draw(const RsDev* D, rs_stream* st) {
         m = (0.5 - 1.0) / (1.0 - 0.75); b = -m * 0.75 + 1.0;  bool c4 = y < m * x + b;
         if (c1 && c2 && c3 && c4) break;
     }
-    double LogF = rs_stream_normal(st, 0.0, 10.0);
+    // rs_stream_normal(st, 0.0, 10.0) spelled out with the in-line logarithm: this function must stay a leaf (a nested
+    // call would make it save its return address through a stack slot, i.e. scratch)
+    double LogF;
+    {
+        double v1, v2, r2;
+        do {
+            v1 = 2.0 * rs_stream_uniform(st) - 1.0;
+            v2 = 2.0 * rs_stream_uniform(st) - 1.0;
+            r2 = v1 * v1 + v2 * v2;
+        } while (r2 >= 1.0 || r2 == 0.0);
+        const double z = v1 * RS_SQRT((-2.0 * rs_log(r2)) / r2);
+        LogF = 0.0 + 10.0 * z;
+    }
     double x_t = x - 0.5 / 2;
     double distance = RS_SQRT(x_t * x_t + y * y);
     double cos_theta = x_t / distance;
@@ -322,7 +406,10 @@ __device__ __noinline__ double macro_cell_draw(const RsDev* D, rs_stream* st) {
     L = L > FSPL ? L : FSPL;
     double loss = L + LogF - G;
     double Rx_pw = 30 - (loss > 70 ? loss : 70);
-    return Rx_pw - (-110) - 9;
+    MacroCell out;
+    out.x = Rx_pw - (-110) - 9;
+    out.y = (double)stv.ctr;
+    return out;
 }
 
 __device__ __forceinline__ int rint_slots(double seconds_or_slots, double slot_length) {
@@ -349,39 +436,36 @@ struct StepArgs {
     int32_t replay;           // 1: process only tasks whose redo flag is set
     double* mi_wide;          // [n_tasks][RS_MAX_PRBS] scratch rows for slices wider than the LDS slice
     const int32_t* order;     // [n_tasks] launch order of the tasks (rs_order.hip) or null = task index order
-    uint32_t grant_div;       // GRANT instances: the heaviest 1/grant_div of the waves take the one-trip-per-pair loop
 };
 
-// where R1 parks the per-RB mutual information for R2
-struct MiLds {
-    double* p;
-    __device__ __forceinline__ void st(int i, double v) const { p[i] = v; }
-    __device__ __forceinline__ double ld(int i) const { return p[i]; }
-    __device__ __forceinline__ void sync() const {}  // LDS operations of one wave complete in order
-};
-struct MiHbm {
-    double* p;
-    __device__ __forceinline__ void st(int i, double v) const { p[i] = v; }
-    __device__ __forceinline__ double ld(int i) const {  // L1-bypassing: the row is rewritten every slot
-        return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// select among three wave-uniform values by a per-lane index 0..2
+template <class T>
+__device__ __forceinline__ T sel3(int i, T a, T b, T c) {
+    return i == 0 ? a : (i == 1 ? b : c);
+}
+
+// SINRSelectiveFading.get_snr's index walk (channel_models.py:171-191): one step, redraw on leaving [0, T)
+// (time-addressed, include/rs_philox.h), skipping columns that contain NaN (Q10)
+__device__ __forceinline__ void walker_advance(int& findex, int& fstep, int Tn, bool has_nan, const uint8_t* valid_col,
+                                               uint32_t key0, uint32_t key1, uint32_t sl, uint32_t serial, uint32_t now) {
+    unsigned attempt = 0u;
+    for (;;) {
+        findex += fstep;
+        if (findex >= Tn || findex < 0) rs_walker_redraw(key0, key1, sl, serial, now, attempt++, Tn, &findex, &fstep);
+        if (!has_nan || valid_col[findex]) break;
     }
-    __device__ __forceinline__ void sync() const { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-};
+}
 
 // 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
-// instances are test tooling: they keep the register budget of 3 waves per SIMD, which needs no spills.
-template <int G, bool TRACE, bool GRANT>
-__global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_kernel(StepArgs A) {
-    constexpr int LPU = RS_LPU;                      // lanes that share one UE's pairwise sums
-    constexpr int LOG_LPU = LPU == 8 ? 3 : (LPU == 4 ? 2 : 1);
-    constexpr int NSUB = G / LPU;                    // subgroups (UEs per pass) in a group
-    constexpr int LOG_NSUB = (G == 32 ? 5 : (G == 16 ? 4 : 3)) - LOG_LPU;
+// instances are test tooling: they keep the register budget of 3 waves per SIMD.
+template <int G, bool TRACE>
+__global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_step_kernel(StepArgs A) {
+    static_assert(G == 8 || G == 16 || G == 32, "lanes per task");
     constexpr int TPB = 256 / G;                     // tasks per block
-    constexpr int MI_CAP = G == 32 ? RS_MAX_PRBS : 112;  // RBs whose MI values fit the group's LDS slice; wider
-                                                         // slices take the LDS-free variant of R1/R2 below
-    __shared__ double lds_mi[TPB][MI_CAP];           // per-group MI values of the slot's RBs
+    constexpr int TPW = 64 / G;                      // tasks per wave
+    constexpr int CH = 12;                           // slots per chunk of channel estimates (table row = 24 B)
     // Cold per-UE state lives in LDS (one slot per thread, conflict-free), so that the hot loop keeps few
-    // enough VGPRs for 4-5 resident waves per SIMD.  Timers are absolute slot numbers; `evt_at` (a VGPR)
+    // enough VGPRs for 5 resident waves per SIMD.  Timers are absolute slot numbers; `evt_at` (a VGPR)
     // is the earliest of them, so these arrays are touched only in slots where something happens.
     __shared__ int L_burst[RS_BURSTS][256];  // VBR burst end times, 0 = free
     __shared__ int L_hold[256];              // departure time
@@ -389,17 +473,23 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     __shared__ unsigned L_serial[256], L_ctr[256];
     __shared__ int L_acc_traf[256], L_acc_bits[256], L_acc_prbs[256];
     __shared__ double L_nom[256];            // nominal SINR
+    __shared__ short T_esnr[256][CH];        // round(mean(snr)) of the UE in the CH slots of the current chunk
+    __shared__ int L_lut[RS_LUT_MAX];        // e_snr -> modulation << 24 | mcs << 16 | rate (mcs_rate_vs_error)
+    __shared__ double L_ref[32];             // MCS reference SNR (estimate_rx_prob)
+    __shared__ int L_task[TPB][4];           // per task: cbr_at, vbr_at, slice draw counter, next UE serial
     const RsDev* __restrict__ D = A.D;
+    const int tid = (int)threadIdx.x;
+    if (tid < RS_LUT_MAX) L_lut[tid] = tid < D->lut_n ? ((D->mcs_mod[D->lut_mcs[tid]] << 24) | (D->lut_mcs[tid] << 16) | D->lut_rate[tid]) : 0;
+    if (tid >= 64 && tid < 96) L_ref[tid - 64] = D->mcs_ref[tid - 64];
+    __syncthreads();
     const RsState& S = *A.S;
     const int clock0 = (int)A.run[0];
-    double* const mi = lds_mi[threadIdx.x / G];
     const int lane = (int)(threadIdx.x & 63u);
     const int gl = lane & (G - 1);       // UE index owned by this lane
     const int gbase = lane & ~(G - 1);   // first lane of my group inside the wave
-    const int sub = gl >> LOG_LPU;       // subgroup inside the group
-    const int j8 = gl & (LPU - 1);
-    const int tid = (int)threadIdx.x;
     const int tb = tid - gl;             // first thread of my group in the block
+    const int wb = tid & ~63;            // first thread of my wave in the block
+    const int tq = tid / G;              // my group's index in the block
     const int n_tasks = D->n_envs * D->n_embb;
     int task = (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
     const bool in_range = task < n_tasks;
@@ -416,6 +506,10 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     const double slot_rc = D->slot_rc;
     const bool pf_div_fast = D->pf_div_fast != 0;
     const int gran = D->gran;
+    const bool has_nan = D->has_nan != 0;
+    const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2];
+    const int fo0 = (int)D->fad_off[0], fo1 = (int)D->fad_off[1], fo2 = (int)D->fad_off[2];  // < 2^31 (rs_load_fading)
+    const int vo0 = (int)D->valid_off[0], vo1 = (int)D->valid_off[1], vo2 = (int)D->valid_off[2];
 
     // set_prbs (node_b.py:71-74): contiguous ranges in slice order
     int prb_lo = 0;
@@ -429,10 +523,17 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     bool aborted = G < 32 && selected && n_ue > G;
     bool valid = selected && !aborted;
     if (!valid) { n_prb = 0; n_ue = 0; }
-    int cbr_at = S.t_cbr_at[task];
-    int vbr_at = S.t_vbr_at[task];
-    uint32_t sl_ctr = S.t_ctr[task];
-    uint32_t next_serial = S.t_serial[task];
+    int slice_evt;  // earlier of the slice's next CBR / VBR arrival checks (the pair itself sits in L_task)
+    {
+        const int cbr_at = S.t_cbr_at[task], vbr_at = S.t_vbr_at[task];
+        if (gl == 0) {
+            L_task[tq][0] = cbr_at;
+            L_task[tq][1] = vbr_at;
+            L_task[tq][2] = (int)S.t_ctr[task];
+            L_task[tq][3] = (int)S.t_serial[task];
+        }
+        slice_evt = valid ? (cbr_at < vbr_at ? cbr_at : vbr_at) : RS_NEVER;
+    }
     const uint64_t seed = S.seeds[rep];
     const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
     int err = 0;
@@ -488,18 +589,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     // per-step statistics of the task in one register: UE-slots (bits 0-11, <= 50 x 32), scheduled slots (bits
     // 12-17, <= 50), PF trips (bits 18-31, <= 50 x 128); the fading-sample and RB-pair counters follow from them
     unsigned stat = 0u;
-    // The heaviest waves of the launch (by cost rank) set its duration through their dependent chains, the others
-    // through their instruction count: in a GRANT instance the former schedule with one trip per RB pair and
-    // overlapped chains, the latter with the leader-run loop (fewer instructions per task).  Wave-uniform.  The
-    // second loop costs the plain instance ~1 % just by being there, so it is a template parameter, chosen per
-    // launch (rs_api.hip: agent-driven allocations and latency-bound small batches take the GRANT instance).
-    bool grant_loop = false;
     {
         // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
         // get issue priority over their lighter neighbours on the SIMD for the whole step.
         if (A.order) {
-            grant_loop = GRANT && (blockIdx.x * 4u + (threadIdx.x >> 6)) * A.grant_div < gridDim.x * 4u;
             // launch order = cost rank (rs_order.hip): the heaviest tenth of the waves, the next fifth, ...
             const unsigned w = blockIdx.x * 4u + (threadIdx.x >> 6), nw = gridDim.x * 4u;
             if (w * RS_PRIO_A < nw) __builtin_amdgcn_s_setprio(3);
@@ -554,15 +648,28 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     };
 
     const int slots = D->slots;
+    const int n_pairs_full = n_prb / gran;  // RB pairs of full size in this slice
+    int t0 = 0, CL = 0;                     // current chunk of channel estimates: slots [t0, t0 + CL)
     SEC_DECL
     for (int t = 0; t < slots; ++t) {
         const int now = clock0 + t + 1;
         const int slot_counter = t + 1;
+        const bool chunk_start = t == t0 + CL;  // wave-uniform
+        if (chunk_start) {
+            t0 = t;
+            CL = slots - t < CH ? slots - t : CH;
+        }
+        const int tt0 = t - t0;
+        const int n_ue_before = n_ue;
+        int n_new = 0;
 
         // ================= SliceRANeMBB.slot: arrivals (slice_ran.py:205-249)
-        const bool cbr_fire = valid && cbr_at == now;
-        const bool vbr_fire = valid && vbr_at == now;
-        if (wave_any(cbr_fire || vbr_fire)) {
+        if (wave_any(slice_evt == now)) {
+            const bool fire = slice_evt == now;
+            int cbr_at = L_task[tq][0], vbr_at = L_task[tq][1];
+            uint32_t sl_ctr = (uint32_t)L_task[tq][2], next_serial = (uint32_t)L_task[tq][3];
+            const bool cbr_fire = fire && cbr_at == now;
+            const bool vbr_fire = fire && vbr_at == now;
             int n_pend = 0;
             int pend_type0 = 0, pend_type1 = 0;
             if (wave_any(cbr_fire)) flush();  // cbr_cac reads this step's running sums
@@ -629,12 +736,15 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 const int hold_at = hv >= 1 ? now + hv - 1 : RS_NEVER;    // Q5
                 int ftype = 0, fstep = 1;
                 double nominal = 0.0;
+                findex = 0;
                 if (hold_at != now) {  // Q13: a one-slot holding time never joins the slice
                     // SINRSelectiveFading.insert_user (channel_models.py:163-169)
                     ftype = (int)rs_stream_integers(&st, RS_N_TRACES);
-                    findex = (int)rs_stream_integers(&st, D->T[ftype]);
+                    findex = (int)rs_stream_integers(&st, sel3(ftype, T0, T1, T2));
                     fstep = rs_stream_pm1(&st);
-                    nominal = macro_cell_draw(D, &st);
+                    const MacroCell mc = macro_cell_draw(D, st);
+                    nominal = mc.x;
+                    st.ctr = (uint32_t)mc.y;
                 }
                 L_hold[tid] = hold_at;
                 L_uvbr[tid] = uvbr_at;
@@ -645,10 +755,78 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 flags = type | (ftype << 1) | ((fstep > 0 ? 1 : 0) << 3);
                 active = true;
             }
-            n_ue += n_pend;
-            next_serial += (uint32_t)n_pend;
+            if (fire) {
+                n_ue += n_pend;
+                n_new = n_pend;
+                next_serial += (uint32_t)n_pend;
+                if (gl == 0) {
+                    L_task[tq][0] = cbr_at;
+                    L_task[tq][1] = vbr_at;
+                    L_task[tq][2] = (int)sl_ctr;
+                    L_task[tq][3] = (int)next_serial;
+                }
+                slice_evt = valid ? (cbr_at < vbr_at ? cbr_at : vbr_at) : RS_NEVER;
+            }
         }
 
+        SEC_MARK(9)
+        // ================= channel estimates of the chunk's slots (get_snr + estimate_snr: channel_models.py:171-191,
+        // slice_ran.py:43-45), at the start of a chunk for every UE of the wave's tasks, and for a UE that joins
+        // mid-chunk from its arrival slot on.  One (UE, slot) item per lane and round.
+        if (chunk_start || wave_any(n_new > 0)) {
+            const int span = CL - tt0;                                // slots still ahead in the chunk (wave-uniform)
+            const int row0 = chunk_start ? 0 : n_ue_before;           // first UE row to estimate (group-uniform)
+            const int cnt = chunk_start ? n_ue : n_new;
+            const int items = (valid && n_prb > 0) ? cnt * span : 0;  // group-uniform
+            int pre[TPW + 1];
+            pre[0] = 0;
+#pragma unroll
+            for (int g = 0; g < TPW; ++g) pre[g + 1] = pre[g] + __builtin_amdgcn_readlane(items, g * G);
+            const int total = pre[TPW];
+            const int Mdiv = (1048576 + span - 1) / span;            // loc / span == (loc * Mdiv) >> 20 for loc < 2^11
+            for (int base = 0; base < total; base += 64) {
+                const int idx = base + lane;
+                const bool have = idx < total;
+                int g = 0, pg = 0;
+#pragma unroll
+                for (int k = 1; k < TPW; ++k)
+                    if (idx >= pre[k]) { g = k; pg = pre[k]; }
+                const int loc = have ? idx - pg : 0;
+                const int r = (loc * Mdiv) >> 20;
+                const int tt = tt0 + (loc - r * span);
+                const int gl0 = g * G;                               // first lane of the item's group in the wave
+                const int row = bperm(row0, gl0) + r;
+                const int src = gl0 + (have ? row : 0);              // lane that owns the item's UE
+                const int f0 = bperm(findex, src), fl = bperm(flags, src);
+                const int np = bperm(n_prb, gl0), plo = bperm(prb_lo, gl0);
+                const uint32_t k0 = bperm(key0, gl0), k1 = bperm(key1, gl0);
+                const int isl = bperm(sl, gl0);
+                const double nom = L_nom[wb + src];
+                const int dep = L_hold[wb + src];
+                const int adv = tt - tt0 + 1;                        // walker steps from the owner's current state
+                // a UE that departs in slot `dep` is extracted before its get_snr of that slot
+                const bool on = have && clock0 + t0 + tt + 1 < dep;
+                const int ftype = (fl >> 1) & 3;
+                int fs = (fl & 8) ? 1 : -1;
+                const int Tn = sel3(ftype, T0, T1, T2);
+                int f = f0 + fs * adv;
+                const bool straight = !has_nan && f >= 0 && f < Tn;
+                if (wave_any(on && !straight)) {
+                    if (on && !straight) {
+                        const uint32_t ser = L_serial[wb + src];
+                        const uint8_t* vcol = A.fad_valid + sel3(ftype, vo0, vo1, vo2);
+                        f = f0;
+                        for (int a = 0; a < adv; ++a)
+                            walker_advance(f, fs, Tn, has_nan, vcol, k0, k1, (uint32_t)isl, ser, (uint32_t)(now + a));
+                    }
+                }
+                const double* __restrict__ colp = A.fad + (on ? sel3(ftype, fo0, fo1, fo2) + f * P + plo : 0);
+                const double sum = lane_pairwise(np, on, [&](int i) { return colp[i] + nom; });
+                if (on) T_esnr[wb + src][tt] = (short)(int)RS_RINT(sum / (double)np);  // round(np.mean(...)): half-to-even (Q7)
+            }
+        }
+
+        SEC_MARK(7)
         // ================= per-UE timer events: departures, VBR burst ends and arrivals
         int n_cur = n_act;  // bursts that emit in THIS slot (an arrival of this slot starts emitting next slot)
         if (wave_any(active && evt_at == now)) {
@@ -657,7 +835,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             if (wave_any(depart)) {
                 flush();
                 const unsigned keep = group_ballot<G>(active && !depart, gbase);
-                const int n_new = __popc(keep);
+                const int n_keep = __popc(keep);
                 const int su = kth_set_bit(keep, gl);
                 const int src = gbase + su;
                 queue = bperm(queue, src);
@@ -677,7 +855,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 int m_b[RS_BURSTS];
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) m_b[k] = L_burst[k][st_];
-                n_ue = n_new;
+                int m_e[CH / 2];
+#pragma unroll
+                for (int k = 0; k < CH / 2; ++k) m_e[k] = ((const int*)T_esnr[st_])[k];
+                __builtin_amdgcn_wave_barrier();
+                n_ue = n_keep;
                 active = gl < n_ue;
                 L_hold[tid] = active ? m_hold : RS_NEVER;
                 L_uvbr[tid] = active ? m_uvbr : RS_NEVER;
@@ -686,6 +868,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
                 L_nom[tid] = m_nom;
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) L_burst[k][tid] = m_b[k];
+#pragma unroll
+                for (int k = 0; k < CH / 2; ++k) ((int*)T_esnr[tid])[k] = m_e[k];
                 if (!active) { evt_at = RS_NEVER; n_act = 0; }
                 n_cur = n_act;
             }
@@ -739,47 +923,17 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
         const bool any_queue = group_ballot<G>(active && queue > 0.0, gbase) != 0u;
 
         SEC_MARK(1)
-        // ================= channel: get_snr + estimate_snr (channel_models.py:171-191, slice_ran.py:43-45)
+        // ================= channel: this slot's walker step and the estimate tabulated for it (Q3: with no PRBs the
+        // walker does not move and e_snr is stale)
         int col = 0;  // element offset of this UE's fading column
-        if (n_prb > 0) {
-            if (active) {
-                const int ftype = (flags >> 1) & 3;
-                int fstep = (flags & 8) ? 1 : -1;
-                const int Tn = D->T[ftype];
-                for (;;) {
-                    findex += fstep;
-                    if (findex >= Tn || findex < 0) {
-                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
-                        findex = (int)rs_stream_integers(&st, Tn);
-                        fstep = rs_stream_pm1(&st);
-                        L_ctr[tid] = st.ctr;
-                    }
-                    if (!D->has_nan || A.fad_valid[D->valid_off[ftype] + findex]) break;  // Q10
-                }
-                flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
-#ifdef RS_EXP_NOMISS  // timing experiment only: every fading load hits the cache
-                col = (int)(D->fad_off[ftype] + (int64_t)(findex & 3) * P);
-#else
-                col = (int)(D->fad_off[ftype] + (int64_t)findex * P);
-#endif
-            }
-            SEC_MARK(7)
-            // NSUB UEs per group at a time, one per subgroup
-            for (int rho = 0; wave_any(rho * NSUB < n_ue); ++rho) {
-                const int k = rho * NSUB + sub;
-                const bool have = k < n_ue;
-                const int srcl = gbase + (have ? k : 0);
-                const int c_col = bperm(col, srcl);
-                const double c_nom = L_nom[tb + (have ? k : 0)];
-                int es = 0;
-                if (have) {
-                    const double* __restrict__ base = A.fad + c_col + prb_lo;
-                    double sum = subl_pairwise<LPU>(n_prb, j8, [&](int i) { return base[i] + c_nom; });
-                    es = (int)RS_RINT(sum / (double)n_prb);  // round(np.mean(...)): half-to-even (Q7)
-                }
-                const int got = bperm(es, gbase + ((gl & (NSUB - 1)) << LOG_LPU));
-                if (active && (gl >> LOG_NSUB) == rho) e_snr = got;
-            }
+        const int ftype = (flags >> 1) & 3;
+        if (n_prb > 0 && active) {
+            int fstep = (flags & 8) ? 1 : -1;
+            walker_advance(findex, fstep, sel3(ftype, T0, T1, T2), has_nan, A.fad_valid + sel3(ftype, vo0, vo1, vo2), key0,
+                           key1, (uint32_t)sl, L_serial[tid], (uint32_t)now);
+            flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
+            col = sel3(ftype, fo0, fo1, fo2) + findex * P;
+            e_snr = T_esnr[tid][tt0];
         }
         stat += (unsigned)n_ue;
 
@@ -791,106 +945,39 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             // ---- ProportionalFair.allocate (schedulers.py:21-76)
             int li = e_snr - D->lut_lo;
             li = li < 0 ? 0 : (li >= D->lut_n ? D->lut_n - 1 : li);
-            const int mcs = D->lut_mcs[li];
-            const int rate = D->lut_rate[li];
+            const int lut = L_lut[li];
+            const int mcs = (lut >> 16) & 0xff;
+            const int mod = lut >> 24;
+            const int rate = lut & 0xffff;
             const double rate_d = (double)rate;
             int q = active ? (int)(queue < 1073741824.0 ? queue : 1073741824.0) : 0;
             double thl = th > 1.0 ? th : 1.0;
             int rbs = 0, bits = 0;
-            double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
             int r = 0;
-            bool need_full = true;
-            double mx = 0.0;
-            int idx = 0;
-            SEC_MARK(8)
-            if (grant_loop) {
-                // One trip per RB pair (the heaviest waves of the launch, see `grant_loop` above).  Every lane
-                // precomputes its own state *as if* it were granted the pair -- in SIMD that costs what the
-                // leader's update alone would cost -- so the f64 divide of the update does not depend on the
-                // cross-lane reduction of the same trip and the two chains overlap; the leader just selects.
-                bool need_second = true;
-                double m2 = 0.0;
-                int idx2 = 0;
-                for (;;) {
-                    const bool more = sched && r < n_prb;
-                    if (!wave_any(more)) break;
-                    if (more) stat += 1u << 18;
-#ifdef RS_SECTION_PROFILE
-                    sec_acc[15] += 1;
-#endif
-                    // candidate state after one more RB pair at position r (schedulers.py:52-63)
-                    const int c_prbs = n_prb - r < gran ? n_prb - r : gran;
-                    const int c_tx = c_prbs * rate < q ? c_prbs * rate : q;
-                    const int c_q = q - c_tx, c_bits = bits + c_tx;
-                    const double c_thl = pf_a * thl + pf_share(c_bits);
-                    const double c_m = c_q > 0 ? rate_d / c_thl : 0.0;  // a drained UE's metric is 0
-                    if (wave_any(more && need_full)) {
-                        const double fm = group_max<G>(m);
-                        const unsigned eq = group_ballot<G>(m == fm, gbase);
-                        if (need_full) {
-                            mx = fm;
-                            idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
-                        }
-                    }
-                    if (wave_any(more && need_second)) {  // a leader that stays keeps its runner-up
-                        const double m_rest = gl == idx ? -2.0 : m;
-                        const double f2 = group_max<G>(m_rest);
-                        const unsigned eq2 = group_ballot<G>(m_rest == f2, gbase);
-                        if (need_second) {
-                            m2 = f2;
-                            idx2 = __ffs((int)eq2) - 1;
-                        }
-                    }
-                    const bool contested = more && mx != 0.0 && m2 > 0.0;
-                    const bool lead = contested && gl == idx;
-                    if (lead) {
-                        rbs += c_prbs;
-                        q = c_q;
-                        bits = c_bits;
-                        thl = c_q > 0 ? c_thl : thl;  // a drained UE keeps its (discarded) local th
-                        m = c_m;
-                    }
-                    // the leader stays while it is still the first maximum
-                    const bool stays = group_ballot<G>(lead && (c_m > m2 || (c_m == m2 && gl < idx2)), gbase) != 0u;
-                    if (contested) {
-                        r += gran;
-                        need_full = false;
-                        need_second = !stays;
-                        if (!stays) {  // the runner-up's metric is the group's maximum now
-                            mx = m2;
-                            idx = idx2;
-                        }
-                    }
-                    // every queue empty, or only the leader has data (closed form)
-                    if (wave_any(more && !contested)) {
-                        int take = 0;
-                        if (more && !contested) {
-                            if (mx == 0.0) {
-                                if (gl == 0) rbs += n_prb - r;  // Q4: the remaining RB pairs go to UE 0
-                            } else if (gl == idx) {
-                                const int R = n_prb - r;
-                                const int per_it = gran * rate;
-                                const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
-                                const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
-                                const bool all = k_full >= K;
-                                const int cap_bits = R * rate;
-                                const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
-                                take = all ? K * gran : k_full * gran;
-                                rbs += all ? R : take;
-                                q -= tx;
-                                bits += tx;
-                                m = 0.0;  // drained, or no RBs left
-                            }
-                        }
-                        const int tk = bperm(take, gbase + idx);
-                        if (more && !contested) {
-                            r = mx == 0.0 ? n_prb : r + tk;
-                            need_full = true;
-                            need_second = true;
-                        }
-                    }
+            {
+                // Under-loaded slot (the common case): while any UE has data an RB pair goes to a UE with data (a
+                // positive metric beats the zeros), and a UE that drains stops competing, so UE u is granted exactly
+                // k_u = ceil(q_u / (gran * rate_u)) pairs WHATEVER the order in which the argmax serves them,
+                // provided all of those grants land on full pairs: sum(k_u) <= floor(n_prb / gran).  Then
+                // rbs_u = k_u * gran, every queue is sent whole, and the idle remainder goes to UE 0 (Q4).  The
+                // local throughput averages that decide the order are discarded by the reference
+                // (schedulers.py:64-76), so nothing else is needed.
+                const int per_it = gran * rate;
+                const int k_u = (active && q > 0) ? (int)((double)(q + per_it - 1) / (double)per_it) : 0;
+                const int need = group_sum<G>(k_u);
+                if (sched && need <= n_pairs_full) {
+                    rbs = k_u * gran;
+                    bits = k_u > 0 ? q : 0;
+                    if (gl == 0) rbs += n_prb - need * gran;
+                    r = n_prb;
                 }
-            } else {
+            }
+            SEC_MARK(8)
+            if (wave_any(sched && r < n_prb)) {
+                double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
+                bool need_full = true;
+                double mx = 0.0;
+                int idx = 0;
                 // leader (first maximum) and runner-up of the group's metrics.  After a contested run only the
                 // leader's metric has changed and it ended below the runner-up, so the runner-up is the next leader
                 // and only the new runner-up needs a reduction; `need_full` (group-uniform) asks for both.
@@ -984,116 +1071,70 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
             const int prb_i = group_excl_scan<G>(rbs, gl);
-            const int prb_end = prb_i + rbs;
-            const unsigned smask = group_ballot<G>(sched && active && rbs > 0, gbase);
-            const int nsched = __popc(smask);
-            const int my_rank = __popc(smask & ((1u << gl) - 1u));  // gl <= 31
-            // ---- MCSCodeset.response (channel_models.py:297-313) in three phases.
-            // R1 + R2.  R1: mutual information of every allocated RB, one RB per lane and pass; the owner UE of
-            // an RB is found by walking the (few) scheduled UEs.  Values go to the group's LDS slice -- or, for a
-            // slice wider than that slice (n_prb > MI_CAP, rare), to a per-task HBM scratch row read back with
-            // L1-bypassing loads.  R2: np.mean's pairwise sum per scheduled UE, one UE per 8-lane subgroup.
-            const bool wide = n_prb > MI_CAP;  // group-uniform
-            auto r1r2 = [&](auto mip, const bool sel, const bool r1_done) -> double {
-                for (int pass = 0; wave_any(sched && sel && !r1_done && pass * G < n_prb); ++pass) {
-                    int o_col = 0, o_mcs = 0, o_rbs = 0;
-                    double o_nom = 0.0;
-                    const int k = pass * G + gl;
-                    unsigned mm = smask;
-                    while (wave_any(mm != 0u)) {
-                        const int src = gbase + (mm ? __ffs((int)mm) - 1 : 0);
-                        const int s_u = bperm(prb_i, src), e_u = bperm(prb_end, src);
-                        const int c_u = bperm(col, src), m_u = bperm(mcs, src);
-                        const double nom_u = L_nom[tb + (src - gbase)];
-                        if (mm != 0u && k >= s_u && k < e_u) {
-                            o_col = c_u;
-                            o_mcs = m_u;
-                            o_rbs = e_u - s_u;
-                            o_nom = nom_u;
-                        }
-                        mm &= mm - 1u;
+            // ---- MCSCodeset.response (channel_models.py:297-313), for the UEs whose reception outcome can change
+            // anything: those that sent bits.  (A UE holding RBs without data still consumes its Bernoulli draw
+            // below; the allocation trace wants every probability, so the tracing instances evaluate them all.)
+            const bool needed = sched && active && rbs > 0 && (TRACE || bits > 0);
+            const double x0_0 = D->mi_x0[0], x0_1 = D->mi_x0[1], x0_2 = D->mi_x0[2];
+            const double kk_0 = D->mi_k[0], kk_1 = D->mi_k[1], kk_2 = D->mi_k[2];
+            // R1 + R2 fused: np.mean's pairwise sum of the mutual information over a UE's RBs.  The spans to evaluate
+            // (all tasks of the wave) are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator
+            // R_j: it evaluates the sigmoid of its elements one after the other and adds them in numpy's order, the
+            // team meets for the tree and the remainder.  No per-RB values are stored anywhere.
+            double sum_rx = 0.0;
+            {
+                const unsigned long long wmask = __builtin_amdgcn_ballot_w64(needed);
+                const int n_sp = __popcll(wmask);
+                const int my_sp = __popcll(wmask & ((1ull << lane) - 1ull));   // my span's index in the wave
+                const int team = lane >> 3, j = lane & 7;
+                const int span_col = col + prb_lo + prb_i;                      // first element of my span in the table
+                unsigned long long rest = wmask;
+                for (int round = 0; round * 8 < n_sp; ++round) {
+                    // owners of this round's 8 spans (uniform), then mine by team
+                    int owner = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int o = rest ? __builtin_ctzll(rest) : 0;
+                        rest &= rest - 1ull;
+                        owner = team == k ? o : owner;
                     }
-                    if (sched && sel && !r1_done && k < n_prb) {
-                        const double x = A.fad[o_col + prb_lo + k] + o_nom;
-                        // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
-                        mip.st(k, o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x);
-                    }
+                    const bool on = round * 8 + team < n_sp;
+                    const int c0 = bperm(span_col, owner);
+                    const int n = bperm(rbs, owner);
+                    const int md = bperm(mod, owner);
+                    const double nom = L_nom[wb + owner];
+                    const double x0 = sel3(md, x0_0, x0_1, x0_2), kk = sel3(md, kk_0, kk_1, kk_2);
+                    const double* __restrict__ sp = A.fad + (on ? c0 : 0);
+                    // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
+                    const bool single = n == 1;
+                    const double sv = team_pairwise(n, j, on, [&](int i) {
+                        const double x = sp[i] + nom;
+                        return single ? x : rs_sigmoid(x, x0, kk);
+                    });
+                    const double got = bperm(sv, (my_sp & 7) << 3);
+                    if ((my_sp >> 3) == round) sum_rx = got;
                 }
-                mip.sync();
-                double acc_rx = 0.0;
-                for (int rho = 0; wave_any(sel && rho * NSUB < nsched); ++rho) {
-                    const int k = rho * NSUB + sub;
-                    const bool have = sel && k < nsched;
-                    const int srcl = gbase + (have ? kth_set_bit(smask, k) : 0);
-                    const int c_rbs = bperm(rbs, srcl);
-                    const int c_s = bperm(prb_i, srcl);
-                    double sv = 0.0;
-                    if (have) sv = subl_pairwise<LPU>(c_rbs, j8, [&](int i) { return mip.ld(c_s + i); });
-                    const double got = bperm(sv, gbase + ((my_rank & (NSUB - 1)) << LOG_LPU));
-                    if ((my_rank >> LOG_NSUB) == rho) acc_rx = got;
-                }
-                return acc_rx;
-            };
-            double sum_rx = r1r2(MiLds{mi}, !wide, false);
-            if (wave_any(sched && wide)) {
-                bool r1_done = false;
-                if (GRANT && G < 32) {
-                    // A wide slice is what an agent-made allocation looks like: ~180 RBs in one task, a handful in
-                    // its three wave-mates.  All 64 lanes of the wave then work through the wide task's RBs (its
-                    // per-UE ranges come over v_readlane, the group index being wave-uniform): 3 passes, not 12.
-                    unsigned long long wmask = __builtin_amdgcn_ballot_w64(sched && wide && gl == 0);
-                    while (wmask != 0ull) {
-                        const int wl = __builtin_ctzll(wmask);  // first lane of the wide group
-                        wmask &= wmask - 1ull;
-                        // (fetched into VGPRs: keeps the scalar register file, which already spills, out of it)
-                        const int w_nprb = bperm(n_prb, wl);
-                        const int w_lo = bperm(prb_lo, wl);
-                        const int w_task = bperm(task, wl);
-                        const unsigned w_smask = (unsigned)__builtin_amdgcn_readlane((int)smask, wl);
-                        double* const row = A.mi_wide + (size_t)w_task * RS_MAX_PRBS;
-                        for (int k0 = 0; wave_any(k0 < w_nprb); k0 += 64) {
-                            const int k = k0 + lane;
-                            int o_col = 0, o_mcs = 0, o_rbs = 0;
-                            double o_nom = 0.0;
-                            for (unsigned mm = w_smask; mm != 0u; mm &= mm - 1u) {
-                                const int ul = wl + __ffs((int)mm) - 1;  // lane of the scheduled UE (uniform)
-                                const int s_u = __builtin_amdgcn_readlane(prb_i, ul);
-                                const int e_u = __builtin_amdgcn_readlane(prb_end, ul);
-                                if (k >= s_u && k < e_u) {
-                                    o_col = __builtin_amdgcn_readlane(col, ul);
-                                    o_mcs = __builtin_amdgcn_readlane(mcs, ul);
-                                    o_rbs = e_u - s_u;
-                                    o_nom = L_nom[(tid & ~63) + ul];
-                                }
-                            }
-                            if (k < w_nprb) {
-                                const double x = A.fad[o_col + w_lo + k] + o_nom;
-                                row[k] = o_rbs > 1 ? rs_sigmoid(x, D->mcs_x0[o_mcs], D->mcs_k[o_mcs]) : x;
-                            }
-                        }
-                    }
-                    r1_done = true;
-                }
-                const double s2 = r1r2(MiHbm{A.mi_wide + (size_t)task * RS_MAX_PRBS}, wide, r1_done);
-                if (wide) sum_rx = s2;
             }
             SEC_MARK(10)
-            // R3: effective SNR and reception probability, every scheduled UE in its own lane
-            if (sched && active && rbs > 0) {
-                const double x0 = D->mcs_x0[mcs], kk = D->mcs_k[mcs];
+            // R3: effective SNR and reception probability, every evaluated UE in its own lane
+            if (needed) {
+                const double x0 = sel3(mod, x0_0, x0_1, x0_2), kk = sel3(mod, kk_0, kk_1, kk_2);
                 double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
                 if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
-                const double x = D->mcsA * (s_eff - D->mcs_ref[mcs]) - D->mcsB;
+                const double x = D->mcsA * (s_eff - L_ref[mcs]) - D->mcsB;
                 p_rx = rs_sigmoid(x, 0.0, 1.0);
             }
             SEC_MARK(4)
             // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
             if (sched && active) {
                 bool received = false;
-                if (rbs > 0) {
-                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
-                    received = rs_stream_uniform(&st) < p_rx;
-                    L_ctr[tid] = st.ctr;
+                if (rbs > 0) {  // the draw is consumed whether or not anything rides on it
+                    const unsigned c = L_ctr[tid];
+                    if (needed) {
+                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], c};
+                        received = rs_stream_uniform(&st) < p_rx;
+                    }
+                    L_ctr[tid] = c + 1u;
                 }
                 if (!received) bits = 0;
                 double nq = queue - (double)bits;
@@ -1175,6 +1216,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
     SEC_FLUSH(A.sections)
 
     // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)
+    // (the state pointers are fetched again here, through a pointer the compiler cannot see through, instead of
+    // being kept alive -- twenty of them -- across the whole step)
+    const RsState* sp_end = A.S;
+    asm volatile("" : "+s"(sp_end));
+    const RsState& SE = *sp_end;
     const double i1 = bperm(infok, gbase + 1), i2 = bperm(infok, gbase + 2), i3 = bperm(infok, gbase + 3);
     const double i6 = bperm(infok, gbase + 6), i7 = bperm(infok, gbase + 7);
     // info[8], info[9] live in lanes 8, 9: a G = 8 group keeps them in lanes 0, 1 of a second register
@@ -1197,34 +1243,34 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? 5 : 3) void embb_step_ke
             int viol = !(cbr_ok && vbr_ok);
             A.violations[rep * n_slices + sl] = viol;
             A.labels[rep * n_slices + sl] = viol == 0 ? 1 : -1;
-            S.t_n_ue[task] = n_ue;
-            S.t_cbr_at[task] = cbr_at;
-            S.t_vbr_at[task] = vbr_at;
-            S.t_ctr[task] = sl_ctr;
-            S.t_serial[task] = next_serial;
-            S.t_cost[task] = (int)(stat >> 18);
+            SE.t_n_ue[task] = n_ue;
+            SE.t_cbr_at[task] = L_task[tq][0];
+            SE.t_vbr_at[task] = L_task[tq][1];
+            SE.t_ctr[task] = (uint32_t)L_task[tq][2];
+            SE.t_serial[task] = (uint32_t)L_task[tq][3];
+            SE.t_cost[task] = (int)(stat >> 18);
             uint64_t* c = A.counters + (size_t)task * 4;
             const unsigned cnt_ue = stat & 0xfffu, n_sched = (stat >> 12) & 0x3fu;
             c[0] += cnt_ue * (unsigned)n_prb;  // every UE reads n_prb fading samples per slot (n_prb is fixed for the step)
             c[2] += n_sched * (unsigned)((n_prb + gran - 1) / gran);  // RB pairs per scheduled slot
             c[3] += cnt_ue;
-            if (e_any != 0u) atomicOr(&S.err[rep], 1);
+            if (e_any != 0u) atomicOr(&SE.err[rep], 1);
         }
         if (active) {
-            S.u_queue[ui] = queue;
-            S.u_th[ui] = th;
-            S.u_nominal[ui] = L_nom[tid];
-            S.u_hold_at[ui] = L_hold[tid];
-            S.u_e_snr[ui] = e_snr;
-            S.u_findex[ui] = findex;
-            S.u_bits[ui] = ue_bits;
-            S.u_prbs[ui] = ue_prbs;
-            S.u_vbr_at[ui] = L_uvbr[tid];
-            S.u_ctr[ui] = L_ctr[tid];
-            S.u_serial[ui] = L_serial[tid];
-            S.u_flags[ui] = flags;
+            SE.u_queue[ui] = queue;
+            SE.u_th[ui] = th;
+            SE.u_nominal[ui] = L_nom[tid];
+            SE.u_hold_at[ui] = L_hold[tid];
+            SE.u_e_snr[ui] = e_snr;
+            SE.u_findex[ui] = findex;
+            SE.u_bits[ui] = ue_bits;
+            SE.u_prbs[ui] = ue_prbs;
+            SE.u_vbr_at[ui] = L_uvbr[tid];
+            SE.u_ctr[ui] = L_ctr[tid];
+            SE.u_serial[ui] = L_serial[tid];
+            SE.u_flags[ui] = flags;
 #pragma unroll
-            for (int k = 0; k < RS_BURSTS; ++k) S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = L_burst[k][tid];
+            for (int k = 0; k < RS_BURSTS; ++k) SE.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] = L_burst[k][tid];
         }
     }
 }

@@ -84,6 +84,8 @@ struct rs_oracle {
     const double* tape_val;
     int64_t tape_n, tape_pos;
     uint64_t seed;
+    int64_t slots_done; /* slots since reset (completed steps) */
+    int64_t now;        /* absolute number of the slot being simulated (1-based) */
     double mcsA, mcsB;
     uint64_t counters[4];
     int err;
@@ -334,11 +336,20 @@ static void fading_insert(rs_oracle* o, rso_ue* u) {
 static const double* fading_advance(rs_oracle* o, rso_ue* u) {
     int T = o->fad_T[u->ftype];
     int guard = 0;
+    uint32_t attempt = 0;
     for (;;) {
         u->findex += u->fstep;
         if (u->findex >= T || u->findex < 0) {
-            u->findex = dr_integers(o, &u->st, T);
-            u->fstep = dr_pm1(o, &u->st);
+            if (o->use_tape) {
+                u->findex = dr_integers(o, &u->st, T);
+                u->fstep = dr_pm1(o, &u->st);
+            } else { /* build-defined streams: the redraw is addressed by (slot, attempt), include/rs_philox.h */
+                int fi, fs;
+                rs_walker_redraw(u->st.key0, u->st.key1, u->st.slice, u->st.serial, (uint32_t)o->now, attempt++, T, &fi,
+                                 &fs);
+                u->findex = fi;
+                u->fstep = fs;
+            }
         }
         if (o->fad_valid[u->ftype][u->findex]) break; /* Q10 */
         if (++guard > 4 * T + 16) {
@@ -827,6 +838,8 @@ int rso_reset(rs_oracle* o) {
     o->err = 0;
     o->errmsg[0] = 0;
     memset(o->counters, 0, sizeof o->counters);
+    o->slots_done = 0;
+    o->now = 0;
     for (int i = 0; i < o->cfg.n_embb; ++i) embb_reset(o, &o->embb[i], i);
     for (int i = 0; i < o->cfg.n_mmtc; ++i) mmtc_reset(o, &o->mmtc[i], o->cfg.n_embb + i);
     return o->err;
@@ -868,10 +881,12 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
     }
     /* slots (node_b.py:77-78): slot-major, slices in order (they share one rng in the reference) */
     for (int t = 0; t < c->slots_per_step; ++t) {
+        o->now = o->slots_done + t + 1;
         for (int s = 0; s < c->n_embb; ++s)
             embb_slot(o, &o->embb[s], trace ? trace + ((size_t)s * c->slots_per_step + t) * o->max_ue : NULL);
         for (int s = 0; s < c->n_mmtc; ++s) mmtc_slot(o, &o->mmtc[s]);
     }
+    o->slots_done += c->slots_per_step;
     o->counters[1] += 1;
     /* get_state (node_b.py:40-44; slice_ran.py:321-325, 133-137): f64 ratio stored as f32 */
     int64_t tv = 0;

@@ -49,9 +49,9 @@ env.synchronize()
 env.L.rs_get_section_profile(env.h, a)
 d = [a[i] - base[i] for i in range(16)]
 # section i accumulates the time from the previous mark to mark i
-names = {11: 'PF trip: leader / runner-up reductions', 12: 'PF trip: leader run or closed form', 0: 'arrivals + timer events', 1: 'traffic_step', 7: 'fading walker', 2: 'e_snr rounds (loads, pairwise sum)',
-         8: 'PF set-up (MCS lookup, first metric)', 3: 'PF trip: take broadcast + loop control', 9: 'RB scan + R1 (MI of every RB)',
-         10: 'R2 (pairwise sums from LDS)', 4: 'R3 (inv_sigmoid + rx prob)', 5: 'reception draw + tx_step',
+names = {9: 'slice arrivals', 11: 'PF trip: leader / runner-up reductions', 12: 'PF trip: leader run or closed form', 0: 'timer events', 1: 'traffic_step', 7: 'channel estimates ahead (chunk prologue)', 2: 'walker step + table read',
+         8: 'PF set-up (MCS lookup, first metric)', 3: 'PF trip: take broadcast + loop control', 
+         10: 'RB scan + R1 + R2 (MI of the evaluated spans, pairwise sums)', 4: 'R3 (inv_sigmoid + rx prob)', 5: 'reception draw + tx_step',
          6: 'update_info'}
 trips = d[15]
 runs = d[13]
@@ -62,7 +62,7 @@ slowest = a[14]
 d[14] = 0
 tot = sum(d) or 1
 waves = N * 5 / 4  # 16 lanes per task
-for i in (0, 1, 7, 2, 8, 11, 12, 3, 9, 10, 4, 5, 6):
+for i in (9, 7, 0, 1, 2, 8, 11, 12, 3, 10, 4, 5, 6):
     print('%-38s %6.2f%%   %9.0f cycles/wave/slot' % (names[i], 100.0 * d[i] / tot, d[i] / K / waves / 50))
 print('slowest wave of any launch: %.0f cycles/slot (mean wave: %.0f)' % (slowest / 50, tot / K / waves / 50))
 print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (tot / K / waves / 50, trips / K / waves / 50))
@@ -74,7 +74,7 @@ env.L.rs_get_task_profile(env.h, raw.ctypes.data_as(C.POINTER(C.c_uint64)))
 tp = raw[:N * 5 * 4].reshape(N * 5, 4)
 sw = raw[N * 5 * 4:].astype(np.float64)
 print('section split of the slowest wave of the run (cycles/slot):')
-for i in (0, 1, 7, 2, 8, 11, 12, 3, 9, 10, 4, 5, 6):
+for i in (9, 7, 0, 1, 2, 8, 11, 12, 3, 10, 4, 5, 6):
     print('   %-38s %9.0f  %5.1f%%' % (names[i], sw[i] / 50, 100.0 * sw[i] / max(1.0, sw[:13].sum())))
 cyc = tp[:, 0].astype(np.float64) / 50
 print('last step: wave cycles/slot percentiles 50/90/99/99.9/max: %s' % np.percentile(cyc, [50, 90, 99, 99.9, 100]).round(0))
