@@ -686,7 +686,7 @@ static int launch_step(rs_handle* h) {
                                h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
-                               h->d_order, h->order_mode > 3 ? 1 : 0, 64 / h->group);
+                               h->d_order, h->order_mode > 3 ? 1 : 0, 64 / h->group);  // modes 4.. = keys 1.. with heavy+light pairing
             a.order = h->d_order;
         }
         // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)

@@ -970,6 +970,18 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                     bits = k_u > 0 ? q : 0;
                     if (gl == 0) rbs += n_prb - need * gran;
                     r = n_prb;
+                } else {
+                    // over-loaded, but a single UE holds all the data: it wins every pair (k_u > floor(n_prb / gran), so
+                    // it is not drained before the last, possibly single-RB, pair)
+                    const unsigned nz = group_ballot<G>(sched && k_u > 0, gbase);
+                    if (sched && (nz & (nz - 1u)) == 0u) {
+                        if (k_u > 0) {
+                            const int cap_bits = n_prb * rate;
+                            rbs = n_prb;
+                            bits = q < cap_bits ? q : cap_bits;
+                        }
+                        r = n_prb;
+                    }
                 }
             }
             SEC_MARK(8)

@@ -26,7 +26,9 @@ namespace rs {
 __device__ __forceinline__ int order_key(int mode, int n_ue, int n_prb, int cost) {
     int key;
     mode = mode > 3 ? mode - 3 : mode;
-    if (mode == 2) key = n_ue * 64 + (n_prb >> 2);  // UE count first, then width
+    if (mode == 4) key = ((n_ue * n_prb) >> 2) + 2 * cost;  // PF trips dominate (a trip costs what ~30 fading samples do)
+    else if (mode == 5) key = cost;
+    else if (mode == 2) key = n_ue * 64 + (n_prb >> 2);  // UE count first, then width
     else if (mode == 3) key = n_ue * n_prb + cost;  // work + last step's contested PF trips
     else key = n_ue * n_prb;                         // fading samples per slot
     key = key < 0 ? 0 : key;
