@@ -6,34 +6,42 @@ One "step" = one pass of the hot path over one batch: RanSlice.step for 4096 env
 actions generated on the device.  Inputs (fading tables, simulator state, actions) are resident
 in HBM when the timed region starts; nothing crosses PCIe inside it.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]          (N > 1: spawns its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Replicas are independent, so GPUs shard them with no data-path collective (weak scaling: 4096
 replicas per GPU).  torch is used only for the process group (barrier, max-over-ranks).
 
-Before the W warm-up steps the environments are advanced `--burn-in` steps (default 1000 = 50 s of
-simulated time) so that the UE population is at its steady state (~3.5 UEs per slice) instead of
-the 2-UE state right after reset; this is environment set-up, not part of the timed work.
+Before the W warm-up steps the environments are advanced until the UE population is stationary: blocks of 500
+steps (25 s of simulated time; the holding times have a 30 s mean) until the mean number of UEs per slice changes
+by less than 0.5 % from one block to the next (every rank runs the same number of blocks).  This is environment
+set-up, not part of the timed work; the line reports the steps it took and the population.
 
 The JSON line also carries
   roofline     : algorithmic bytes per launch of the dominant kernel (embb_step_kernel) divided by
                  its mean launch duration measured with HIP events on the launch stream, against
-                 the 8 TB/s HBM peak (DESIGN.md §Measurement states the byte model);
+                 the 8 TB/s HBM peak (DESIGN.md §Measurement states the byte model).  `traffic` is null: this
+                 process does not read PMC counters; the HBM bytes of a separate rocprofv3 --pmc run of this
+                 same command are reported as `profiled_traffic` with the file they come from;
   cpu_baseline : the CPU oracle (a C port of the reference's numpy path, pinned bit-exact to the
                  reference on golden tapes) timed on this box's host cores on a bounded sample of
-                 the same workload -- a reported baseline, never the thing measured above.
+                 the same workload -- a reported baseline, never the thing measured above;
+  kbrl         : (1 GPU) BASELINE config 3 -- the same 4096 replicas with one KBRL agent each, closed loop on
+                 the device: env-steps/s, RBF kernel evaluations/s, the flop rate of the scoring against the
+                 78.6 TFLOP/s f64 peak.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for _p in (ROOT, os.path.join(ROOT, 'network-slicing_amd')):
+for _p in (ROOT, os.path.join(ROOT, 'network-slicing_amd'), os.path.join(ROOT, 'tools')):
     if _p not in sys.path:
         sys.path.insert(0, _p)
 
@@ -43,7 +51,10 @@ ENVS_PER_GPU = 4096
 SCENARIO = 0
 FADING_COLS = 10000
 ACTION_SEED = 2024
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+F64_PEAK_TFLOPS = 78.6     # MI355X f64 vector / matrix peak
+BURN_BLOCK = 500
+BURN_MAX = 8000
 
 # bytes of persistent simulator state the step kernel reads and writes per task / per active UE
 # (network-slicing_amd/csrc/rs_device.h): header 5 x 4 B; UE 3 f64 + 9 i32 + 8 burst i32
@@ -86,7 +97,7 @@ def _init_pool(b):
     _BARRIER = b
 
 
-def cpu_baseline(burn, timed):
+def host_cores():
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
@@ -100,6 +111,11 @@ def cpu_baseline(burn, timed):
             cores = max(1, min(cores, int(int(q) / int(per))))
     except Exception:
         pass
+    return cores
+
+
+def cpu_baseline(burn, timed):
+    cores = host_cores()
     ctx = mp.get_context('fork')
     barrier = ctx.Barrier(cores)
     with ctx.Pool(cores, initializer=_init_pool, initargs=(barrier,)) as pool:
@@ -114,33 +130,147 @@ def cpu_baseline(burn, timed):
                        % (cores, timed, burn))
 
 
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def kbrl_record(n_envs, device, steps, warmup):
+    """BASELINE config 3 on this GPU: closed loop with one KBRL agent per replica (kb_step_resident)."""
+    import ctypes as C
+    from ranslice import _lib
+    from ranslice.config import make_config, EMBB_A, EMBB_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    cfg = make_config(SCENARIO, n_envs=n_envs)
+    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=[synth_fading(t, FADING_COLS) for t in range(3)], device=device)
+    agent, capacity = None, None
+    for cap in (1024, 512, 256):
+        try:
+            agent = VecKBRL(n_envs, [10] * cfg.n_embb, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=cap,
+                            device=device)
+            capacity = cap
+            break
+        except _lib.RanSliceError:
+            agent = None
+    if agent is None:
+        env.close()
+        return None
+    rng = np.random.default_rng(0)
+    ia = rng.integers(EMBB_A[0], EMBB_A[1], size=(n_envs, cfg.n_embb)).astype(np.int32)   # scenario_creator.py:220-221
+    sf = rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(n_envs, cfg.n_embb)).astype(np.int32)
+    env.reset()
+    agent.reset(ia, sf)
+    env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+
+    def run(k):
+        for _ in range(k):
+            agent.step_resident(env)
+            env.step_resident()
+    run(warmup)
+    env.synchronize()
+    agent.synchronize()
+    s0 = agent.stats()
+    agent.set_kernel_timing(True)
+    env.set_kernel_timing(True)
+    t0 = time.perf_counter()
+    run(steps)
+    env.synchronize()
+    agent.synchronize()          # also raises if any dictionary overflowed its capacity
+    dt = time.perf_counter() - t0
+    s1 = agent.stats()
+    kb_ms, kb_n = agent.kernel_time_ms()
+    env_ms, _ = env.kernel_time_ms()
+    sizes = agent.dictionary_sizes()
+    evals = s1[3] - s0[3]
+    d = 11   # eMBB learner: 10 state variables + the candidate allocation
+    flops = evals * (3 * d + 3)   # SURVEY.md 8d: distance 3d + 1, exp counted as 1, k.coeff 2  (per landmark x candidate)
+    rec = {
+        'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device, steps %d-%d of '
+                    'learning' % (n_envs, warmup, warmup + steps),
+        'dictionary_capacity': capacity,
+        'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / steps,
+        'embb_kernel_ms': env_ms, 'kb_kernel_ms_mean_of_update_and_select': kb_ms,
+        'kernel_evaluations_per_s': evals / dt,
+        'predicts_per_env_step': (s1[0] - s0[0]) / (n_envs * steps),
+        'mistakes_per_env_step': (s1[1] - s0[1]) / (n_envs * steps),
+        'flops_model': '(3 d + 3) flop per kernel evaluation, d = 11 (SURVEY.md 8d)',
+        'achieved_tflops': flops / dt / 1e12, 'peak_tflops_f64': F64_PEAK_TFLOPS,
+        'frac_of_f64_peak': flops / dt / 1e12 / F64_PEAK_TFLOPS,
+        'dictionary_size_mean': float(np.mean(sizes)), 'dictionary_size_max': int(np.max(sizes)),
+    }
+    ppath = os.path.join(ROOT, 'profiles', 'kbrl_mfma_share.json')
+    if os.path.exists(ppath):
+        try:
+            with open(ppath) as f:
+                rec['profiled_mfma_share'] = json.load(f)
+        except Exception:
+            pass
+    env.close()
+    agent.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2000)
     ap.add_argument('--warmup', type=int, default=200)
-    ap.add_argument('--burn-in', type=int, default=1000)
+    ap.add_argument('--burn-in', type=int, default=-1,
+                    help='fixed number of burn-in steps; default -1 = until the UE population is stationary')
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kbrl', action='store_true')
+    ap.add_argument('--kbrl-steps', type=int, default=200)
     ap.add_argument('--graph', action='store_true',
                     help='replay the timed loop from a captured hipGraph (rs_run_random); the kernel time for the '
                          'roofline is then taken from a separate event-timed pass of 100 steps')
     ap.add_argument('--cpu-steps', type=int, default=3000)
+    ap.add_argument('--cpu-baseline-json', default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    under_launcher = 'WORLD_SIZE' in os.environ and 'RANK' in os.environ
+    cpu_burn = 1000
+
+    if args.gpus > 1 and not under_launcher:
+        # one command for the whole report: time the CPU baseline here, then launch one rank per GPU
+        cpu_file = None
+        if not args.no_cpu_baseline:
+            cpu_file = os.path.join('/tmp', 'bench_cpu_%d.json' % os.getpid())
+            with open(cpu_file, 'w') as f:
+                json.dump(cpu_baseline(cpu_burn, args.cpu_steps), f)
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)]
+        cmd += [a for a in sys.argv[1:]]
+        if cpu_file:
+            cmd += ['--cpu-baseline-json', cpu_file]
+        else:
+            cmd += ['--no-cpu-baseline'] if '--no-cpu-baseline' not in sys.argv else []
+        env = dict(os.environ)
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        rc = subprocess.call(cmd, env=env)
+        if cpu_file and os.path.exists(cpu_file):
+            os.remove(cpu_file)
+        sys.exit(rc)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d '
-                             '--master-addr 127.0.0.1 --master-port 29500 bench.py --gpus %d ...' % (args.gpus, args.gpus))
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
 
-    # the CPU baseline forks worker processes: do it before any HIP/torch initialisation
+    # the CPU baseline forks worker processes: do it before any HIP/torch initialisation (rank 0 only; the other
+    # ranks wait for it in the process-group rendezvous)
     cpu_base = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_base = cpu_baseline(args.burn_in, args.cpu_steps)
+    if rank == 0:
+        if args.cpu_baseline_json and os.path.exists(args.cpu_baseline_json):
+            with open(args.cpu_baseline_json) as f:
+                cpu_base = json.load(f)
+        elif not args.no_cpu_baseline:
+            cpu_base = cpu_baseline(cpu_burn, args.cpu_steps)
 
     import torch
     import torch.distributed as dist
@@ -155,8 +285,10 @@ def main():
         if world > 1:
             dist.barrier()
 
+    from dist_util import max_over_ranks
     from ranslice.config import make_config
     from ranslice.fading import synth_fading
+    from ranslice.sharding import shard_range, replica_seeds, aggregate_throughput
     from ranslice.vec_env import VecRanSlice
 
     n_envs = args.envs_per_gpu
@@ -164,10 +296,10 @@ def main():
     fading = [synth_fading(t, FADING_COLS) for t in range(3)]
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, device=local_rank)
     # replica ids are global: rank r owns [r*n_envs, (r+1)*n_envs)
-    from ranslice.sharding import shard_range, replica_seeds, max_over_ranks, aggregate_throughput
     first, count = shard_range(world * n_envs, rank, world)
     assert count == n_envs
     env.reset(seeds=replica_seeds(0, first, count))
+    n_tasks = n_envs * cfg.n_embb
 
     step_idx = 0
 
@@ -178,7 +310,30 @@ def main():
             env.step_resident()
             step_idx += 1
 
-    run(args.burn_in)
+    def block_mean_ue(k):
+        c_a = env.counters()
+        run(k)
+        env.synchronize()
+        c_b = env.counters()
+        return (c_b[3] - c_a[3]) / float(k * cfg.slots_per_step * n_tasks)
+
+    # ---- burn-in to the stationary UE population
+    burn_hist = []
+    if args.burn_in >= 0:
+        run(args.burn_in)
+    else:
+        prev = None
+        while step_idx < BURN_MAX:
+            cur = block_mean_ue(BURN_BLOCK)
+            burn_hist.append(round(cur, 4))
+            done = prev is not None and abs(cur - prev) <= 0.005 * prev
+            # every rank must run the same number of blocks: continue while ANY rank is still moving
+            if world > 1:
+                done = max_over_ranks(0.0 if done else 1.0, device='cuda') == 0.0
+            prev = cur
+            if done:
+                break
+    burn_steps = step_idx
     run(args.warmup)
     env.synchronize()
     c0 = env.counters()
@@ -210,13 +365,13 @@ def main():
     assert np.isfinite(out['reward']).all()
 
     elapsed = max_over_ranks(t1 - t0, device='cuda')
+    env.close()
 
     if rank == 0:
         value = aggregate_throughput(n_envs * args.steps, world, elapsed)
         # ---- roofline of the dominant kernel (per launch = one step of n_envs replicas)
         samples = (c1[0] - c0[0]) / args.steps          # fading samples read per launch
         ue_slots = (c1[3] - c0[3]) / args.steps
-        n_tasks = n_envs * cfg.n_embb
         mean_ue = ue_slots / (n_tasks * cfg.slots_per_step)
         nv = cfg.n_embb * 10 + cfg.n_mmtc * 3
         n_slices = cfg.n_embb + cfg.n_mmtc
@@ -225,17 +380,25 @@ def main():
         b_io = n_envs * (4.0 * n_slices + 4.0 * nv + 8.0 + 8.0 * n_slices)
         alg_bytes = b_fading + b_state + b_io
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-        traffic = None
-        valu_frac = None
+        roof = {
+            'bound': 'hbm', 'kernel': 'embb_step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+            'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
+            'traffic': None,   # not measured by this process (needs rocprofv3 --pmc); see profiled_traffic
+            'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'launches_timed': launches,
+            'bytes_per_env_step': alg_bytes / n_envs, 'mean_ues_per_slice': mean_ue,
+            'pf_iterations_per_env_step': (c1[2] - c0[2]) / args.steps / n_envs,
+        }
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     prof = json.load(f)
-                    traffic = prof.get('embb_step_kernel_bytes_per_launch')
-                    valu_frac = prof.get('valu_issue_frac')
+                # numbers of a separate rocprofv3 --pmc run of this command, NOT of this process
+                roof['profiled_traffic'] = {'bytes_per_launch': prof.get('embb_step_kernel_bytes_per_launch'),
+                                            'valu_issue_frac': prof.get('valu_issue_frac'),
+                                            'source': 'profiles/hbm_traffic.json (%s)' % prof.get('source', 'see file')}
             except Exception:
-                traffic = None
+                pass
         line = {
             'metric': 'env-steps/sec (batched RanSlice.step, scenario_0)',
             'value': value,
@@ -252,25 +415,24 @@ def main():
             'config': {
                 'workload': 'scenario_0 (200 PRBs, 5 eMBB slices, 50 slots/step), %d env replicas per GPU, step() only, '
                             'random multinomial actions generated on device' % n_envs,
-                'envs_per_gpu': n_envs, 'global_envs': world * n_envs, 'burn_in_steps': args.burn_in,
+                'envs_per_gpu': n_envs, 'global_envs': world * n_envs,
+                'burn_in_steps': burn_steps,
+                'burn_in': ('fixed' if args.burn_in >= 0 else
+                            'until stationary: mean UEs/slice per %d-step block %s' % (BURN_BLOCK, burn_hist)),
                 'fading': '3 synthetic traces x %d samples x 200 PRB, f64' % FADING_COLS,
                 'parallelism': 'replica-sharded x%d, no collective in step' % world,
                 'loop': 'hipGraph replay (rs_run_random)' if args.graph else 'one launch sequence per step from the host',
             },
-            'roofline': {
-                'bound': 'hbm', 'kernel': 'embb_step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'launches_timed': launches,
-                'bytes_per_env_step': alg_bytes / n_envs, 'mean_ues_per_slice': mean_ue,
-                'pf_iterations_per_env_step': (c1[2] - c0[2]) / args.steps / n_envs,
-                # what actually limits the kernel: f64 VALU issue share from the committed SQ counters
-                'valu_issue_frac_profiled': valu_frac,
-            },
+            'roofline': roof,
         }
         line['cpu_baseline'] = cpu_base
+        if world == 1 and not args.no_kbrl:
+            try:
+                line['kbrl'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100)
+            except Exception as e:  # the headline line must not depend on the agent's sub-record
+                line['kbrl'] = {'error': repr(e)}
         print(json.dumps(line), flush=True)
 
-    env.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -235,8 +235,12 @@ int kb_shared_commit(kb_handle* k, const int32_t* n_accept);
 
 /* sums over learners since kb_reset: [0] predicts, [1] mistakes, [2] insertions, [3] kernel evaluations */
 int kb_get_stats(kb_handle* k, uint64_t stats[4]);
+/* landmarks in every dictionary: i32 [n_envs][S] (one agent per replica) or [S] (shared dictionaries) */
+int kb_get_sizes(kb_handle* k, int32_t* m);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
 int kb_set_kernel_timing(kb_handle* k, int enable);
+/* waits for the agent's stream; returns RS_EOVERFLOW if any dictionary hit its capacity since kb_reset (the
+ * device-resident loop kb_step_resident does not check on its own) */
 int kb_synchronize(kb_handle* k);
 
 #ifdef __cplusplus

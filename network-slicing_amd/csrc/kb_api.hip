@@ -407,6 +407,15 @@ extern "C" int kb_get_stats(kb_handle* k, uint64_t stats[4]) {
     return RS_OK;
 }
 
+// landmarks held by every dictionary: [n_envs][S] (per-replica agents) or [S] (shared dictionaries)
+extern "C" int kb_get_sizes(kb_handle* k, int32_t* m_out) {
+    if (!k || !m_out) return RS_EINVAL;
+    HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipMemcpyAsync(m_out, k->K.m, sizeof(int32_t) * (size_t)k->n_dict, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    return RS_OK;
+}
+
 extern "C" int kb_set_kernel_timing(kb_handle* k, int enable) {
     if (!k) return RS_EINVAL;
     k->timing = enable != 0;

@@ -123,6 +123,13 @@ class VecKBRL:
         self._check(self.L.kb_get_stats(self.h, s))
         return [int(v) for v in s]
 
+    def dictionary_sizes(self):
+        """landmarks held by every dictionary: [n_envs, S] (one agent per replica) or [S] (shared)"""
+        n = self.S if self.cfg.shared_dictionary else self.n_envs * self.S
+        m = np.zeros(n, dtype=np.int32)
+        self._check(self.L.kb_get_sizes(self.h, m.ctypes.data_as(_ip)))
+        return m if self.cfg.shared_dictionary else m.reshape(self.n_envs, self.S)
+
     def set_kernel_timing(self, enable=True):
         self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))
 

@@ -32,7 +32,10 @@ def test_seeds_independent_of_sharding():
 
 def _worker(rank, world, port, q):
     import torch.distributed as dist
-    from ranslice.sharding import shard_range, replica_seeds, max_over_ranks, sum_over_ranks, aggregate_throughput
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from dist_util import max_over_ranks, sum_over_ranks
+    from ranslice.sharding import shard_range, replica_seeds, aggregate_throughput
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
