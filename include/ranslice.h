@@ -211,6 +211,9 @@ int kb_step_resident(kb_handle* k, rs_handle* env);
  * branch: 0 none, 1 projection, 2 dictionary grew. */
 int kb_predict(kb_handle* k, int e, int s, const double* x, int32_t* y_pred, double* f);
 int kb_update(kb_handle* k, int e, int s, const double* x, int32_t y, int32_t* branch, double* delta);
+/* GaussianKernel.k(x) (kernel.py:13-20) of the last kb_predict on learner (e, s): its kernel row, m entries (the third
+ * return value of GaussianKernel.predict, kernel.py:28).  row may be NULL to ask for m only. */
+int kb_get_kernel_row(kb_handle* k, int e, int s, int32_t* m, double* row);
 /* Dictionary of learner (e, s): m landmarks [m][dims+1], coeff [m], Kinv [m][m] (any may be NULL) */
 int kb_get_learner(kb_handle* k, int e, int s, int32_t* m, double* landmarks, double* coeff, double* kinv);
 /* margins / security_factors / current action [n_envs][S], adjusted [n_envs], accuracies [n_envs][S][n_prbs] */

@@ -20,14 +20,21 @@ class GaussianKernel:
         if self._owner is None:
             raise RuntimeError('GaussianKernel must be wrapped in a Projectron (device learner)')
         y = self._owner.predict(x)
-        return y, self._owner.f, None
+        return y, self._owner.f, self._owner._kernel_row()
 
     def k(self, x):
-        raise NotImplementedError('the kernel row stays on the device; use Projectron.predict')
+        """affinity row k_j = exp(-gamma ||l_j - x||^2) (kernel.py:13-20): computed by the device learner's predict
+        (the row is what it caches for the following update), fetched from there"""
+        if self._owner is None:
+            raise RuntimeError('GaussianKernel must be wrapped in a Projectron (device learner)')
+        self._owner.predict(x)
+        return self._owner._kernel_row()
 
 
 class SV:
-    """fixed-budget store (kernel.py:36-50): unused by KBRL (scenario_creator.py:217)"""
+    """fixed-budget store (kernel.py:36-50).  Never instantiated by any scenario (create_kbrl_agent uses SVvariable,
+    scenario_creator.py:217) and its own demo is broken in the reference (kernel.py:58 unpacks two of predict's
+    three values): out of scope (SURVEY.md §2 #8), kept as a name that says so."""
 
     def __init__(self, dimension, budget):
         raise NotImplementedError('SV (fixed budget) is out of scope: create_kbrl_agent uses SVvariable')

@@ -58,6 +58,10 @@ class Projectron:
     def _get(self, with_kinv=False):
         return self._agent.learner(self._e, self._s, with_kinv=with_kinv)
 
+    def _kernel_row(self):
+        """K_f of the last predict (projectron.py:34)"""
+        return self._agent.kernel_row(self._e, self._s)
+
     @property
     def counter(self):
         return self._get()['m'] if self._bound() else 0

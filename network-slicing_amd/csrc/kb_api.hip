@@ -101,6 +101,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.Kinv, ND * cap * cap, false);  // entries are written before they are read
     KA(K.kf, T * cap, true);
     KA(K.f_last, T, true);
+    KA(K.m_last, T, true);
     KA(K.tie_ctr, T, true);
     KA(K.seeds, N, true);
     KA(K.action, T, true);
@@ -171,8 +172,8 @@ static int kb_check(kb_handle* k) {
     HIPCHK(k, hipMemcpyAsync(e.data(), k->K.err, sizeof(int32_t) * e.size(), hipMemcpyDeviceToHost, k->stream));
     HIPCHK(k, hipStreamSynchronize(k->stream));
     for (size_t i = 0; i < e.size(); ++i)
-        if (e[i]) {
-            k->err = "KBRL dictionary capacity exceeded in agent " + std::to_string(i);
+        if (e[i] & ~8) {  // bit 8 = a dictionary is saturated (projects instead of growing): reported, not an error
+            k->err = "KBRL agent " + std::to_string(i) + ": internal error flag " + std::to_string(e[i]);
             return RS_EOVERFLOW;
         }
     return RS_OK;
@@ -336,6 +337,11 @@ extern "C" int kb_update(kb_handle* k, int e, int s, const double* x, int32_t y,
     double out[4] = {0, 0, 0, 0};
     int rc = kb_one(k, e, s, x, y, true, out);
     if (rc != RS_OK) return rc;
+    if (out[2] < 0.0) {
+        k->err = "kb_update: the dictionary changed since the kb_predict whose (f, K_f) this update would use "
+                 "(projectron.py:40-42 caches them; update_control / select_action grew the shared dictionary)";
+        return RS_ESTATE;
+    }
     if (branch) *branch = (int32_t)out[2];
     if (delta) *delta = out[3];
     return RS_OK;
@@ -404,6 +410,22 @@ extern "C" int kb_get_stats(kb_handle* k, uint64_t stats[4]) {
     HIPCHK(k, hipMemcpy(g, k->d_gstats, sizeof g, hipMemcpyDeviceToHost));
     stats[1] += g[1];
     stats[2] += g[2];
+    return RS_OK;
+}
+
+// GaussianKernel.k(x) of the last kb_predict on learner (e, s) (kernel.py:13-20): the cached row K_f, m entries
+extern "C" int kb_get_kernel_row(kb_handle* k, int e, int s, int32_t* m_out, double* row) {
+    if (!k || e < 0 || e >= k->cfg.n_envs || s < 0 || s >= k->cfg.n_slices) return RS_EINVAL;
+    HIPCHK(k, hipSetDevice(k->device));
+    const size_t task = (size_t)e * k->cfg.n_slices + s, cap = (size_t)k->cfg.capacity;
+    int32_t m = 0;
+    HIPCHK(k, hipMemcpyAsync(&m, k->K.m_last + task, sizeof m, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    if (m_out) *m_out = m;
+    if (row && m > 0) {
+        HIPCHK(k, hipMemcpyAsync(row, k->K.kf + task * cap, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, k->stream));
+        HIPCHK(k, hipStreamSynchronize(k->stream));
+    }
     return RS_OK;
 }
 

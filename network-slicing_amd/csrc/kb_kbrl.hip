@@ -47,6 +47,7 @@ struct KbState {
     double* Kinv;      // [T][cap][cap]
     double* kf;        // [T][cap]  K_f cached by the last predict (projectron.py:34)
     double* f_last;    // [T]
+    int32_t* m_last;   // [T] dictionary size the cached (f_last, kf) was computed against (Q12 guard)
     uint32_t* tie_ctr; // [T] Philox counter of the tie-break stream (kernel.py:26-27)
     uint64_t* seeds;   // [n_envs]
     int32_t* action;   // [n_envs][S]
@@ -209,10 +210,10 @@ __device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
     __syncthreads();
 }
 
-// Projectron.update (projectron.py:39-60) for x = (state, c/n), given sm.kf.  Returns the new m.
-// branch: 1 = projection onto the dictionary, 2 = dictionary grew.
-__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, int c, int y, Lds& sm,
-                            int* branch, double* delta_out) {
+// Projectron.update (projectron.py:39-60) for x = (sm.x[0..d-2], t_last), given its kernel column in sm.kf.
+// Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.
+__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, double t_last, int y,
+                            Lds& sm, int* branch, double* delta_out) {
     const int cap = D.cap;
     double* Kinv = K.Kinv + (size_t)dict * cap * cap;
     double* coeffg = K.coeff + (size_t)dict * cap;
@@ -243,10 +244,12 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
     delta = delta > 0.0 ? delta : 0.0;
     *delta_out = delta;
-    // Shared-dictionary mode pools every replica's samples into one dictionary, which therefore reaches
-    // the capacity: from then on a sample is always projected onto the span (the fixed-budget reading of
-    // Projectron).  Per-replica agents follow the reference (unbounded growth) and report the overflow.
-    const bool full = D.shared && (m >= cap || m >= 1024);
+    // A dictionary that has reached its capacity projects every further sample onto its span (the fixed-budget
+    // reading of Projectron) instead of growing as the reference's unbounded SVvariable would: learning goes on,
+    // nothing is dropped, and the replica is flagged (err bit 8, "saturated": reported by kb_get_sizes == capacity
+    // and by the host classes as a warning, not as an error).
+    const bool full = m >= cap;
+    if (delta > D.eta && full && threadIdx.x == 0) atomicOr(&K.err[err_env], 8);
     if (delta <= D.eta || full) {
         *branch = 1;
         for (int j = threadIdx.x; j < m; j += blockDim.x) {
@@ -259,14 +262,9 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         return m;
     }
     *branch = 2;
-    if (m >= cap || m >= 1024) {
-        if (threadIdx.x == 0) atomicOr(&K.err[err_env], 4);
-        __syncthreads();
-        return m;
-    }
     // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
     double* L = K.L + (size_t)dict * KB_DMAX * cap;
-    const double t = (double)c / (double)D.n_prbs;
+    const double t = t_last;
     if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < sm.capr) {
         // the landmark after this one opens a new 16-landmark tile: make it read as empty
         const int j = m + 1 + threadIdx.x;
@@ -371,9 +369,12 @@ __global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
     // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
     int c_from = y == 1 ? a_i : 0;
     const int c_to = y == 1 ? n : a_i;
+    bool rescore = true;
     while (c_from <= c_to) {
-        score_range(D, m, c_from, c_to, sm);
-        n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
+        if (rescore) {
+            score_range(D, m, c_from, c_to, sm);
+            n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
+        }
         // first candidate (in order) with f * y <= 0
         if (threadIdx.x == 0) sm.ired[2] = 0x7fffffff;
         __syncthreads();
@@ -398,10 +399,27 @@ __global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
         kernel_column(D, m, cstar, sm);
         int branch;
         double delta;
-        const int m_new = apply_update(D, K, dict, env, m, d, cstar, y, sm, &branch, &delta);
-        if (branch == 2 && m_new > m) n_grow += 1;
-        m = m_new;
+        const int m_new = apply_update(D, K, dict, env, m, d, (double)cstar / (double)n, y, sm, &branch, &delta);
         c_from = cstar + 1;
+        rescore = true;
+        if (branch == 2 && m_new > m) {
+            n_grow += 1;
+            // The dictionary grew by the landmark (state, c*/n) with coefficient y and nothing else changed, so
+            // the scores of the remaining candidates move by one kernel value each (same state: only the last
+            // coordinate differs) -- instead of a full rescoring.  The float32 regime of a
+            // single-landmark dictionary (kernel.py:16) keeps the full pass.
+            if (m >= 2) {
+                const double ts = (double)cstar / (double)n;
+                for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x) {
+                    const double dl = ts - (double)c / (double)n;
+                    sm.f[c] += (double)y * rs_exp(-D.gamma * (dl * dl));
+                }
+                n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0);
+                __syncthreads();
+                rescore = false;
+            }
+        }
+        m = m_new;
     }
     if (threadIdx.x == 0) {
         K.m[dict] = m;
@@ -419,7 +437,9 @@ struct SelArgs {
     const float* state;  // [n_envs][nv] new state
 };
 
-// per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63)
+// per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63): the smallest candidate the classifier
+// accepts.  The reference scans c = 0, 1, 2, ... and stops at the first +1 (about 15 candidates in); so does this:
+// batches of one 16-candidate strip per wave, in order, until a batch contains the answer.
 __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
     const KbDev& D = A.D;
     Lds sm = carve_lds(D.cap);
@@ -430,37 +450,40 @@ __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
     const int m = K.m[dict];
     if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
     __syncthreads();
-    prepare_operands(D, K, dict, m, d, sm);
-    score_range(D, m, 0, n, sm);
-    if (threadIdx.x == 0) sm.ired[0] = 0x7fffffff;
-    __syncthreads();
-    int firstc = 0x7fffffff;
-    if (m > 0)
-        for (int c = threadIdx.x; c <= n; c += blockDim.x)
-            if (sm.f[c] >= 0.0) { firstc = c; break; }  // positive, or a tie to be drawn
-    if (firstc != 0x7fffffff) atomicMin(&sm.ired[0], firstc);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int c = sm.ired[0];
-        int found = -1;
-        uint64_t n_pred = 0;
-        if (m == 0) {
-            n_pred = (uint64_t)n + 1;
-        } else {
-            int prev = -1;
-            // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
-            while (c != 0x7fffffff && c <= n) {
-                if (sm.f[c] > 0.0) { found = c; break; }
-                if (sm.f[c] == 0.0 && tie_draw(K, task, env, s) == 1) { found = c; break; }
-                prev = c;
-                int nx = 0x7fffffff;
-                for (int q = c + 1; q <= n; ++q)
-                    if (sm.f[q] >= 0.0) { nx = q; break; }
-                c = nx;
+    int found = -1;
+    uint64_t n_scored = 0;
+    if (m > 0) {
+        prepare_operands(D, K, dict, m, d, sm);
+        const int batch = 16 * (int)(blockDim.x >> 6);
+        for (int c0 = 0; c0 <= n && found < 0; c0 += batch) {
+            const int c1 = c0 + batch - 1 < n ? c0 + batch - 1 : n;
+            score_range(D, m, c0, c1, sm);
+            n_scored += (uint64_t)(c1 - c0 + 1);
+            if (threadIdx.x == 0) sm.ired[0] = 0x7fffffff;
+            __syncthreads();
+            const int c = c0 + (int)threadIdx.x;
+            if (c <= c1 && sm.f[c] >= 0.0) atomicMin(&sm.ired[0], c);  // positive, or a tie to be drawn
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                // walk the (rare) exact ties of this batch in order; each consumes one draw (kernel.py:26-27)
+                int cc = sm.ired[0], hit = -1;
+                while (cc <= c1) {
+                    if (sm.f[cc] > 0.0) { hit = cc; break; }
+                    if (sm.f[cc] == 0.0 && tie_draw(K, task, env, s) == 1) { hit = cc; break; }
+                    int nx = 0x7fffffff;
+                    for (int q = cc + 1; q <= c1; ++q)
+                        if (sm.f[q] >= 0.0) { nx = q; break; }
+                    cc = nx;
+                }
+                sm.ired[1] = hit;
             }
-            (void)prev;
-            n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
+            __syncthreads();
+            found = sm.ired[1];
+            __syncthreads();
         }
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
         const int offset = K.security[env * D.S + s];
         int act, margin = 0;
         if (found >= 0) {
@@ -474,7 +497,7 @@ __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
         K.margins[env * D.S + s] = margin;
         uint64_t* st = K.stats + (size_t)task * 4;
         st[0] += n_pred;
-        st[3] += ((uint64_t)n + 1) * (uint64_t)m;
+        st[3] += n_scored * (uint64_t)m;
     }
 }
 
@@ -678,7 +701,7 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
         if (f * (double)y <= 0.0) {  // still a mistake against the evolving dictionary
             int branch;
             double delta;
-            const int m_new = apply_update(D, K, s, 0, m, d, c, y, sm, &branch, &delta);
+            const int m_new = apply_update(D, K, s, 0, m, d, (double)c / (double)D.n_prbs, y, sm, &branch, &delta);
             n_mist += 1;
             if (branch == 2 && m_new > m) n_grow += 1;
             m = m_new;
@@ -736,6 +759,7 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
             kfg[0] = 0.0;
         }
         K.f_last[task] = f;
+        K.m_last[task] = m;
         A.out[0] = (double)y;
         A.out[1] = f;
         K.stats[(size_t)task * 4 + 0] += 1;
@@ -749,16 +773,21 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
     const int d = D.dims[s] + 1, cap = D.cap;
-    (void)env;
     int m = K.m[dt];
+    // Q12: Projectron.update uses the (f, K_f) cached by the predict that immediately preceded it.  Learners bound
+    // into a KBRL_Control share their dictionary with update_control / select_action, which may have grown it in
+    // between; the reference would then multiply arrays of different lengths (numpy raises).  Report it.
+    if (K.m_last[task] != m) {
+        if (threadIdx.x == 0) { A.out[2] = -1.0; A.out[3] = 0.0; }
+        return;
+    }
     const double f = K.f_last[task];
     if (!(f * (double)A.y <= 0.0)) {
         if (threadIdx.x == 0) { A.out[2] = 0.0; A.out[3] = 0.0; }
         return;
     }
-    // stage x, coefficients and the cached kernel row; apply_update works on (state, c/n) so the
-    // last coordinate is handed over through sm.lam/sm.x with n_prbs-independent arithmetic
-    for (int q = threadIdx.x; q < d; q += blockDim.x) sm.x[q] = A.x[q];
+    // stage x, the coefficients and the cached kernel row for apply_update
+    for (int q = threadIdx.x; q < d - 1; q += blockDim.x) sm.x[q] = A.x[q];
     for (int j = threadIdx.x; j < sm.capr; j += blockDim.x) {
         sm.co[j] = j < m ? K.coeff[(size_t)dt * cap + j] : 0.0;
         sm.kf[j] = j < (m > 0 ? m : 1) ? K.kf[(size_t)task * cap + j] : 0.0;
@@ -766,72 +795,13 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     __syncthreads();
     int branch;
     double delta;
-    // generic x: reuse apply_update with c/n == x[d-1] by passing n_prbs = 1 semantics
-    KbDev D1 = D;
-    // apply_update computes t = c / n_prbs; encode the exact last coordinate via a local copy
-    // of the grow step instead (below) when the dictionary grows.
-    double* Kinv = K.Kinv + (size_t)dt * cap * cap;
-    double dot;
-    if (m <= 1) {
-        float kinv = m == 0 ? 0.0f : 1.0f;
-        float ds = kinv * (float)(m == 0 ? 0.0 : sm.kf[0]);
-        if (threadIdx.x == 0) sm.ds[0] = (double)ds;
-        dot = (double)(float)(ds * (float)(m == 0 ? 0.0 : sm.kf[0]));
-        __syncthreads();
-    } else {
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        for (int i = wave; i < m; i += nw) {
-            double a = 0.0;
-            for (int j = lane; j < m; j += 64) a += Kinv[(size_t)i * cap + j] * sm.kf[j];
-            for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
-            if (lane == 0) sm.ds[i] = a;
-        }
-        __syncthreads();
-        double p = 0.0;
-        for (int j = threadIdx.x; j < m; j += blockDim.x) p += sm.ds[j] * sm.kf[j];
-        dot = block_sum(p, sm);
-    }
-    delta = 1.0 - dot;
-    delta = delta > 0.0 ? delta : 0.0;
-    (void)D1;
-    if (delta <= D.eta) {
-        branch = 1;
-        for (int j = threadIdx.x; j < m; j += blockDim.x) {
-            double nc = sm.co[j] + (double)A.y * sm.ds[j];
-            if (m == 1) nc = (double)(float)nc;
-            K.coeff[(size_t)dt * cap + j] = nc;
-        }
-    } else if (m >= cap || m >= 1024) {
-        branch = 2;
-        if (threadIdx.x == 0) atomicOr(&K.err[task / D.S], 4);
-    } else {
-        branch = 2;
-        double* L = K.L + (size_t)dt * KB_DMAX * cap;
-        if (threadIdx.x == 0) {
-            for (int q = 0; q < d; ++q) L[(size_t)q * cap + m] = sm.x[q];
-            K.coeff[(size_t)dt * cap + m] = (double)A.y;
-            sm.ds[m] = -1.0;
-        }
-        __syncthreads();
-        if (m == 0) {
-            if (threadIdx.x == 0) Kinv[0] = 1.0;
-        } else {
-            const int m1 = m + 1;
-            for (int e = threadIdx.x; e < m1 * m1; e += blockDim.x) {
-                const int i = e / m1, j = e - i * m1;
-                double old = (i < m && j < m) ? Kinv[(size_t)i * cap + j] : 0.0;
-                Kinv[(size_t)i * cap + j] = old + (sm.ds[i] * sm.ds[j]) / delta;
-            }
-        }
-        m += 1;
-    }
-    __syncthreads();
+    const int m_new = apply_update(D, K, dt, env, m, d, A.x[d - 1], A.y, sm, &branch, &delta);
     if (threadIdx.x == 0) {
-        K.m[dt] = m;
+        K.m[dt] = m_new;
         A.out[2] = (double)branch;
         A.out[3] = delta;
         K.stats[(size_t)task * 4 + 1] += 1;
-        if (branch == 2) K.stats[(size_t)task * 4 + 2] += 1;
+        if (branch == 2 && m_new > m) K.stats[(size_t)task * 4 + 2] += 1;
     }
 }
 
@@ -842,6 +812,7 @@ __global__ void kb_reset_kernel(KbDev D, KbState K, const int32_t* init_action, 
     if (i < T) {  // per-learner state; the dictionaries (K.m: one per learner, or one per slice when shared) are
                   // cleared by kb_reset with their own count
         K.f_last[i] = 0.0;
+        K.m_last[i] = 0;
         K.tie_ctr[i] = 0;
         K.action[i] = init_action[i];
         K.security[i] = init_sec[i];

@@ -49,11 +49,11 @@ class KBRL_Control:
     # ---- public fields of the reference, read from the device
     @property
     def security_factors(self):
-        return self._dev.control()['security_factors'][0].astype(np.int16)
+        return self._dev.control(with_accuracies=False)['security_factors'][0].astype(np.int16)
 
     @property
     def margins(self):
-        return self._dev.control()['margins'][0].astype(np.int16)
+        return self._dev.control(with_accuracies=False)['margins'][0].astype(np.int16)
 
     @property
     def accuracies(self):
@@ -103,6 +103,13 @@ class KBRL_Control:
             resources_history[i] = action.sum()
             adjusted_actions[i] = self.adjusted
             hits_history[:, i] = hits
+        sizes = self._dev.dictionary_sizes()
+        if (sizes >= self._dev.capacity).any():
+            import warnings
+            warnings.warn('KBRL dictionaries %s reached their capacity of %d landmarks: further samples were projected '
+                          'onto the span instead of growing the dictionary (the reference grows without bound); pass a '
+                          'larger capacity to KBRL_Control / create_kbrl_agent'
+                          % (np.nonzero(sizes[0] >= self._dev.capacity)[0].tolist(), self._dev.capacity))
         print('mean resources = {}'.format(resources_history.mean()))
         print('total violations = {}'.format(violation_history.sum()))
         print('mean adjusted = {}'.format(adjusted_actions.mean()))

@@ -104,15 +104,26 @@ class VecKBRL:
                                               kinv.ctypes.data_as(_dp) if with_kinv else None))
         return dict(m=m, landmarks=L, coeff=co, kinv=kinv)
 
-    def control(self):
+    def control(self, with_accuracies=True):
+        """margins / security_factors / action [N, S], adjusted [N] and (optionally: it is the big one) the
+        accuracy tables [N, S, n_prbs]"""
         T = (self.n_envs, self.S)
         margins, security, action = (np.zeros(T, dtype=np.int32) for _ in range(3))
         adjusted = np.zeros(self.n_envs, dtype=np.int32)
-        acc = np.zeros(T + (self.n_prbs,))
+        acc = np.zeros(T + (self.n_prbs,)) if with_accuracies else None
         self._check(self.L.kb_get_control(self.h, margins.ctypes.data_as(_ip), security.ctypes.data_as(_ip),
                                           action.ctypes.data_as(_ip), adjusted.ctypes.data_as(_ip),
-                                          acc.ctypes.data_as(_dp)))
+                                          acc.ctypes.data_as(_dp) if with_accuracies else None))
         return dict(margins=margins, security_factors=security, action=action, adjusted=adjusted, accuracies=acc)
+
+    def kernel_row(self, e, s):
+        """GaussianKernel.k(x) of the last predict(e, s, x) (kernel.py:13-20)"""
+        m = C.c_int32()
+        self._check(self.L.kb_get_kernel_row(self.h, e, s, C.byref(m), None))
+        row = np.zeros(max(m.value, 1))
+        if m.value:
+            self._check(self.L.kb_get_kernel_row(self.h, e, s, C.byref(m), row.ctypes.data_as(_dp)))
+        return row[:m.value] if m.value else np.array([0.0])  # empty dictionary: K_f = [0.0] (projectron.py:35-36)
 
     def set_adjusted(self, adjusted):
         a = np.ascontiguousarray(adjusted, dtype=np.int32).reshape(self.n_envs)

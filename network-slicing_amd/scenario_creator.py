@@ -50,8 +50,10 @@ def create_env(rng, n, slots_per_step=50, propagation_type='macro_cell_urban_2GH
     return make('gym_ran_slice:RanSlice-v1', node_b=node, penalty=penalty)
 
 
-def create_kbrl_agent(rng, n, accuracy_range=[0.99, 0.999], device=0):
-    """scenario_creator.py:197-238: one Projectron learner per slice, random initial action/offset"""
+def create_kbrl_agent(rng, n, accuracy_range=[0.99, 0.999], device=0, capacity=1024):
+    """scenario_creator.py:197-238: one Projectron learner per slice, random initial action/offset.
+    capacity: landmarks a learner's dictionary can hold (the authors' 50,400-step runs end at 45-305 on average,
+    1,025 at most); a full dictionary projects instead of growing and KBRL_Control.run warns."""
     sc = scenarios[n]
     n_prbs, n_embb, n_mmtc = sc['n_prbs'], sc['n_embb'], sc['n_mmtc']
     embb_dim, mmtc_dim = len(state_variables_embb), len(state_variables_mmtc)
@@ -70,4 +72,5 @@ def create_kbrl_agent(rng, n, accuracy_range=[0.99, 0.999], device=0):
         learners.append(Learner(algorithm, slice(i, i + mmtc_dim), initial_action, sec))
         i += mmtc_dim
     seed = int(rng.integers(0, 2 ** 63 - 1))
-    return KBRL_Control(learners, n_prbs, alfa=alfa, accuracy_range=accuracy_range, device=device, seed=seed)
+    return KBRL_Control(learners, n_prbs, alfa=alfa, accuracy_range=accuracy_range, device=device, seed=seed,
+                        capacity=capacity)

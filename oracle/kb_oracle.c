@@ -191,16 +191,15 @@ int kbo_update(kb_oracle* a, int s, const double* x, int y, double* delta_out) {
     double delta = Kii - dot;
     delta = delta > 0 ? delta : 0;
     if (delta_out) *delta_out = delta;
-    if (delta <= a->eta) {
+    /* build-defined: a dictionary at its capacity projects every further sample onto its span instead of growing
+     * (the reference's SVvariable grows without bound); err = 2 records that it happened */
+    if (delta > a->eta && m >= l->cap) a->err = 2;
+    if (delta <= a->eta || m >= l->cap) {
         /* SVvariable.update (projectron.py:13-14); the single-landmark coeff array is float32 */
         if (m == 1)
             l->coeff[0] = (double)(float)(l->coeff[0] + (double)y * l->dstar[0]);
         else
             for (int i = 0; i < m; ++i) l->coeff[i] += (double)y * l->dstar[i];
-        return 1;
-    }
-    if (m >= l->cap) {
-        a->err = 2;
         return 1;
     }
     /* SVvariable.extend / insert (projectron.py:7-21) */

@@ -106,18 +106,20 @@ def test_ue_capacity_overflow_is_reported(golden_dir):
     env.close()
 
 
-def test_kbrl_capacity_overflow_is_reported():
+def test_kbrl_full_dictionary_saturates_without_error():
+    """a full dictionary projects further samples instead of growing (build-defined; the reference's dictionary is
+    unbounded): learning goes on, nothing raises, and the size report shows the saturation"""
     from ranslice.kbrl_dev import VecKBRL
     ag = VecKBRL(1, [3], 100, capacity=4)
     ag.reset([[5]], [[2]])
     rng = np.random.default_rng(0)
-    with pytest.raises(_lib.RanSliceError) as ei:
-        for i in range(200):
-            x = rng.random(4) * 8.0  # far-apart points: every mistake grows the dictionary
-            y = 1 if i % 2 else -1
-            ag.predict(0, 0, x)
-            ag.update(0, 0, x, y)
-    assert ei.value.code == _lib.RS_EOVERFLOW
+    for i in range(200):
+        x = rng.random(4) * 8.0  # far-apart points: every mistake would grow the dictionary
+        y = 1 if i % 2 else -1
+        ag.predict(0, 0, x)
+        ag.update(0, 0, x, y)
+    assert ag.dictionary_sizes().tolist() == [[4]]
+    ag.synchronize()
     ag.close()
 
 

@@ -14,6 +14,9 @@ from ranslice.config import make_config
 from ranslice.fading import synth_fading
 
 pytestmark = pytest.mark.gpu
+# oracle workers are SPAWNED: forking a process whose HIP runtime is already initialised is not safe
+import multiprocessing as _mp  # noqa: E402
+_SPAWN = _mp.get_context('spawn')
 
 ACTION_SEED = 2024  # bench.py's script seed
 N_FULL = 4096
@@ -80,7 +83,7 @@ def test_bench_path_steady_state_vs_oracle():
     from ranslice.vec_env import VecRanSlice
     steps = 500
     cfg = make_config(0, n_envs=N_FULL)
-    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
         fut = ex.map(_oracle_script_run, [(0, r, r, steps, COLS) for r in SAMPLE], chunksize=1)
         env = VecRanSlice(n_envs=N_FULL, cfg=cfg, fading=_fading())
         env.reset()
@@ -137,7 +140,7 @@ def test_soak_every_replica(golden_dir, scenario, n, steps):
     rng = np.random.default_rng(seed0)
     ns = cfg.n_embb + cfg.n_mmtc
     acts = [_actions(rng, n, ns, cfg.n_prbs, i) for i in range(steps)]
-    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
         fut = ex.map(_oracle_acts_run, [(scenario, seed0 + r, [a[r] for a in acts], True) for r in range(n)],
                      chunksize=8)
         env = VecRanSlice(n_envs=n, cfg=cfg, fading=[g['t0'], g['t1'], g['t2']], seed=seed0)

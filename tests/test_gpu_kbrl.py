@@ -13,6 +13,9 @@ from oracle import pyoracle as po
 from ranslice.config import make_config
 
 pytestmark = pytest.mark.gpu
+# oracle workers are SPAWNED: forking a process whose HIP runtime is already initialised is not safe
+import multiprocessing as _mp  # noqa: E402
+_SPAWN = _mp.get_context('spawn')
 TOL = 1e-9
 
 
@@ -254,7 +257,7 @@ def test_full_size_closed_loop_vs_oracle():
     sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
     sample = [0, 1, 2, 3, 15, 16, 63, 64, 100, 255, 256, 777, 1023, 1024, 2000, 2047, 2048, 3000, 3333, 4000, 4093,
               4094, 4095, 1234]
-    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
         fut = ex.map(_oracle_closed_loop, [(scenario, 300 + r, 7 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
                      chunksize=1)
         env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)],
@@ -289,3 +292,71 @@ def test_full_size_closed_loop_vs_oracle():
             assert (h[2][k] == lab).all(), ('labels', r, i)
             assert (h[3][k] == na).all(), ('selected action', r, i, h[3][k], na)
         assert sizes[k] == m_ref, (r, sizes[k], m_ref)
+
+
+def test_kernel_row_and_stale_cache_guard(golden_dir):
+    """GaussianKernel.k / predict()[2] (kernel.py:13-28) are served from the row the device learner caches, and
+    Projectron.update refuses to use that cache once the dictionary has changed under it (reference Q12: numpy would
+    raise on the length mismatch)"""
+    import scenario_creator as sc
+    from ranslice import _lib
+    rng = np.random.default_rng(3)
+    agent = sc.create_kbrl_agent(rng, 0, capacity=64)
+    alg = agent.learners[0].algorithm
+    xs = rng.random((30, 11))
+    for i in range(30):
+        y = 1 if xs[i].sum() > 5.5 else -1
+        alg.predict(xs[i])
+        alg.update(xs[i], y)
+    x = rng.random(11)
+    yp, f, krow = alg.kernel.predict(x)
+    L, co = alg.sv.landmarks, alg.sv.coeff
+    want = np.exp(-1.0 * ((np.atleast_2d(L) - x) ** 2).sum(axis=1))
+    np.testing.assert_allclose(krow, want, rtol=1e-12)
+    assert f == pytest.approx(float(want @ co), rel=1e-9, abs=1e-12) and yp == (1 if f > 0 else -1)
+    np.testing.assert_allclose(alg.kernel.k(x), want, rtol=1e-12)
+    assert alg.kernel.k_eval(x, x) == 1.0
+    # update_control grows learner 0's dictionary between a predict and its update: the update must refuse
+    alg.predict(x)
+    m0 = alg.counter
+    state = np.zeros(50, dtype=np.float32)
+    state[:10] = 0.9
+    for _ in range(3):
+        agent.update_control(state, np.full(5, 20, dtype=np.int16), -np.ones(5, dtype=np.int32))
+        state[:10] -= 0.2
+    assert alg.counter > m0
+    with pytest.raises(_lib.RanSliceError) as e:
+        alg.update(x, -1 if f > 0 else 1)
+    assert e.value.code == _lib.RS_ESTATE
+
+
+def test_saturated_dictionary_projects(golden_dir):
+    """a dictionary at its capacity keeps learning by projection (build-defined; the reference grows without bound):
+    no error, sizes stay at the capacity, and the device agent still agrees with the oracle agent of the same
+    capacity, decision for decision"""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g10_kbrl_s0')
+    dims, n_prbs = _dims(0)
+    cap = 6
+    ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=cap)
+    ag.reset(g['init_action'][None], g['init_sec'][None])
+    oa = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']), capacity=cap)
+    oa.set_seed(0)
+    steps = len(g['state'])
+    for i in range(steps):
+        hits = ag.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        oh = oa.update_control(g['state'][i], g['action_in'][i], g['labels'][i])
+        assert (hits[0] == oh).all(), i
+        nxt = g['state'][i + 1] if i + 1 < steps else g['final_state']
+        act, adj = ag.select_action(nxt[None])
+        oact, oadj = oa.select_action(nxt)
+        oa.adjusted = oadj
+        ag.set_adjusted([oadj])
+        assert (act[0] == oact).all() and adj[0] == oadj, i
+    sizes = ag.dictionary_sizes()
+    assert sizes.max() == cap and (sizes <= cap).all()
+    assert [oa.m(s) for s in range(len(dims))] == sizes[0].tolist()
+    ag.synchronize()   # saturation is not an error
+    for s in range(len(dims)):
+        np.testing.assert_allclose(ag.learner(0, s)['coeff'], oa.coeff(s), rtol=1e-7, atol=1e-9)
+    ag.close()

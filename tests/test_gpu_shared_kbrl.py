@@ -121,24 +121,12 @@ def test_dictionaries_do_not_depend_on_sharding():
         p.close()
 
 
-def test_two_shared_agents_in_one_process_agree():
-    """two identical shared-dictionary loops side by side (two environments, two agents, one process): the same
-    observations, hits, dictionaries and actions at every step.  Guards the per-handle memory layout: a reset
-    that wrote one dictionary counter per learner into the per-slice array used to corrupt neighbouring
-    allocations, which showed up as run-to-run differences at 4096 replicas."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = subprocess.run([sys.executable, os.path.join(root, 'tests', 'shared_determinism_check.py'), '1536', '15'],
-                         capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert 'no difference' in out.stdout
-
-
 def test_shared_loop_run_to_run_determinism():
-    """(was tests/shared_determinism_check.py) two identical shared-dictionary closed loops at 2048 replicas of
-    scenario_2 (BASELINE config 4's per-GPU workload shape): observations, hits, dictionary sizes, coefficients
-    and actions identical at every step.  Caught the kb_reset overrun of round 1 (commit 9726634)."""
+    """(was tests/shared_determinism_check.py) two identical shared-dictionary closed loops side by side (two
+    environments, two agents, one process) at 2048 replicas of scenario_2 (BASELINE config 4's per-GPU workload
+    shape): observations, hits, dictionary sizes, coefficients and actions identical at every step.  Guards the
+    per-handle memory layout: a reset that wrote one dictionary counter per learner into the per-slice array used to
+    corrupt neighbouring allocations (commit 9726634), which showed up as run-to-run differences."""
     from ranslice.config import EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
     from ranslice.fading import synth_fading
     from ranslice.kbrl_dev import SharedVecKBRL
