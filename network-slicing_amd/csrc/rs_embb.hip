@@ -456,6 +456,38 @@ __device__ __forceinline__ void walker_advance(int& findex, int& fstep, int Tn, 
     }
 }
 
+// Response sums of spans wider than RS_WIDE_SPAN RBs (an agent's allocation: ~180 RBs in one slice).  In a team such a
+// span would keep 8 lanes busy with 12-23 sigmoids each in a row; here the WHOLE wave evaluates it, one RB per lane
+// and pass, into the wave's LDS buffer `wmi`, and one team adds the buffer up in numpy's order.  Out of line on
+// purpose: random-action batches never come here, and in line its registers cost the hot loop spills.
+#define RS_WIDE_SPAN 64
+#define RS_WIDE_MAX 192   // wider spans (193..256 RBs) take the team path
+__device__ __noinline__ double wide_response(const RsDev* D, const double* fad, double* wmi, const double* nom_wave,
+                                             bool mine, int rbs, int span_col, int mod) {
+    const int lane = (int)(threadIdx.x & 63u);
+    double out = 0.0;
+    unsigned long long wm = __builtin_amdgcn_ballot_w64(mine);
+    while (wm != 0ull) {
+        const int ol = __builtin_ctzll(wm);  // the span's owner lane (uniform)
+        wm &= wm - 1ull;
+        const int n = __builtin_amdgcn_readlane(rbs, ol);
+        const int c0 = __builtin_amdgcn_readlane(span_col, ol);
+        const int md = __builtin_amdgcn_readlane(mod, ol);
+        const double nom = nom_wave[ol];
+        const double x0 = D->mi_x0[md], kk = D->mi_k[md];
+        for (int k0 = 0; k0 < n; k0 += 64) {
+            const int k = k0 + lane;
+            if (k < n) wmi[k] = rs_sigmoid(fad[c0 + k] + nom, x0, kk);
+        }
+        __builtin_amdgcn_wave_barrier();
+        const double sv = team_pairwise(n, lane & 7, lane < 8, [&](int i) { return wmi[i]; });
+        const double got = bperm(sv, 0);
+        if (lane == ol) out = got;
+        __builtin_amdgcn_wave_barrier();
+    }
+    return out;
+}
+
 // 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
 // instances are test tooling: they keep the register budget of 3 waves per SIMD.
 template <int G, bool TRACE>
@@ -477,6 +509,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     __shared__ int L_lut[RS_LUT_MAX];        // e_snr -> modulation << 24 | mcs << 16 | rate (mcs_rate_vs_error)
     __shared__ double L_ref[32];             // MCS reference SNR (estimate_rx_prob)
     __shared__ int L_task[TPB][4];           // per task: cbr_at, vbr_at, slice draw counter, next UE serial
+    __shared__ double W_mi[4][RS_WIDE_MAX];  // per wave: MI values of one WIDE span (response of 65..192 RBs); sized so
+                                             // that a block stays within 25 LDS granules of 1280 B: 5 blocks per CU
     const RsDev* __restrict__ D = A.D;
     const int tid = (int)threadIdx.x;
     if (tid < RS_LUT_MAX) L_lut[tid] = tid < D->lut_n ? ((D->mcs_mod[D->lut_mcs[tid]] << 24) | (D->lut_mcs[tid] << 16) | D->lut_rate[tid]) : 0;
@@ -1094,12 +1128,15 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
             // R_j: it evaluates the sigmoid of its elements one after the other and adds them in numpy's order, the
             // team meets for the tree and the remainder.  No per-RB values are stored anywhere.
             double sum_rx = 0.0;
+            const int span_col = col + prb_lo + prb_i;  // first element of my span in the fading table
+            constexpr int WIDE = RS_WIDE_SPAN;
+            const bool wide_sp = needed && rbs > WIDE && rbs <= RS_WIDE_MAX;
+            if (wave_any(wide_sp)) sum_rx = wide_response(D, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
             {
-                const unsigned long long wmask = __builtin_amdgcn_ballot_w64(needed);
+                const unsigned long long wmask = __builtin_amdgcn_ballot_w64(needed && !wide_sp);
                 const int n_sp = __popcll(wmask);
                 const int my_sp = __popcll(wmask & ((1ull << lane) - 1ull));   // my span's index in the wave
                 const int team = lane >> 3, j = lane & 7;
-                const int span_col = col + prb_lo + prb_i;                      // first element of my span in the table
                 unsigned long long rest = wmask;
                 for (int round = 0; round * 8 < n_sp; ++round) {
                     // owners of this round's 8 spans (uniform), then mine by team
@@ -1124,7 +1161,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                         return single ? x : rs_sigmoid(x, x0, kk);
                     });
                     const double got = bperm(sv, (my_sp & 7) << 3);
-                    if ((my_sp >> 3) == round) sum_rx = got;
+                    if (needed && !wide_sp && (my_sp >> 3) == round) sum_rx = got;
                 }
             }
             SEC_MARK(10)
