@@ -236,6 +236,18 @@ int kb_shared_scan(kb_handle* k, const float* state, const int32_t* action, cons
 int kb_shared_apply(kb_handle* k, const int32_t* counts, const double* props, int32_t budget);
 int kb_shared_commit(kb_handle* k, const int32_t* n_accept);
 
+/* The same learning step with the exchange kept on the device: every round scans, packs this rank's proposals,
+ * all-gathers the blocks of all ranks with ncclAllGather (RCCL, bound at run time, on the agent's stream), merges by
+ * global replica id, applies and commits -- until no rank proposes anything or max_rounds rounds were made
+ * (rounds_out).  Only a 4-byte "anything left" flag per round returns to the host.  kb_comm_unique_id: 128 bytes
+ * from ncclGetUniqueId, generated by ONE rank and handed to the others by the launcher; kb_comm_init joins the
+ * communicator (rank = the handle's index among the `world` agents that share their dictionaries; kb_config.first_env
+ * must be rank * n_envs).  Without kb_comm_init the handle is its own world (no RCCL needed). */
+int kb_comm_unique_id(void* id128);
+int kb_comm_init(kb_handle* k, const void* id128, int rank, int world);
+int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t budget,
+                   int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
+
 /* sums over learners since kb_reset: [0] predicts, [1] mistakes, [2] insertions, [3] kernel evaluations */
 int kb_get_stats(kb_handle* k, uint64_t stats[4]);
 /* landmarks in every dictionary: i32 [n_envs][S] (one agent per replica) or [S] (shared dictionaries) */

@@ -660,6 +660,80 @@ __global__ void shared_collect_kernel(KbDev D, const float* state, const int32_t
     counts[s] = cnt;
 }
 
+// ---- device-resident exchange (kb_shared_step): the proposal block a rank contributes to the all-gather is
+//   block = [S doubles: proposers per slice] [S][budget][KB_PROP_W] proposals
+__global__ void shared_collect_block_kernel(KbDev D, const float* state, const int32_t* labels, const int32_t* cstar,
+                                            int budget, double* block) {
+    const int s = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int cnt = 0;
+    const int d = D.dims[s] + 1;
+    double* props = block + D.S;
+    for (int env = 0; env < D.n_envs; ++env) {
+        const int c = cstar[env * D.S + s];
+        if (c < 0) continue;
+        if (cnt < budget) {
+            double* p = props + ((size_t)s * budget + cnt) * KB_PROP_W;
+            p[0] = (double)(D.first_env + env);
+            p[1] = (double)(c * 4 + (labels[env * D.S + s] == 1 ? 1 : 0));
+            for (int q = 0; q < d - 1; ++q) p[2 + q] = (double)state[(size_t)env * D.nv + D.off[s] + q];
+        }
+        cnt += 1;
+    }
+    block[s] = (double)cnt;
+}
+
+// Merge the gathered blocks of all W ranks for slice s = blockIdx.x: ascending global replica id, the first `budget`
+// (the rule of kbrl_dev.merge_proposals, evaluated where the data is).  taken[s] = how many of rank `me`'s proposers
+// made it; total[0] += proposers of all ranks (0 ends the learning step).
+__global__ __launch_bounds__(256) void shared_merge_kernel(KbDev D, const double* gathered, int W, int me, int budget,
+                                                           size_t blk_doubles, double* mprops, int32_t* mcounts,
+                                                           int32_t* taken, int32_t* total) {
+    const int s = blockIdx.x;
+    __shared__ int n_of[64];   // candidates rank w contributes
+    __shared__ int off_of[65];
+    __shared__ int s_taken, s_all;
+    if (threadIdx.x == 0) {
+        int o = 0, all = 0;
+        for (int w = 0; w < W; ++w) {
+            const int c = (int)gathered[(size_t)w * blk_doubles + s];
+            all += c;
+            n_of[w] = c < budget ? c : budget;
+            off_of[w] = o;
+            o += n_of[w];
+        }
+        off_of[W] = o;
+        s_taken = 0;
+        s_all = all;
+    }
+    __syncthreads();
+    const int n = off_of[W];
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        int w = 0;
+        while (e >= off_of[w + 1]) ++w;
+        const int i = e - off_of[w];
+        const double* p = gathered + (size_t)w * blk_doubles + D.S + ((size_t)s * budget + i) * KB_PROP_W;
+        const double id = p[0];
+        int rank = 0;
+        for (int w2 = 0; w2 < W; ++w2)
+            for (int i2 = 0; i2 < n_of[w2]; ++i2) {
+                const double id2 = gathered[(size_t)w2 * blk_doubles + D.S + ((size_t)s * budget + i2) * KB_PROP_W];
+                rank += (id2 < id || (id2 == id && (w2 < w || (w2 == w && i2 < i)))) ? 1 : 0;
+            }
+        if (rank < budget) {
+            double* q = mprops + ((size_t)s * budget + rank) * KB_PROP_W;
+            for (int k = 0; k < KB_PROP_W; ++k) q[k] = p[k];
+            if (w == me) atomicAdd(&s_taken, 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mcounts[s] = n < budget ? n : budget;
+        taken[s] = s_taken;
+        atomicAdd(total, s_all);
+    }
+}
+
 // the first n_accept[s] local proposers of slice s (replica order) had their sample applied: move on
 __global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_t* n_accept, int32_t* cursor) {
     const int s = blockIdx.x;

@@ -184,21 +184,50 @@ def merge_proposals(all_counts, all_props, budget):
 
 class SharedVecKBRL(VecKBRL):
     """One KBRL dictionary per slice index, learned from every replica of every rank (build-defined
-    extension; the reference trains one independent agent per run).  `exchange(counts, props)` must
-    return the lists of all ranks stacked on a leading axis ([W][S], [W][S][budget][PROP_W]) and this
-    rank's index; the default is a single rank.  With torch.distributed it is one all_gather over RCCL
-    (`rccl_exchange`)."""
+    extension; the reference trains one independent agent per run).
+
+    Default: the whole learning step runs on the device (kb_shared_step) -- scan, all-gather of the proposal blocks
+    over RCCL (bound directly by libranslice.so, on the agent's HIP stream), merge, apply, commit.  One process per
+    GPU joins the communicator with `comm_init(unique_id, rank, world)`; `SharedVecKBRL.unique_id()` is generated by
+    one rank and distributed by whatever launched the ranks.  Without comm_init the handle is its own world.
+
+    `exchange(counts, props)` (optional) replaces the device exchange by a host callback that must return the lists of
+    all ranks stacked on a leading axis ([W][S], [W][S][budget][PROP_W]) and this rank's index: used to run several
+    handles side by side in ONE process (tests) and to pin the merge rule on CPU (merge_proposals, gloo test)."""
 
     def __init__(self, n_envs, dims, n_prbs, budget=64, max_rounds=4, exchange=None, **kw):
         super().__init__(n_envs, dims, n_prbs, shared=True, **kw)
         self.budget, self.max_rounds = budget, max_rounds
-        self.exchange = exchange or (lambda c, p: (c[None], p[None], 0))
+        self.exchange = exchange
+        self.rounds_last = 0
+
+    @staticmethod
+    def unique_id():
+        """128 opaque bytes (ncclGetUniqueId) for comm_init; call on ONE rank"""
+        buf = C.create_string_buffer(128)
+        rc = _lib.load().kb_comm_unique_id(buf)
+        if rc != 0:
+            raise _lib.RanSliceError(rc, 'kb_comm_unique_id failed (librccl.so missing?)')
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        if self.cfg.first_env != rank * self.n_envs:
+            raise ValueError('first_env must be rank * n_envs (contiguous replica shards)')
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self.L.kb_comm_init(self.h, buf, int(rank), int(world)))
 
     def update_control(self, state, action, labels):
         state = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, self.nv)
         action = np.ascontiguousarray(action, dtype=np.int32).reshape(self.n_envs, self.S)
         labels = np.ascontiguousarray(labels, dtype=np.int32).reshape(self.n_envs, self.S)
         hits = np.zeros((self.n_envs, self.S), dtype=np.int32)
+        if self.exchange is None:
+            rounds = C.c_int32()
+            self._check(self.L.kb_shared_step(self.h, state.ctypes.data_as(_fp), action.ctypes.data_as(_ip),
+                                              labels.ctypes.data_as(_ip), self.budget, self.max_rounds,
+                                              hits.ctypes.data_as(_ip), C.byref(rounds)))
+            self.rounds_last = rounds.value
+            return hits
         counts = np.zeros(self.S, dtype=np.int32)
         props = np.zeros((self.S, self.budget, PROP_W))
         self.rounds_last = 0
@@ -219,19 +248,3 @@ class SharedVecKBRL(VecKBRL):
             self._check(self.L.kb_shared_commit(self.h, acc.ctypes.data_as(_ip)))
             self.rounds_last = rnd + 1
         return hits
-
-
-def rccl_exchange(device='cuda'):
-    """exchange() over torch.distributed (backend nccl = RCCL on ROCm): one all_gather of the proposal block"""
-    import torch
-    import torch.distributed as dist
-
-    def ex(counts, props):
-        W, me = dist.get_world_size(), dist.get_rank()
-        blk = torch.from_numpy(np.concatenate([counts.astype(np.float64), props.ravel()])).to(device)
-        out = [torch.empty_like(blk) for _ in range(W)]
-        dist.all_gather(out, blk)
-        arr = np.stack([o.cpu().numpy() for o in out])
-        S = len(counts)
-        return arr[:, :S].astype(np.int32), arr[:, S:].reshape((W,) + props.shape), me
-    return ex

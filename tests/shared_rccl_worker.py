@@ -1,0 +1,77 @@
+"""One rank of the RCCL test of the shared-dictionary exchange (tests/test_gpu_shared_kbrl.py starts `world` of these
+on the same box).  usage: shared_rccl_worker.py <rank> <world> <id_file> <n_per_rank> <steps>
+Rank 0 writes the ncclUniqueId to <id_file>; every rank learns from its contiguous shard of one synthetic batch and
+prints a hash of the (replicated) dictionaries."""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
+from ranslice.kbrl_dev import SharedVecKBRL  # noqa: E402
+
+
+def batch(n_total, steps, seed=8):
+    """the synthetic (state, action, labels, next state) sequence every layout of the test learns from"""
+    rng = np.random.default_rng(seed)
+    ia = rng.integers(4, 20, size=(n_total, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(n_total, 5)).astype(np.int32)
+    seq = []
+    state = rng.random((n_total, 50)).astype(np.float32) * 0.5
+    for _ in range(steps):
+        action = rng.integers(5, 60, size=(n_total, 5)).astype(np.int32)
+        demand = (state.reshape(n_total, 5, 10)[:, :, [0, 5]].sum(axis=2) * 60).astype(np.int32) + 8
+        labels = np.where(action >= demand, 1, -1).astype(np.int32)
+        nxt = rng.random((n_total, 50)).astype(np.float32) * 0.5
+        seq.append((state, action, labels, nxt))
+        state = nxt
+    return ia, sf, seq
+
+
+def digest(agent):
+    h = hashlib.sha256()
+    sizes = []
+    for s in range(5):
+        L = agent.learner(0, s, with_kinv=True)
+        sizes.append(L['m'])
+        for k in ('landmarks', 'coeff', 'kinv'):
+            h.update(np.ascontiguousarray(L[k]).tobytes())
+    return h.hexdigest(), sizes
+
+
+def main():
+    rank, world, id_file, n, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
+    ia, sf, seq = batch(n * world, steps)
+    lo, hi = rank * n, (rank + 1) * n
+    agent = SharedVecKBRL(n, [10] * 5, 200, capacity=256, budget=16, max_rounds=3, first_env=lo)
+    if world > 1 or os.environ.get('RCCL_WORLD1'):
+        if rank == 0:
+            uid = SharedVecKBRL.unique_id()
+            with open(id_file + '.tmp', 'wb') as f:
+                f.write(uid)
+            os.replace(id_file + '.tmp', id_file)
+        else:
+            t0 = time.time()
+            while not os.path.exists(id_file):
+                if time.time() - t0 > 120:
+                    raise SystemExit('no unique id')
+                time.sleep(0.05)
+            with open(id_file, 'rb') as f:
+                uid = f.read()
+        agent.comm_init(uid, rank, world)
+    agent.reset(ia[lo:hi], sf[lo:hi])
+    acts = []
+    for state, action, labels, nxt in seq:
+        agent.update_control(state[lo:hi], action[lo:hi], labels[lo:hi])
+        a, _ = agent.select_action(nxt[lo:hi])
+        acts.append(a)
+    d, sizes = digest(agent)
+    print('RESULT %d %s %s %s' % (rank, d, sizes, hashlib.sha256(np.stack(acts).tobytes()).hexdigest()), flush=True)
+    agent.close()
+
+
+if __name__ == '__main__':
+    main()

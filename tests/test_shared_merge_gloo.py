@@ -55,13 +55,16 @@ def test_merge_is_sharding_independent():
 
 def _worker(rank, world, port, q):
     import torch.distributed as dist
-    from ranslice.kbrl_dev import merge_proposals, rccl_exchange
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    from dist_util import gather_exchange
+    from ranslice.kbrl_dev import merge_proposals
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     rng = np.random.default_rng(100 + rank)
     counts, props = _fake_props(rng, range(rank * 10, rank * 10 + 10), budget=4)
-    all_c, all_p, me = rccl_exchange(device='cpu')(counts, props)
+    all_c, all_p, me = gather_exchange(device='cpu')(counts, props)
     mc, mp, taken = merge_proposals(all_c, all_p, 4)
     q.put((rank, me, mc.tolist(), float(mp.sum()), taken.tolist()))
     dist.barrier()

@@ -25,3 +25,21 @@ def sum_over_ranks(values, device=None):
     t = torch.tensor(v, dtype=torch.float64, device=device if device is not None else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t.cpu().numpy()
+
+
+def gather_exchange(device='cpu'):
+    """exchange() callback for SharedVecKBRL over a torch.distributed process group: one all_gather of the proposal
+    block.  The product's exchange is ncclAllGather inside libranslice.so (kb_shared_step); this host version exists
+    so that the merge rule can be exercised by world_size-2 gloo tests on CPU."""
+    import torch
+    import torch.distributed as dist
+
+    def ex(counts, props):
+        W, me = dist.get_world_size(), dist.get_rank()
+        blk = torch.from_numpy(np.concatenate([counts.astype(np.float64), props.ravel()])).to(device)
+        out = [torch.empty_like(blk) for _ in range(W)]
+        dist.all_gather(out, blk)
+        arr = np.stack([o.cpu().numpy() for o in out])
+        S = len(counts)
+        return arr[:, :S].astype(np.int32), arr[:, S:].reshape((W,) + props.shape), me
+    return ex

@@ -40,8 +40,10 @@ def main():
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
     from ranslice.config import make_config, EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
     from ranslice.fading import synth_fading
-    from ranslice.kbrl_dev import SharedVecKBRL, rccl_exchange
-    from ranslice.sharding import shard_range, replica_seeds, max_over_ranks
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from dist_util import max_over_ranks
+    from ranslice.kbrl_dev import SharedVecKBRL
+    from ranslice.sharding import shard_range, replica_seeds
     from ranslice.vec_env import VecRanSlice
     N = args.envs_per_gpu
     cfg = make_config(args.scenario, n_envs=N)
@@ -49,7 +51,13 @@ def main():
     env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, 10000) for t in range(3)], device=local_rank)
     dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
     agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=args.budget, max_rounds=args.rounds, capacity=args.capacity,
-                          device=local_rank, first_env=first, exchange=rccl_exchange('cuda') if use_dist else None)
+                          device=local_rank, first_env=first)
+    if use_dist:
+        # the exchange itself is ncclAllGather inside libranslice.so (kb_shared_step); the launcher's process group
+        # only carries the 128-byte communicator id from rank 0 to the others
+        box = [SharedVecKBRL.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        agent.comm_init(box[0], rank, world)
     rng = np.random.default_rng(1000 + rank)
     ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
                          rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
