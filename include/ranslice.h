@@ -248,6 +248,14 @@ int kb_comm_init(kb_handle* k, const void* id128, int rank, int world);
 int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t budget,
                    int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
 
+/* Histories of KBRL_Control.run (kbrl_control.py:119-124,135-141) kept on the device: after kb_history_begin(steps)
+ * every kb_step_resident records one column per replica -- reward f64, resources (sum of the newly selected action),
+ * hits [S], adjusted, SLA (sum of labels), violation (total), all int16 as in the reference -- so a whole run needs no
+ * per-step read-back.  kb_history_fetch: [n_envs][steps] arrays (hits [n_envs][S][steps]) and the columns recorded. */
+int kb_history_begin(kb_handle* k, int32_t steps);
+int kb_history_fetch(kb_handle* k, double* reward, int16_t* resources, int16_t* hits, int16_t* adjusted, int16_t* sla,
+                     int16_t* violation, int32_t* n_recorded);
+
 /* sums over learners since kb_reset: [0] predicts, [1] mistakes, [2] insertions, [3] kernel evaluations */
 int kb_get_stats(kb_handle* k, uint64_t stats[4]);
 /* landmarks in every dictionary: i32 [n_envs][S] (one agent per replica) or [S] (shared dictionaries) */

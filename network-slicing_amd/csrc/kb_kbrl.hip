@@ -523,6 +523,47 @@ __global__ void adjust_kernel(KbDev D, KbState K, int32_t* action_out) {
         for (int s = 0; s < D.S; ++s) action_out[env * D.S + s] = K.action[env * D.S + s];
 }
 
+// ---- per-step histories of KBRL_Control.run (kbrl_control.py:119-124,135-141), recorded on the device by the resident
+// loop: one column per step, one row per replica
+struct HistArgs {
+    KbDev D;
+    KbState K;
+    const double* reward;      // env: reward of the step just executed
+    const int32_t* labels;     // env: [n_envs][S]
+    const int32_t* violations; // env: [n_envs][S]
+    const int32_t* hits;       // [n_envs][S] of this update_control
+    double* h_reward;          // [n_envs][steps]
+    int16_t* h_resources;      // [n_envs][steps]   action.sum() of the NEW action
+    int16_t* h_hits;           // [n_envs][S][steps]
+    int16_t* h_adjusted;       // [n_envs][steps]
+    int16_t* h_sla;            // [n_envs][steps]   SLA_labels.sum()
+    int16_t* h_violation;      // [n_envs][steps]   total_violations
+    int32_t* cursor;           // [1] next column
+    int32_t steps;
+};
+
+__global__ void history_kernel(HistArgs A) {
+    const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = A.cursor[0];
+    if (env < A.D.n_envs && i < A.steps) {
+        const int S = A.D.S;
+        int res = 0, sla = 0, viol = 0;
+        for (int s = 0; s < S; ++s) {
+            res += A.K.action[env * S + s];
+            sla += A.labels[env * S + s];
+            viol += A.violations[env * S + s];
+            A.h_hits[((size_t)env * S + s) * A.steps + i] = (int16_t)A.hits[env * S + s];
+        }
+        const size_t o = (size_t)env * A.steps + i;
+        A.h_reward[o] = A.reward[env];
+        A.h_resources[o] = (int16_t)res;
+        A.h_adjusted[o] = (int16_t)A.K.adjusted[env];
+        A.h_sla[o] = (int16_t)sla;
+        A.h_violation[o] = (int16_t)viol;
+    }
+}
+__global__ void history_advance_kernel(int32_t* cursor) { cursor[0] += 1; }
+
 // ---- shared-dictionary mode (build-defined extension): one dictionary per slice index,
 // learned from every replica on every GPU.  A step is a few rounds of
 //   scan    each replica finds its first mistake (in the reference's augmentation order) against the frozen

@@ -3,7 +3,13 @@
 KBRL in the three scenarios and stores results/scenario_N/KBRL_xx/results_K.npz with the same keys
 and dtypes (kbrl_control.py:148-155), so the reference's plot_results.py reads them unchanged.
 
-  python experiments_kbrl.py [--steps 50400] [--runs 30] [--scenarios 0 1 2]
+The reference fans its RUNS independent runs over a process pool (experiments_kbrl.py:67-70); that is exactly the
+replica axis the simulator is batched over, so here all runs of one (scenario, accuracy range) are the replicas of
+ONE VecRanSlice + VecKBRL pair, advanced by the device-resident closed loop with the per-step histories recorded on
+the device (BatchedEvaluator).  Run i is seeded exactly as Evaluator.evaluate(i) seeds it, so its results file is
+the one the run-by-run path writes (tests/test_gpu_kbrl.py::test_batched_evaluator_equals_run_by_run).
+
+  python experiments_kbrl.py [--steps 50400] [--runs 30] [--scenarios 0 1 2] [--serial]
 """
 import argparse
 import os
@@ -12,6 +18,9 @@ from itertools import product
 from numpy import savez
 from numpy.random import default_rng
 
+import numpy as np
+
+import scenario_creator as sc
 from scenario_creator import create_env, create_kbrl_agent
 
 STEPS = 50400
@@ -41,14 +50,86 @@ class Evaluator():
         return file_path
 
 
+class BatchedEvaluator(Evaluator):
+    """All runs of one (scenario, accuracy range) at once: run i = replica i."""
+
+    def evaluate_all(self, runs, device=0, capacity=1024, verbose=True):
+        import ctypes as C
+        from ranslice import config as _c
+        from ranslice.kbrl_dev import VecKBRL
+        from ranslice.vec_env import VecRanSlice, default_fading
+        runs = list(runs)
+        n = len(runs)
+        scn = sc.scenarios[self.scenario]
+        n_embb, n_mmtc, n_prbs = scn['n_embb'], scn['n_mmtc'], scn['n_prbs']
+        # the draws of Evaluator.evaluate(i), in its order: create_env (one seed), create_kbrl_agent (initial action and
+        # security factor per learner, eMBB learners first; then the agent's tie-break seed)
+        env_seeds = np.zeros(n, dtype=np.uint64)
+        ag_seeds = np.zeros(n, dtype=np.uint64)
+        ia = np.zeros((n, n_embb + n_mmtc), dtype=np.int32)
+        sf = np.zeros((n, n_embb + n_mmtc), dtype=np.int32)
+        for k, i in enumerate(runs):
+            rng = default_rng(seed=i)
+            env_seeds[k] = int(rng.integers(0, 2 ** 63 - 1))
+            for s in range(n_embb):
+                ia[k, s] = rng.integers(sc.embb_a[0], sc.embb_a[1])
+                sf[k, s] = rng.integers(sc.embb_sec[0], sc.embb_sec[1])
+            for s in range(n_embb, n_embb + n_mmtc):
+                ia[k, s] = rng.integers(sc.mmtc_a[0], sc.mmtc_a[1])
+                sf[k, s] = rng.integers(sc.mmtc_sec[0], sc.mmtc_sec[1])
+            ag_seeds[k] = int(rng.integers(0, 2 ** 63 - 1))
+        fading = sc._FADING if sc._FADING is not None else default_fading()
+        cfg = _c.make_config(self.scenario, n_envs=n)
+        env = VecRanSlice(n_envs=n, cfg=cfg, fading=fading, device=device)
+        dims = [len(sc.state_variables_embb)] * n_embb + [len(sc.state_variables_mmtc)] * n_mmtc
+        agent = VecKBRL(n, dims, n_prbs, alfa=sc.alfa, accuracy_range=tuple(self.a_range), capacity=capacity,
+                        device=device)
+        env.reset(seeds=env_seeds)
+        agent.reset(ia, sf, seeds=ag_seeds)
+        agent.history_begin(self.steps)
+        # KBRL_Control.run (kbrl_control.py:126-141): the first action is the learners' initial action
+        a0 = np.ascontiguousarray(ia)
+        env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        for i in range(self.steps):
+            agent.step_resident(env)          # update_control + select_action + this step's history column
+            if i + 1 < self.steps:
+                env.step_resident()
+        hist = agent.history_fetch()          # waits for the loop; raises on a device-side error
+        env.fetch()                           # surfaces simulator capacity errors
+        assert hist['recorded'] == self.steps
+        sizes = agent.dictionary_sizes()
+        if (sizes >= capacity).any():
+            import warnings
+            warnings.warn('KBRL dictionaries of runs %s reached their capacity of %d landmarks and projected further '
+                          'samples instead of growing' % (sorted({runs[k] for k in np.nonzero(sizes >= capacity)[0]}),
+                                                          capacity))
+        files = []
+        for k, i in enumerate(runs):
+            results = {'reward': hist['reward'][k], 'resources': hist['resources'][k], 'hits': hist['hits'][k],
+                       'adjusted': hist['adjusted'][k], 'SLA': hist['SLA'][k], 'violation': hist['violation'][k]}
+            file_path = '{}results_{}.npz'.format(self.path, i)
+            savez(file_path, **results)
+            files.append(file_path)
+            if verbose:
+                print('run {}: mean resources = {}, total violations = {}. Results saved!'.format(
+                    i, results['resources'].mean(), results['violation'].sum()))
+        env.close()
+        agent.close()
+        return files
+
+
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--steps', type=int, default=STEPS)
     ap.add_argument('--runs', type=int, default=RUNS)
     ap.add_argument('--scenarios', type=int, nargs='*', default=scenarios)
     ap.add_argument('--out', default='./results')
+    ap.add_argument('--serial', action='store_true', help='one run at a time through the N=1 drop-in classes')
     args = ap.parse_args()
     for scenario, a_range in product(args.scenarios, accuracy_list):
-        evaluator = Evaluator(scenario, a_range, steps=args.steps, out_dir=args.out)
-        for run in range(args.runs):
-            evaluator.evaluate(run)
+        if args.serial:
+            evaluator = Evaluator(scenario, a_range, steps=args.steps, out_dir=args.out)
+            for run in range(args.runs):
+                evaluator.evaluate(run)
+        else:
+            BatchedEvaluator(scenario, a_range, steps=args.steps, out_dir=args.out).evaluate_all(range(args.runs))

@@ -50,5 +50,33 @@ def extend_rows(table, n_prbs):
 
 
 def load_csv(path):
-    """Load a real trace in the reference's CSV layout (headerless, rows=PRB)."""
-    return np.ascontiguousarray(np.genfromtxt(path, delimiter=",", dtype=np.float64))
+    """Load a real trace in the reference's CSV layout (channel_models.py:143: pd.read_csv(header=None)): headerless,
+    comma separated, rows = PRB, columns = time samples, dB; empty / 'nan' fields become NaN (the walker skips columns
+    that contain one, channel_models.py:188-189)."""
+    t = np.genfromtxt(path, delimiter=",", dtype=np.float64)
+    if t.ndim != 2:
+        raise ValueError('%s: expected a 2-D table (rows = PRB, columns = time)' % path)
+    return np.ascontiguousarray(t)
+
+
+def load_fad(path, n_rows=100):
+    """Load an ns-3 LTE fading trace (`fading_trace_*.fad`, the files the reference's CSVs were exported from):
+    whitespace-separated dB values, RB-major -- all time samples of RB 0, then RB 1, ... (ns-3's
+    TraceFadingLossModel::LoadTrace reads m_rbNum x m_samplesNum in that order; 100 RBs).  Returns the reference's
+    layout, float64 [rows = PRB][cols = time]; 'nan' tokens are kept as NaN."""
+    with open(path) as f:
+        vals = np.array(f.read().split(), dtype=np.float64)
+    if vals.size == 0 or vals.size % n_rows:
+        raise ValueError('%s: %d values are not a multiple of %d RBs' % (path, vals.size, n_rows))
+    return np.ascontiguousarray(vals.reshape(n_rows, vals.size // n_rows))
+
+
+def load_traces(paths):
+    """The three traces of SINRSelectiveFading (EPA_3kmph, ETU_3kmph, EVA_60kmph: channel_models.py:29-33) from
+    files, .csv or .fad by extension, ready for VecRanSlice(fading=...) / scenario_creator.set_fading."""
+    out = []
+    for p in paths:
+        out.append(load_fad(p) if str(p).lower().endswith('.fad') else load_csv(p))
+    if len(out) != 3:
+        raise ValueError('three traces are needed')
+    return out

@@ -79,6 +79,27 @@ class VecKBRL:
     def step_resident(self, env):
         self._check(self.L.kb_step_resident(self.h, env.h))
 
+    def history_begin(self, steps):
+        """start recording KBRL_Control.run's per-step histories on the device (one column per step_resident)"""
+        self._hist_steps = int(steps)
+        self._check(self.L.kb_history_begin(self.h, int(steps)))
+
+    def history_fetch(self):
+        """-> dict of the reference's result arrays per replica: reward f64 [N, steps]; resources, adjusted, SLA,
+        violation int16 [N, steps]; hits int16 [N, S, steps] (kbrl_control.py:148-155), and `recorded`"""
+        n, st = self.n_envs, self._hist_steps
+        sp = C.POINTER(C.c_int16)
+        out = dict(reward=np.zeros((n, st)), resources=np.zeros((n, st), dtype=np.int16),
+                   hits=np.zeros((n, self.S, st), dtype=np.int16), adjusted=np.zeros((n, st), dtype=np.int16),
+                   SLA=np.zeros((n, st), dtype=np.int16), violation=np.zeros((n, st), dtype=np.int16))
+        rec = C.c_int32()
+        self._check(self.L.kb_history_fetch(self.h, out['reward'].ctypes.data_as(_dp), out['resources'].ctypes.data_as(sp),
+                                            out['hits'].ctypes.data_as(sp), out['adjusted'].ctypes.data_as(sp),
+                                            out['SLA'].ctypes.data_as(sp), out['violation'].ctypes.data_as(sp),
+                                            C.byref(rec)))
+        out['recorded'] = rec.value
+        return out
+
     def predict(self, e, s, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         y, f = C.c_int32(), C.c_double()

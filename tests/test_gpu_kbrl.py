@@ -360,3 +360,28 @@ def test_saturated_dictionary_projects(golden_dir):
     for s in range(len(dims)):
         np.testing.assert_allclose(ag.learner(0, s)['coeff'], oa.coeff(s), rtol=1e-7, atol=1e-9)
     ag.close()
+
+
+def test_batched_evaluator_equals_run_by_run(golden_dir, tmp_path):
+    """experiments_kbrl.BatchedEvaluator (all runs = replicas of one device-resident loop, histories recorded on the
+    device) writes, run for run, the results_K.npz the reference-shaped Evaluator.evaluate(K) writes through the N=1
+    drop-in classes: same keys, dtypes, shapes (G11) and the same numbers."""
+    import experiments_kbrl as ek
+    import scenario_creator as sc
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    sc.set_fading([g['t0'], g['t1'], g['t2']])
+    ref = _load(golden_dir, 'g11_results_schema')
+    steps, runs = 40, [0, 1, 2, 5]
+    for scenario in (0, 2):
+        serial = ek.Evaluator(scenario, [0.97, 0.99], steps=steps, out_dir=str(tmp_path / 'serial'))
+        batched = ek.BatchedEvaluator(scenario, [0.97, 0.99], steps=steps, out_dir=str(tmp_path / 'batched'))
+        files_b = batched.evaluate_all(runs, verbose=False)
+        for k, i in enumerate(runs):
+            a = np.load(serial.evaluate(i))
+            b = np.load(files_b[k])
+            assert sorted(a.files) == sorted(b.files) == sorted(x[4:] for x in ref.files)
+            for key in a.files:
+                assert a[key].dtype == b[key].dtype == ref['key_' + key].dtype, key
+                assert a[key].shape == b[key].shape, key
+                assert (a[key] == b[key]).all(), (scenario, i, key)
+    sc.set_fading(None)
