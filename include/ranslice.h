@@ -70,6 +70,13 @@ typedef struct rs_config {
     int32_t mcs_order[RS_MAX_MCS];
     int32_t mcs_mod[RS_MAX_MCS]; /* 0 qpsk, 1 16qam, 2 64qam */
     double mi_x0[3], mi_k[3];    /* mutual-information sigmoid parameters per modulation */
+    /* create_env(..., L1_level) (scenario_creator.py:156-177).  0 = L1_level=True: one L1 slice per RAN slice, the
+     * action has n_embb + n_mmtc entries.  1 = L1_level=False: the eMBB RAN slices share ONE L1 slice (one UE list,
+     * one PF scheduler, one PRB range) and the mMTC RAN slices ONE FIFO; the action has one entry per L1 slice
+     * ((n_embb > 0) + (n_mmtc > 0)), labels/violations likewise (violations = RAN slices in breach), the observation
+     * and rs_get_info keep one block per RAN slice; UE capacity is 64 per L1 slice. */
+    int32_t l1_multiplex;
+    int32_t reserved_;
 } rs_config;
 
 typedef struct rs_handle rs_handle;

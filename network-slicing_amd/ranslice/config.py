@@ -79,6 +79,7 @@ class RsConfig(C.Structure):
         ('mcs_rate', C.c_double * RS_MAX_MCS), ('mcs_snr', C.c_double * RS_MAX_MCS),
         ('mcs_order', C.c_int32 * RS_MAX_MCS), ('mcs_mod', C.c_int32 * RS_MAX_MCS),
         ('mi_x0', C.c_double * 3), ('mi_k', C.c_double * 3),
+        ('l1_multiplex', C.c_int32), ('reserved_', C.c_int32),
     ]
 
 

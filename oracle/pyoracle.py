@@ -89,7 +89,9 @@ class OracleEnv:
         self.cfg = cfg
         self.L = lib()
         self.h = self.L.rso_create(C.byref(cfg))
-        self.n_slices = cfg.n_embb + cfg.n_mmtc
+        self.n_ran = cfg.n_embb + cfg.n_mmtc
+        # action / label entries: one per L1 slice (all eMBB RAN slices share one, all mMTC ones another, when multiplexed)
+        self.n_slices = ((cfg.n_embb > 0) + (cfg.n_mmtc > 0)) if cfg.l1_multiplex else self.n_ran
         self.n_vars = n_vars(cfg)
         self.max_ue = self.L.rso_max_ue(self.h)
         self._keep = []
@@ -132,11 +134,12 @@ class OracleEnv:
         reward = np.zeros(1, dtype=np.float64)
         labels = np.zeros(self.n_slices, dtype=np.int32)
         viol = np.zeros(self.n_slices, dtype=np.int32)
-        info = np.zeros((self.n_slices, 10), dtype=np.float64)
+        info = np.zeros((self.n_ran, 10), dtype=np.float64)
         tr = None
         trp = None
         if trace:
-            tr = np.zeros((self.cfg.n_embb, self.cfg.slots_per_step, self.max_ue), dtype=np.dtype(RsAllocRec))
+            n_l1_embb = min(self.cfg.n_embb, 1) if self.cfg.l1_multiplex else self.cfg.n_embb
+            tr = np.zeros((n_l1_embb, self.cfg.slots_per_step, self.max_ue), dtype=np.dtype(RsAllocRec))
             trp = tr.ctypes.data_as(C.c_void_p)
         self._check(self.L.rso_step(self.h, _p(action, _ip), _p(obs, C.POINTER(C.c_float)), _p(reward, _dp),
                                     _p(labels, _ip), _p(viol, _ip), _p(info, _dp), trp))

@@ -23,6 +23,7 @@ enum { I_CBR_TRAFFIC = 0, I_CBR_TH, I_CBR_PRB, I_CBR_QUEUE, I_CBR_SNR,
 
 typedef struct {
     int type;
+    int ran;      /* RAN slice the UE belongs to (UE.slice_ran_id); matters when slices are multiplexed in one L1 */
     uint32_t serial;
     rs_stream st;
     double hold;  /* remaining_time[id] (slice_ran.py:222,240) */
@@ -73,6 +74,12 @@ struct rs_oracle {
     int n_slices, n_vars, max_ue, max_bursts, max_queue;
     rso_embb* embb;
     rso_mmtc* mmtc;
+    /* L1_level=False (scenario_creator.py:168-177): every eMBB RAN slice under ONE SliceL1eMBB (one UE list, one PF
+     * scheduler, one PRB range), every mMTC RAN slice in ONE SliceL1mMTC (one FIFO) */
+    int mux;
+    rso_embb mux_embb; /* the UE list and the PRB range of the multiplexed L1 slice (its RAN-level fields are unused) */
+    rso_mmtc mux_mmtc; /* time, n_prbs and the FIFO of the multiplexed mMTC L1 slice */
+    int64_t* mq_ran;   /* RAN slice of every FIFO entry (SliceL1mMTC.slice_ran_ids) */
     /* fading tables, device layout [trace][time][prb] */
     double* fad[RS_N_TRACES];
     uint8_t* fad_valid[RS_N_TRACES];
@@ -532,13 +539,10 @@ static int cbr_cac(const rs_oracle* o, const rso_embb* e) {
     return 1;
 }
 
-/* one slot of SliceL1eMBB (slice_l1.py:193-228) with its single SliceRANeMBB (L1_level=True) */
-static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
+/* SliceRANeMBB.slot's arrival half (slice_ran.py:205-249,263-266) for RAN slice e: new UEs go to pend[] */
+static int embb_arrivals(rs_oracle* o, rso_embb* e, int ran, rso_ue* pend) {
     const rs_config* c = &o->cfg;
-    rso_ue pend[2];
     int n_pend = 0;
-
-    /* ---- SliceRANeMBB.slot (slice_ran.py:263-268) */
     e->slot_counter += 1;
     /* cbr_arrivals (slice_ran.py:205-227): inter-arrival is drawn BEFORE admission control */
     if (e->cbr_next == 0) {
@@ -563,19 +567,24 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
     } else {
         e->vbr_next -= 1;
     }
-    /* departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191): every timer is
-     * decremented, new arrivals included; ==0 departs.  Q5: a timer drawn as 0 never fires. */
-    {
-        int w = 0;
-        for (int i = 0; i < e->n_ue; ++i) {
-            e->ue[i].hold -= 1;
-            if (e->ue[i].hold == 0) continue;
-            if (w != i) e->ue[w] = e->ue[i];
-            ++w;
+    for (int k = 0; k < n_pend; ++k) pend[k].ran = ran;
+    return n_pend;
+}
+
+/* departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191) of RAN slice `ran` on the L1 slice's UE
+ * list, then add_users (slice_l1.py:183-185) -> insert_user draws, in arrival order.  Every timer of the RAN slice is
+ * decremented, new arrivals included; ==0 departs.  Q5: a timer drawn as 0 never fires. */
+static void embb_depart_and_insert(rs_oracle* o, rso_embb* L, int ran, rso_ue* pend, int n_pend) {
+    int w = 0;
+    for (int i = 0; i < L->n_ue; ++i) {
+        if (L->ue[i].ran == ran) {
+            L->ue[i].hold -= 1;
+            if (L->ue[i].hold == 0) continue;
         }
-        e->n_ue = w;
+        if (w != i) L->ue[w] = L->ue[i];
+        ++w;
     }
-    /* add_users (slice_l1.py:183-185) -> insert_user draws, in arrival order */
+    L->n_ue = w;
     for (int k = 0; k < n_pend; ++k) {
         pend[k].hold -= 1;
         if (pend[k].hold == 0) {
@@ -585,46 +594,48 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
              * simply never joins the slice. */
             continue;
         }
-        if (e->n_ue >= o->max_ue || e->n_ue >= RSO_MAX_UE) {
+        if (L->n_ue >= o->max_ue || L->n_ue >= RSO_MAX_UE) {
             fail(o, RS_EOVERFLOW, "UE capacity exceeded");
             continue;
         }
-        rso_ue* u = &e->ue[e->n_ue++];
+        rso_ue* u = &L->ue[L->n_ue++];
         *u = pend[k];
         fading_insert(o, u);
     }
+}
 
-    /* ---- per-UE traffic and channel estimate (slice_l1.py:200-213) */
+/* per-UE traffic and channel estimate, scheduling and transmission of one L1 slice (slice_l1.py:200-224) */
+static int embb_l1_serve(rs_oracle* o, rso_embb* L) {
+    const rs_config* c = &o->cfg;
     const double* col[RSO_MAX_UE];
     rso_ue* ptr[RSO_MAX_UE];
     double queued_data = 0;
-    for (int i = 0; i < e->n_ue; ++i) {
-        rso_ue* u = &e->ue[i];
+    for (int i = 0; i < L->n_ue; ++i) {
+        rso_ue* u = &L->ue[i];
         ptr[i] = u;
         /* UE.traffic_step (slice_ran.py:47-49); CbrSource = PeriodicSource(bit_rate*1e-3, period 1) */
         u->new_bits = u->type == CBR ? c->cbr_bit_rate * 1e-3 : vbr_step(o, u);
         u->queue += u->new_bits;
         queued_data += u->queue;
         col[i] = NULL;
-        if (e->n_prbs > 0) { /* Q3: with 0 PRBs the walker does not advance and e_snr is stale */
+        if (L->n_prbs > 0) { /* Q3: with 0 PRBs the walker does not advance and e_snr is stale */
             col[i] = fading_advance(o, u);
             /* UE.estimate_snr (slice_ran.py:43-45): round(np.mean(snr[prb_slice])), half-to-even (Q7) */
             double sn[1024];
-            for (int k = 0; k < e->n_prbs; ++k) sn[k] = col[i][e->prb_lo + k] + u->nominal;
-            double mean = rso_pairwise_sum(sn, e->n_prbs) / (double)e->n_prbs;
+            for (int k = 0; k < L->n_prbs; ++k) sn[k] = col[i][L->prb_lo + k] + u->nominal;
+            double mean = rso_pairwise_sum(sn, L->n_prbs) / (double)L->n_prbs;
             u->e_snr = (int64_t)rint(mean);
-            o->counters[0] += (uint64_t)e->n_prbs;
+            o->counters[0] += (uint64_t)L->n_prbs;
         }
         o->counters[3] += 1;
     }
-
     /* ---- scheduling and transmission (slice_l1.py:215-224); Q2: skipped -> stale bits/prbs */
-    int scheduled = queued_data > 0 && e->n_prbs > 0;
+    int scheduled = queued_data > 0 && L->n_prbs > 0;
     if (scheduled) {
-        pf_allocate(o, c, o->mcsA, o->mcsB, e->n_ue, ptr, col, e->prb_lo, e->n_prbs);
+        pf_allocate(o, c, o->mcsA, o->mcsB, L->n_ue, ptr, col, L->prb_lo, L->n_prbs);
         double b = 1.0 / c->pf_window, a = 1 - b; /* UE.__init__: b = 1/window, a = 1-b */
-        for (int i = 0; i < e->n_ue; ++i) {
-            rso_ue* u = &e->ue[i];
+        for (int i = 0; i < L->n_ue; ++i) {
+            rso_ue* u = &L->ue[i];
             int received = 0;
             if (u->prbs) received = dr_random(o, &u->st) < u->p;
             /* UE.transmission_step (slice_ran.py:51-55) */
@@ -634,15 +645,18 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
             u->th = a * u->th + b * (double)u->bits / c->slot_length;
         }
     }
+    return scheduled;
+}
 
-    /* ---- SliceRANeMBB.update_info (slice_ran.py:278-305) */
+/* SliceRANeMBB.update_info (slice_ran.py:278-305) of RAN slice e over its UEs in the L1 slice's list */
+static void embb_update_info(rso_embb* e, int ran, const rso_embb* L) {
     for (int cls = 0; cls < 2; ++cls) {
         double queue = 0, snr = 0;
         int n = 0;
         int base = cls == CBR ? I_CBR_TRAFFIC : I_VBR_TRAFFIC;
-        for (int i = 0; i < e->n_ue; ++i) {
-            rso_ue* u = &e->ue[i];
-            if (u->type != cls) continue;
+        for (int i = 0; i < L->n_ue; ++i) {
+            const rso_ue* u = &L->ue[i];
+            if (u->type != cls || u->ran != ran) continue;
             e->info[base + 0] += u->new_bits;
             e->info[base + 1] += (double)u->bits;
             e->info[base + 2] += (double)u->prbs;
@@ -654,23 +668,46 @@ static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
         e->info[base + 3] += queue / n;
         e->info[base + 4] += snr / n;
     }
+}
 
-    if (trace) {
-        for (int i = 0; i < o->max_ue; ++i) {
-            rs_alloc_rec* r = &trace[i];
-            memset(r, 0, sizeof *r);
-            if (i >= e->n_ue) continue;
-            rso_ue* u = &e->ue[i];
-            r->serial = (int32_t)u->serial;
-            r->type = u->type;
-            r->e_snr = (int32_t)u->e_snr;
-            r->prbs = (int32_t)u->prbs;
-            r->bits = u->bits;
-            r->queue = u->queue;
-            r->th = u->th;
-            r->p = scheduled ? u->p : 0.0; /* this slot's allocation only */
-        }
+static void embb_trace(const rs_oracle* o, const rso_embb* L, int scheduled, rs_alloc_rec* trace) {
+    for (int i = 0; i < o->max_ue; ++i) {
+        rs_alloc_rec* r = &trace[i];
+        memset(r, 0, sizeof *r);
+        if (i >= L->n_ue) continue;
+        const rso_ue* u = &L->ue[i];
+        r->serial = (int32_t)u->serial;
+        r->type = u->type | (u->ran << 8); /* bits 8..: RAN slice (0 unless slices are multiplexed) */
+        r->e_snr = (int32_t)u->e_snr;
+        r->prbs = (int32_t)u->prbs;
+        r->bits = u->bits;
+        r->queue = u->queue;
+        r->th = u->th;
+        r->p = scheduled ? u->p : 0.0; /* this slot's allocation only */
     }
+}
+
+/* one slot of SliceL1eMBB (slice_l1.py:193-228) with its single SliceRANeMBB (L1_level=True) */
+static void embb_slot(rs_oracle* o, rso_embb* e, rs_alloc_rec* trace) {
+    rso_ue pend[2];
+    const int n_pend = embb_arrivals(o, e, 0, pend);
+    embb_depart_and_insert(o, e, 0, pend, n_pend);
+    const int scheduled = embb_l1_serve(o, e);
+    embb_update_info(e, 0, e);
+    if (trace) embb_trace(o, e, scheduled, trace);
+}
+
+/* one slot of the multiplexed SliceL1eMBB (L1_level=False): slice_l1.py:193-228 with several slices_ran */
+static void mux_embb_slot(rs_oracle* o, rs_alloc_rec* trace) {
+    rso_embb* L = &o->mux_embb;
+    for (int m = 0; m < o->cfg.n_embb; ++m) { /* arrivals, departures, extract, add -- RAN slice by RAN slice */
+        rso_ue pend[2];
+        const int n_pend = embb_arrivals(o, &o->embb[m], m, pend);
+        embb_depart_and_insert(o, L, m, pend, n_pend);
+    }
+    const int scheduled = embb_l1_serve(o, L);
+    for (int m = 0; m < o->cfg.n_embb; ++m) embb_update_info(&o->embb[m], m, L);
+    if (trace) embb_trace(o, L, scheduled, trace);
 }
 
 /* SliceRANeMBB.compute_reward (slice_ran.py:307-319) */
@@ -752,10 +789,66 @@ static void mmtc_slot(rs_oracle* o, rso_mmtc* m) {
     m->info[2] += (double)w;
 }
 
+/* one slot of the multiplexed SliceL1mMTC (L1_level=False, slice_l1.py:87-125 with several slices_ran): one FIFO;
+ * arrivals are appended RAN slice by RAN slice (device order inside a slice), every entry remembers its slice, and
+ * each slice's delay / repetitions / devices are taken over its own entries */
+static void mux_mmtc_slot(rs_oracle* o) {
+    rso_mmtc* Q = &o->mux_mmtc;
+    Q->time += 1;
+    for (int s = 0; s < o->cfg.n_mmtc; ++s) {
+        rso_mmtc* m = &o->mmtc[s];
+        for (int i = 0; i < m->n_dev; ++i) {
+            m->t_to_arrival[i] -= 1;
+            if (m->t_to_arrival[i] == 0) {
+                if (Q->n_users >= Q->cap) {
+                    fail(o, RS_EOVERFLOW, "mMTC queue capacity exceeded");
+                } else {
+                    Q->q_rep[Q->n_users] = m->dev_rep[i];
+                    Q->q_start[Q->n_users] = Q->time;
+                    o->mq_ran[Q->n_users] = s;
+                    Q->n_users += 1;
+                }
+                m->t_to_arrival[i] = m->period[i];
+            }
+        }
+    }
+    int n_tx = Q->n_prbs < Q->n_users ? Q->n_prbs : Q->n_users; /* one NB-IoT carrier per PRB */
+    for (int i = 0; i < n_tx; ++i) Q->q_rep[i] -= 1;
+    int w = 0;
+    for (int i = 0; i < Q->n_users; ++i) {
+        if (Q->q_rep[i] > 0) {
+            Q->q_rep[w] = Q->q_rep[i];
+            Q->q_start[w] = Q->q_start[i];
+            o->mq_ran[w] = o->mq_ran[i];
+            ++w;
+        }
+    }
+    Q->n_users = w;
+    for (int s = 0; s < o->cfg.n_mmtc; ++s) {
+        int64_t sd = 0, sr = 0, n = 0;
+        for (int i = 0; i < w; ++i) {
+            if (o->mq_ran[i] != s) continue;
+            int64_t d = Q->time - Q->q_start[i];
+            sd += d > 0 ? d : 0;
+            sr += Q->q_rep[i];
+            n += 1;
+        }
+        double delay = 0, avg_rep = 0;
+        if (n > 0) {
+            delay = (double)sd / (double)n;
+            avg_rep = rint((double)sr / (double)n);
+        }
+        o->mmtc[s].info[0] += delay;
+        o->mmtc[s].info[1] += avg_rep;
+        o->mmtc[s].info[2] += (double)n;
+    }
+}
+
 /* ------------------------------------------------------------------ env */
 
 static void set_defaults(rs_oracle* o) {
-    o->max_ue = o->cfg.max_ue > 0 ? o->cfg.max_ue : 32;
+    o->mux = o->cfg.l1_multiplex != 0;
+    o->max_ue = o->cfg.max_ue > 0 ? o->cfg.max_ue : (o->mux ? 64 : 32);
     o->max_bursts = o->cfg.max_bursts > 0 ? o->cfg.max_bursts : 8;
     o->max_queue = o->cfg.max_mtc_queue > 0 ? o->cfg.max_mtc_queue : 1024;
 }
@@ -783,6 +876,15 @@ rs_oracle* rso_create(const rs_config* cfg) {
         m->q_rep = (int64_t*)calloc((size_t)m->cap, 8);
         m->q_start = (int64_t*)calloc((size_t)m->cap, 8);
     }
+    if (o->mux) {
+        o->mux_embb.ue = (rso_ue*)calloc(RSO_MAX_UE, sizeof(rso_ue));
+        o->mux_embb.n_prbs = 20;
+        o->mux_mmtc.n_prbs = 5;
+        o->mux_mmtc.cap = o->max_queue * (cfg->n_mmtc > 0 ? cfg->n_mmtc : 1);
+        o->mux_mmtc.q_rep = (int64_t*)calloc((size_t)o->mux_mmtc.cap, 8);
+        o->mux_mmtc.q_start = (int64_t*)calloc((size_t)o->mux_mmtc.cap, 8);
+        o->mq_ran = (int64_t*)calloc((size_t)o->mux_mmtc.cap, 8);
+    }
     rso_mcs_factors(&o->mcsA, &o->mcsB);
     return o;
 }
@@ -799,6 +901,10 @@ void rso_destroy(rs_oracle* o) {
     }
     free(o->embb);
     free(o->mmtc);
+    free(o->mux_embb.ue);
+    free(o->mux_mmtc.q_rep);
+    free(o->mux_mmtc.q_start);
+    free(o->mq_ran);
     for (int t = 0; t < RS_N_TRACES; ++t) {
         free(o->fad[t]);
         free(o->fad_valid[t]);
@@ -822,7 +928,7 @@ const char* rso_error(const rs_oracle* o) { return o->errmsg; }
 void rso_get_counters(const rs_oracle* o, uint64_t counters[4]) { memcpy(counters, o->counters, sizeof o->counters); }
 int rso_get_mtc_queue(const rs_oracle* o, int s, int64_t* rep, int64_t* start, int cap, int64_t* time) {
     if (!o || s < 0 || s >= o->cfg.n_mmtc) return -1;
-    const rso_mmtc* m = &o->mmtc[s];
+    const rso_mmtc* m = o->mux ? &o->mux_mmtc : &o->mmtc[s]; /* multiplexed: the one FIFO, whatever s */
     for (int i = 0; i < m->n_users && i < cap; ++i) {
         rep[i] = m->q_rep[i];
         start[i] = m->q_start[i];
@@ -842,6 +948,9 @@ int rso_reset(rs_oracle* o) {
     o->now = 0;
     for (int i = 0; i < o->cfg.n_embb; ++i) embb_reset(o, &o->embb[i], i);
     for (int i = 0; i < o->cfg.n_mmtc; ++i) mmtc_reset(o, &o->mmtc[i], o->cfg.n_embb + i);
+    o->mux_embb.n_ue = 0;
+    o->mux_mmtc.time = 0;
+    o->mux_mmtc.n_users = 0;
     return o->err;
 }
 
@@ -850,8 +959,9 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
              int32_t* violations, double* info, rs_alloc_rec* trace) {
     const rs_config* c = &o->cfg;
     if (o->err) return o->err;
+    const int n_l1 = o->mux ? (c->n_embb > 0) + (c->n_mmtc > 0) : o->n_slices; /* L1 slices = action entries */
     int64_t total = 0;
-    for (int s = 0; s < o->n_slices; ++s) {
+    for (int s = 0; s < n_l1; ++s) {
         if (action[s] < 0) {
             fail(o, RS_EINVAL, "negative action");
             return o->err;
@@ -869,19 +979,32 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
         }
     /* reset_info + set_prbs (node_b.py:64-74) */
     int i_prb = 0;
-    for (int s = 0; s < c->n_embb; ++s) {
-        embb_reset_info(&o->embb[s]);
-        o->embb[s].prb_lo = i_prb;
-        o->embb[s].n_prbs = action[s];
-        i_prb += action[s];
-    }
-    for (int s = 0; s < c->n_mmtc; ++s) {
-        memset(o->mmtc[s].info, 0, sizeof o->mmtc[s].info);
-        o->mmtc[s].n_prbs = action[c->n_embb + s];
+    for (int s = 0; s < c->n_embb; ++s) embb_reset_info(&o->embb[s]);
+    for (int s = 0; s < c->n_mmtc; ++s) memset(o->mmtc[s].info, 0, sizeof o->mmtc[s].info);
+    if (o->mux) {
+        int a = 0;
+        if (c->n_embb > 0) {
+            o->mux_embb.prb_lo = 0;
+            o->mux_embb.n_prbs = action[a];
+            i_prb += action[a++];
+        }
+        if (c->n_mmtc > 0) o->mux_mmtc.n_prbs = action[a];
+    } else {
+        for (int s = 0; s < c->n_embb; ++s) {
+            o->embb[s].prb_lo = i_prb;
+            o->embb[s].n_prbs = action[s];
+            i_prb += action[s];
+        }
+        for (int s = 0; s < c->n_mmtc; ++s) o->mmtc[s].n_prbs = action[c->n_embb + s];
     }
     /* slots (node_b.py:77-78): slot-major, slices in order (they share one rng in the reference) */
     for (int t = 0; t < c->slots_per_step; ++t) {
         o->now = o->slots_done + t + 1;
+        if (o->mux) { /* trace: [slots_per_step][max_ue] of the one eMBB L1 slice */
+            if (c->n_embb > 0) mux_embb_slot(o, trace ? trace + (size_t)t * o->max_ue : NULL);
+            if (c->n_mmtc > 0) mux_mmtc_slot(o);
+            continue;
+        }
         for (int s = 0; s < c->n_embb; ++s)
             embb_slot(o, &o->embb[s], trace ? trace + ((size_t)s * c->slots_per_step + t) * o->max_ue : NULL);
         for (int s = 0; s < c->n_mmtc; ++s) mmtc_slot(o, &o->mmtc[s]);
@@ -891,6 +1014,7 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
     /* get_state (node_b.py:40-44; slice_ran.py:321-325, 133-137): f64 ratio stored as f32 */
     int64_t tv = 0;
     int v = 0;
+    int mux_viol[2] = {0, 0};
     for (int s = 0; s < c->n_embb; ++s) {
         rso_embb* e = &o->embb[s];
         for (int k = 0; k < RS_N_EMBB_VARS; ++k) {
@@ -898,8 +1022,12 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
             ++v;
         }
         int viol = embb_violation(o, e);
-        if (labels) labels[s] = viol == 0 ? 1 : -1; /* slice_l1.py:160-171 */
-        if (violations) violations[s] = viol;
+        if (o->mux) { /* SliceL1eMBB.compute_reward sums its RAN slices' breaches (slice_l1.py:160-171) */
+            mux_viol[0] += viol;
+        } else {
+            if (labels) labels[s] = viol == 0 ? 1 : -1; /* slice_l1.py:160-171 */
+            if (violations) violations[s] = viol;
+        }
         tv += viol;
         if (info) memcpy(info + (size_t)s * 10, e->info, sizeof e->info);
     }
@@ -916,8 +1044,12 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
         int ok = m->info[0] / c->slots_per_step < c->sla_mtc_delay;
         int viol = !ok;
         int S = c->n_embb + s;
-        if (labels) labels[S] = viol == 0 ? 1 : -1;
-        if (violations) violations[S] = viol;
+        if (o->mux) {
+            mux_viol[1] += viol;
+        } else {
+            if (labels) labels[S] = viol == 0 ? 1 : -1;
+            if (violations) violations[S] = viol;
+        }
         tv += viol;
         if (info) {
             double* d = info + (size_t)S * 10;
@@ -925,6 +1057,18 @@ int rso_step(rs_oracle* o, const int32_t* action, float* obs, double* reward, in
             d[0] = m->info[0];
             d[1] = m->info[1];
             d[2] = m->info[2];
+        }
+    }
+    if (o->mux) {
+        int a = 0;
+        if (c->n_embb > 0) {
+            if (labels) labels[a] = mux_viol[0] == 0 ? 1 : -1;
+            if (violations) violations[a] = mux_viol[0];
+            ++a;
+        }
+        if (c->n_mmtc > 0) {
+            if (labels) labels[a] = mux_viol[1] == 0 ? 1 : -1;
+            if (violations) violations[a] = mux_viol[1];
         }
     }
     /* reward (ran_slice.py:45-52) */

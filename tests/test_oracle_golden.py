@@ -189,3 +189,80 @@ def test_g7_full_step(path, golden_dir):
     assert sorted(arrivals) == sorted(ga), 'arrival slots / types / serials differ'
     assert sorted(departures) == sorted(gd), 'departure slots / serials differ'
     assert len(ga) > 0
+
+
+def _g13_files(golden_dir):
+    return sorted(glob.glob(os.path.join(golden_dir, 'g13_mux_*.npz')))
+
+
+@pytest.mark.parametrize('path', _g13_files(os.path.join(os.path.dirname(__file__), 'golden')),
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_g13_multiplexed_l1(path, golden_dir):
+    """create_env(..., L1_level=False) (scenario_creator.py:168-177) replayed on the reference's own tape: all eMBB
+    RAN slices under ONE L1 slice / PF scheduler, all mMTC RAN slices in ONE FIFO.  One action entry per L1 slice;
+    observation and info per RAN slice; per-slot per-UE records of the shared UE list incl. the UE's RAN slice."""
+    g = np.load(path)
+    assert int(g['l1_level']) == 0
+    fad = _load(golden_dir, 'fading_small')
+    cfg = _cfg_for(g)
+    cfg.l1_multiplex = 1
+    env = po.OracleEnv(cfg, [fad['t0'], fad['t1'], fad['t2']])
+    assert env.n_slices == (cfg.n_embb > 0) + (cfg.n_mmtc > 0) == g['actions'].shape[1]
+    env.set_tape(g['tape_kind'], g['tape_val'])
+    obs0 = env.reset()
+    assert (obs0 == g['obs0']).all()
+    slot_i = ue_off = 0
+    arrivals, departures = [], []
+    present = {}
+    q_i = q_off = 0
+    max_ue_seen = 0
+    for i, act in enumerate(g['actions']):
+        out = env.step(act, trace=True)
+        assert out['obs'].tobytes() == g['obs'][i].tobytes(), 'obs bits differ at step %d' % i
+        assert out['reward'] == g['reward'][i]
+        assert (out['labels'] == g['labels'][i]).all()
+        assert (out['violations'] == g['violations'][i]).all()
+        assert (out['info'] == g['info'][i]).all(), 'info accumulators differ at step %d' % i
+        tr = out['trace']
+        for t in range(cfg.slots_per_step if cfg.n_embb else 0):
+            n = int(g['slot_n_ue'][slot_i])
+            slot_i += 1
+            max_ue_seen = max(max_ue_seen, n)
+            rec = tr[0, t]
+            assert int((rec['serial'] > 0).sum()) == n
+            gi = g['slot_ue_int'][ue_off:ue_off + n]
+            gf = g['slot_ue_f64'][ue_off:ue_off + n]
+            gr = g['slot_ue_ran'][ue_off:ue_off + n]
+            ue_off += n
+            r = rec[:n]
+            assert ((r['type'] & 0xff) == gi[:, 0]).all() and ((r['type'] >> 8) == gr).all()
+            assert (r['e_snr'] == gi[:, 1]).all()
+            assert (r['prbs'] == gi[:, 2]).all()
+            assert (r['bits'] == gi[:, 3]).all()
+            assert (r['queue'] == gf[:, 0]).all()
+            assert (r['th'] == gf[:, 1]).all()
+            hit = r['p'] != 0
+            np.testing.assert_allclose(r['p'][hit], gf[hit, 2], rtol=PROB_RTOL, atol=0)
+            now = {(int(x['type']) >> 8, int(x['serial'])): int(x['type']) & 0xff for x in r}
+            gslot = i * cfg.slots_per_step + t
+            for key in sorted(set(now) - set(present)):
+                arrivals.append((gslot, key[0], now[key], key[1]))
+            for key in present:
+                if key not in now:
+                    departures.append((gslot, key[0], key[1]))
+            present = now
+        if cfg.n_mmtc:
+            tm, rep, start = env.mtc_queue(0)
+            n = int(g['g8_n_users'][q_i])
+            assert tm == int(g['g8_time'][q_i]) and len(rep) == n, 'mMTC queue length differs at step %d' % i
+            assert (rep == g['g8_repetitions'][q_off:q_off + n]).all()
+            assert (start == g['g8_t_start'][q_off:q_off + n]).all()
+            q_i += 1
+            q_off += n
+    assert env.tape_pos() == len(g['tape_kind']), 'oracle consumed a different number of draws'
+    assert slot_i == len(g['slot_n_ue']) and q_i == len(g['g8_n_users'])
+    ga = [tuple(int(v) for v in row) for row in g['g5_arrivals']]
+    gd = [tuple(int(v) for v in row) for row in g['g5_departures']]
+    assert sorted(arrivals) == sorted(ga) and sorted(departures) == sorted(gd)
+    if cfg.n_embb > 1:
+        assert len(set(g['slot_ue_ran'].tolist())) > 1, 'fixture should mix RAN slices in one UE list'

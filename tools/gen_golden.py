@@ -181,7 +181,7 @@ def action_script(rng, n_slices, n_prbs, steps):
     return acts
 
 
-def run_g7(tape, scenario, seed, steps, churn):
+def run_g7(tape, scenario, seed, steps, churn, l1_level=True):
     import scenario_creator as sc
     import slice_l1
     saved = (dict(sc.CBR_description), dict(sc.VBR_description))
@@ -191,11 +191,12 @@ def run_g7(tape, scenario, seed, steps, churn):
     np.random.seed(1000 + seed)
     rng = rh.TapeRNG(np.random.default_rng(seed), tape)
     tape.clear()
-    env = sc.create_env(rng, scenario)
+    env = sc.create_env(rng, scenario, L1_level=l1_level)
     n_slices, n_prbs = env.n_slices, env.n_prbs
     acts = action_script(np.random.default_rng(500 + seed), n_slices, n_prbs, steps)
 
     slot_rec = []
+    slot_ran = []
     orig_slot = slice_l1.SliceL1eMBB.slot
     # G5: who arrives and who departs, slot by slot (SliceRANeMBB.slot, slice_ran.py:263-268); UE ids are turned
     # into the arrival rank inside their slice (1-based) so that they do not depend on the shared id counter
@@ -223,6 +224,7 @@ def run_g7(tape, scenario, seed, steps, churn):
         orig_slot(self)
         slot_rec.append([(0 if u.type == 0 else 1, int(u.e_snr), int(u.prbs), int(u.bits), float(u.queue),
                           float(u.th), float(np.ravel(u.p)[0])) for u in self.ues])
+        slot_ran.append([int(u.slice_ran_id) for u in self.ues])
     slice_l1.SliceL1eMBB.slot = slot_hook
     try:
         tape.clear()
@@ -234,14 +236,17 @@ def run_g7(tape, scenario, seed, steps, churn):
             rew.append(r)
             lab.append(np.asarray(inf['SLA_labels'], dtype=np.int32))
             vio.append(np.asarray(inf['violations'], dtype=np.int32))
-            row = np.zeros((n_slices, 10))
-            for s, l1 in enumerate(inf['l1_info']):
-                d = l1[0]
-                if 'cbr_th' in d:
-                    row[s] = [d[k] for k in EMBB_VARS]
-                else:
-                    row[s, :3] = [d[k] for k in MMTC_INFO]
-            info.append(row)
+            rows = []   # one row per RAN slice, L1 slices in order (one RAN slice per L1 slice when L1_level=True)
+            for l1 in inf['l1_info']:
+                for j in sorted(l1):
+                    d = l1[j]
+                    r_ = np.zeros(10)
+                    if 'cbr_th' in d:
+                        r_[:] = [d[k] for k in EMBB_VARS]
+                    else:
+                        r_[:3] = [d[k] for k in MMTC_INFO]
+                    rows.append(r_)
+            info.append(np.asarray(rows))
             for l1 in env.node_b.slices_l1:
                 if l1.type == 'mMTC':
                     g8_n.append(int(l1.n_users))
@@ -267,6 +272,8 @@ def run_g7(tape, scenario, seed, steps, churn):
                 slot_n_ue=n_ue, slot_ue_int=ue_int, slot_ue_f64=ue_f64,
                 g5_arrivals=np.asarray(g5_arr, dtype=np.int64).reshape(-1, 4),
                 g5_departures=np.asarray(g5_dep, dtype=np.int64).reshape(-1, 3),
+                slot_ue_ran=np.asarray([x for r in slot_ran for x in r], dtype=np.int32),
+                l1_level=np.int32(1 if l1_level else 0),
                 g8_n_users=np.asarray(g8_n, dtype=np.int64), g8_time=np.asarray(g8_time, dtype=np.int64),
                 g8_repetitions=np.asarray(g8_rep, dtype=np.int64), g8_t_start=np.asarray(g8_start, dtype=np.int64))
 
@@ -288,6 +295,22 @@ def gen_g7(tape):
             save('g7_s%d_run%d' % (scenario, k), **d)
 
 
+def gen_g13(tape):
+    """full steps with L1_level=False (scenario_creator.py:168-177): every eMBB RAN slice under ONE L1 slice / PF
+    scheduler, every mMTC RAN slice in ONE FIFO; the action has one entry per L1 slice"""
+    for scenario, steps in ((0, 16), (1, 16), (2, 12)):
+        for k in (0, 1):
+            seed = 40 + k
+            while True:
+                try:
+                    d = run_g7(tape, scenario, seed, steps, 1 if k else 0, l1_level=False)
+                    break
+                except KeyError:
+                    print('reference raised KeyError for seed %d, retrying' % seed)
+                    seed += 100
+            save('g13_mux_s%d_run%d' % (scenario, k), **d)
+
+
 # ----------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -300,7 +323,7 @@ def main():
     tape = rh.Tape()
     rh.install_tape(tape)
     save('fading_small', t0=tabs[0], t1=tabs[1], t2=tabs[2])
-    todo = args.only.split(',') if args.only else ['G1', 'G3', 'G4', 'G6', 'G7', 'G9', 'G12']
+    todo = args.only.split(',') if args.only else ['G1', 'G3', 'G4', 'G6', 'G7', 'G9', 'G12', 'G13']
     if 'G1' in todo:
         gen_g1_g2()
     if 'G3' in todo:
@@ -313,6 +336,8 @@ def main():
         gen_g7(tape)
     if 'G12' in todo:
         gen_g12()
+    if 'G13' in todo:
+        gen_g13(tape)
     if 'G9' in todo:
         try:
             import gen_golden_kbrl
