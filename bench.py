@@ -67,12 +67,13 @@ def _cpu_worker(args):
     from oracle import pyoracle as po
     from ranslice.config import make_config
     from ranslice.fading import synth_fading
+    from ranslice.sharding import replica_seed
     cfg = make_config(SCENARIO, n_envs=1, **cfg_kw)
     fading = [synth_fading(t, FADING_COLS) for t in range(3)]
     envs = []
     for r in replicas:
         o = po.OracleEnv(cfg, fading)
-        o.set_seed(r)
+        o.set_seed(replica_seed(0, r))
         o.reset()
         o.bench_run(ACTION_SEED, r, 0, burn)
         envs.append((r, o))

@@ -14,6 +14,7 @@
 #include "rs_embb.hip"
 #include "rs_mmtc.hip"
 #include "rs_order.hip"
+#include "rs_mux.hip"
 
 using namespace rs;
 
@@ -95,7 +96,9 @@ struct rs_handle {
     bool grant_auto = true;      // grant_mode follows the batch size / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
-    int n_slices = 0, n_vars = 0, n_tasks = 0;
+    int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
+    int n_ran = 0;                                // RAN slices (info rows): n_embb + n_mmtc
+    bool mux = false;                             // rs_config.l1_multiplex
     int64_t* d_run = nullptr;    // device-side run state read by the step kernels: [0] slots since reset,
                                  // [1] step index and [2] seed of the on-device action script (rs_run_random)
     hipGraph_t graph = nullptr;  // two captured steps (one per parity of the order counters) of rs_run_random
@@ -216,7 +219,7 @@ __global__ void finalize_kernel(const RsDev* D, const int32_t* actions, const in
         run[0] += D->slots;
         run[1] += 1;
     }
-    int S = D->n_slices;
+    int S = D->n_act;
     long tv = 0, ta = 0;
     for (int s = 0; s < S; ++s) {
         tv += viol[r * S + s];
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(256) void random_actions_kernel(const RsDev* D, int
     const int lane = threadIdx.x & 63;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= D->n_envs) return;
-    const int S = D->n_slices;
+    const int S = D->n_act;
     int my_bin[8];
     int cnt = 0;
     for (int p = lane; p < D->n_prbs; p += 64) {
@@ -316,7 +319,8 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     h->device = device;
     if (cfg->n_envs <= 0 || cfg->n_prbs <= 0 || cfg->n_prbs > RS_MAX_PRBS || cfg->n_embb < 0 || cfg->n_mmtc < 0 ||
         cfg->n_embb + cfg->n_mmtc <= 0 || cfg->slots_per_step <= 0 || cfg->n_mcs <= 0 || cfg->n_mcs > 32 ||
-        cfg->pf_granularity <= 0 || (cfg->max_ue != 0 && cfg->max_ue != RS_GROUP) ||
+        cfg->pf_granularity <= 0 || (cfg->max_ue != 0 && cfg->max_ue != (cfg->l1_multiplex ? RS_MUX_UE : RS_GROUP)) ||
+        (cfg->l1_multiplex && (cfg->n_embb > 6 || cfg->n_mmtc > RS_MUX_RAN)) ||
         (cfg->max_bursts != 0 && cfg->max_bursts != RS_BURSTS)) {
         h->err = "rs_create: unsupported configuration (n_prbs <= 256, max_ue in {0,32}, max_bursts in {0,8})";
         return RS_EINVAL;
@@ -338,7 +342,9 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     }
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    h->n_slices = cfg->n_embb + cfg->n_mmtc;
+    h->mux = cfg->l1_multiplex != 0;
+    h->n_ran = cfg->n_embb + cfg->n_mmtc;
+    h->n_slices = h->mux ? (cfg->n_embb > 0) + (cfg->n_mmtc > 0) : h->n_ran;
     h->n_vars = cfg->n_embb * RS_N_EMBB_VARS + cfg->n_mmtc * RS_N_MMTC_VARS;
     h->n_tasks = cfg->n_envs * cfg->n_embb;
 
@@ -348,7 +354,9 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     d.n_prbs = cfg->n_prbs;
     d.n_embb = cfg->n_embb;
     d.n_mmtc = cfg->n_mmtc;
-    d.n_slices = h->n_slices;
+    d.n_slices = h->n_ran;
+    d.n_act = h->n_slices;
+    d.mux = h->mux ? 1 : 0;
     d.slots = cfg->slots_per_step;
     d.n_vars = h->n_vars;
     d.slot_length = cfg->slot_length;
@@ -453,7 +461,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_reward, N);
     DA(h->d_labels, N * h->n_slices);
     DA(h->d_viol, N * h->n_slices);
-    DA(h->d_info, N * h->n_slices * 10);
+    DA(h->d_info, N * h->n_ran * 10);
     DA(h->d_counters, (T ? T : 1) * 4);
     DA(h->d_counter_sum, 4);
     DA(h->d_sections, 16 + 4 * (T ? T : 1) + 16);
@@ -629,6 +637,60 @@ static int launch_step(rs_handle* h) {
     if (h->clock > 2000000000 - h->cfg.slots_per_step) {
         h->err = "rs_step: slot clock would overflow; reset the environment";
         return RS_ESTATE;
+    }
+    if (h->mux) {
+        if (h->n_tasks > 0) {
+            StepArgs a;
+            memset(&a, 0, sizeof a);
+            a.D = h->ddev;
+            a.S = h->d_st;
+            a.fad = h->fad;
+            a.fad_valid = h->fad_valid;
+            a.actions = h->d_actions;
+            a.run = h->d_run;
+            a.obs = h->d_obs;
+            a.labels = h->d_labels;
+            a.violations = h->d_viol;
+            a.info = h->d_info;
+            a.counters = h->d_counters;
+            a.trace = h->d_trace;
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (h->timing) {
+                if (h->ev_used == h->ev.size()) {
+                    hipEvent_t a0, a1;
+                    HIPCHK(h, hipEventCreate(&a0));
+                    HIPCHK(h, hipEventCreate(&a1));
+                    h->ev.emplace_back(a0, a1);
+                }
+                e0 = h->ev[h->ev_used].first;
+                e1 = h->ev[h->ev_used].second;
+                h->ev_used++;
+                HIPCHK(h, hipEventRecord(e0, h->stream));
+            }
+            if (h->trace_on) hipLaunchKernelGGL((embb_mux_step_kernel<true>), dim3((unsigned)h->cfg.n_envs), dim3(64), 0, h->stream, a);
+            else hipLaunchKernelGGL((embb_mux_step_kernel<false>), dim3((unsigned)h->cfg.n_envs), dim3(64), 0, h->stream, a);
+            if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
+        }
+        if (h->cfg.n_mmtc > 0) {
+            rs::MtcArgs ma;
+            ma.D = h->ddev;
+            ma.M = h->mst;
+            ma.actions = h->d_actions;
+            ma.run = h->d_run;
+            ma.obs = h->d_obs;
+            ma.labels = h->d_labels;
+            ma.violations = h->d_viol;
+            ma.info = h->d_info;
+            ma.err = h->st.err;
+            const size_t lds = ((size_t)2 * h->mst.cap * h->cfg.n_mmtc + (size_t)h->cfg.n_mmtc * MTC_DEV_MAX) * sizeof(int32_t);
+            hipLaunchKernelGGL(rs::mtc_mux_step_kernel, dim3((unsigned)h->cfg.n_envs), dim3(64), lds, h->stream, ma);
+        }
+        hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,
+                           h->d_actions, h->d_viol, h->d_reward, h->d_run);
+        HIPCHK(h, hipGetLastError());
+        h->clock += h->cfg.slots_per_step;
+        h->steps += 1;
+        return RS_OK;
     }
     if (h->n_tasks > 0) {
         StepArgs a;
@@ -851,7 +913,7 @@ extern "C" int rs_run_random(rs_handle* h, uint64_t seed, uint64_t step_index0, 
 extern "C" int rs_get_info(rs_handle* h, double* info) {
     if (!h || !info) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof(double) * (size_t)h->cfg.n_envs * h->n_slices * 10,
+    HIPCHK(h, hipMemcpyAsync(info, h->d_info, sizeof(double) * (size_t)h->cfg.n_envs * h->n_ran * 10,
                              hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;
@@ -862,6 +924,7 @@ extern "C" int rs_set_alloc_trace(rs_handle* h, int enable) {
     HIPCHK(h, hipSetDevice(h->device));
     if (enable && !h->d_trace) {
         size_t n = (size_t)h->n_tasks * h->cfg.slots_per_step * RS_GROUP;
+        if (h->mux) n = (size_t)h->cfg.n_envs * h->cfg.slots_per_step * RS_MUX_UE;
         HIPCHK(h, hipMalloc((void**)&h->d_trace, sizeof(rs_alloc_rec) * (n ? n : 1)));
     }
     h->trace_on = enable != 0;
@@ -873,6 +936,7 @@ extern "C" int rs_get_alloc_trace(rs_handle* h, rs_alloc_rec* out) {
     if (!h || !out || !h->d_trace) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     size_t n = (size_t)h->n_tasks * h->cfg.slots_per_step * RS_GROUP;
+    if (h->mux) n = (size_t)h->cfg.n_envs * h->cfg.slots_per_step * RS_MUX_UE;  // [n_envs][slots][64]
     HIPCHK(h, hipMemcpyAsync(out, h->d_trace, sizeof(rs_alloc_rec) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return RS_OK;

@@ -18,7 +18,9 @@
 
 // Immutable parameters, one copy in HBM, read through scalar loads.
 struct RsDev {
-    int32_t n_envs, n_prbs, n_embb, n_mmtc, n_slices, slots, n_vars;
+    int32_t n_envs, n_prbs, n_embb, n_mmtc, n_slices, slots, n_vars;  // n_slices = RAN slices (info rows)
+    int32_t n_act;          // action / label entries per replica: n_slices, or one per L1 slice when multiplexed
+    int32_t mux;            // rs_config.l1_multiplex
     int32_t P;              // row length of the fading tables (PRBs after row extension)
     int32_t T[3];           // time samples per trace
     int32_t has_nan;        // any trace column flagged invalid

@@ -31,6 +31,7 @@
 //     bits: for the others the Bernoulli draw is consumed (the stream counter advances) but cannot change state.
 // Compiled with -ffp-contract=off: all f64 arithmetic is IEEE and in the oracle's order.
 
+#pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -454,6 +455,50 @@ __device__ __forceinline__ void walker_advance(int& findex, int& fstep, int Tn, 
         if (findex >= Tn || findex < 0) rs_walker_redraw(key0, key1, sl, serial, now, attempt++, Tn, &findex, &fstep);
         if (!has_nan || valid_col[findex]) break;
     }
+}
+
+// Response sums of the spans flagged `mine` (at most RS_WIDE_SPAN RBs each, or wider than RS_WIDE_MAX): R1 + R2 fused --
+// np.mean's pairwise sum of the mutual information over a UE's RBs (channel_models.py:303-307).  The spans of the
+// whole wave are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator R_j: it evaluates the
+// sigmoid of its elements one after the other and adds them in numpy's order, the team meets for the tree and the
+// remainder.  No per-RB values are stored anywhere.  Returns the lane's own sum (or `keep` if it has no span).
+__device__ __forceinline__ double team_response(const RsDev* D, const double* fad, const double* nom_wave, bool mine,
+                                                int rbs, int span_col, int mod, double keep) {
+    const int lane = (int)(threadIdx.x & 63u);
+    const double x0_0 = D->mi_x0[0], x0_1 = D->mi_x0[1], x0_2 = D->mi_x0[2];
+    const double kk_0 = D->mi_k[0], kk_1 = D->mi_k[1], kk_2 = D->mi_k[2];
+    double sum_rx = keep;
+    const unsigned long long wmask = __builtin_amdgcn_ballot_w64(mine);
+    const int n_sp = __popcll(wmask);
+    const int my_sp = __popcll(wmask & ((1ull << lane) - 1ull));   // my span's index in the wave
+    const int team = lane >> 3, j = lane & 7;
+    unsigned long long rest = wmask;
+    for (int round = 0; round * 8 < n_sp; ++round) {
+        // owners of this round's 8 spans (uniform), then mine by team
+        int owner = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = rest ? __builtin_ctzll(rest) : 0;
+            rest &= rest - 1ull;
+            owner = team == k ? o : owner;
+        }
+        const bool on = round * 8 + team < n_sp;
+        const int c0 = bperm(span_col, owner);
+        const int n = bperm(rbs, owner);
+        const int md = bperm(mod, owner);
+        const double nom = nom_wave[owner];
+        const double x0 = sel3(md, x0_0, x0_1, x0_2), kk = sel3(md, kk_0, kk_1, kk_2);
+        const double* __restrict__ sp = fad + (on ? c0 : 0);
+        // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
+        const bool single = n == 1;
+        const double sv = team_pairwise(n, j, on, [&](int i) {
+            const double x = sp[i] + nom;
+            return single ? x : rs_sigmoid(x, x0, kk);
+        });
+        const double got = bperm(sv, (my_sp & 7) << 3);
+        if (mine && (my_sp >> 3) == round) sum_rx = got;
+    }
+    return sum_rx;
 }
 
 // Response sums of spans wider than RS_WIDE_SPAN RBs (an agent's allocation: ~180 RBs in one slice).  In a team such a
@@ -1132,38 +1177,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
             constexpr int WIDE = RS_WIDE_SPAN;
             const bool wide_sp = needed && rbs > WIDE && rbs <= RS_WIDE_MAX;
             if (wave_any(wide_sp)) sum_rx = wide_response(D, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
-            {
-                const unsigned long long wmask = __builtin_amdgcn_ballot_w64(needed && !wide_sp);
-                const int n_sp = __popcll(wmask);
-                const int my_sp = __popcll(wmask & ((1ull << lane) - 1ull));   // my span's index in the wave
-                const int team = lane >> 3, j = lane & 7;
-                unsigned long long rest = wmask;
-                for (int round = 0; round * 8 < n_sp; ++round) {
-                    // owners of this round's 8 spans (uniform), then mine by team
-                    int owner = 0;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int o = rest ? __builtin_ctzll(rest) : 0;
-                        rest &= rest - 1ull;
-                        owner = team == k ? o : owner;
-                    }
-                    const bool on = round * 8 + team < n_sp;
-                    const int c0 = bperm(span_col, owner);
-                    const int n = bperm(rbs, owner);
-                    const int md = bperm(mod, owner);
-                    const double nom = L_nom[wb + owner];
-                    const double x0 = sel3(md, x0_0, x0_1, x0_2), kk = sel3(md, kk_0, kk_1, kk_2);
-                    const double* __restrict__ sp = A.fad + (on ? c0 : 0);
-                    // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
-                    const bool single = n == 1;
-                    const double sv = team_pairwise(n, j, on, [&](int i) {
-                        const double x = sp[i] + nom;
-                        return single ? x : rs_sigmoid(x, x0, kk);
-                    });
-                    const double got = bperm(sv, (my_sp & 7) << 3);
-                    if (needed && !wide_sp && (my_sp >> 3) == round) sum_rx = got;
-                }
-            }
+            sum_rx = team_response(D, A.fad, &L_nom[wb], needed && !wide_sp, rbs, span_col, mod, sum_rx);
             SEC_MARK(10)
             // R3: effective SNR and reception probability, every evaluated UE in its own lane
             if (needed) {

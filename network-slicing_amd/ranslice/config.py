@@ -105,7 +105,7 @@ class RsAllocRec(C.Structure):
 
 
 def make_config(scenario, n_envs=1, slots_per_step=50, propagation_type='macro_cell_urban_2GHz', penalty=100,
-                n_prbs=None, n_embb=None, n_mmtc=None, max_ue=0, max_bursts=0, max_mtc_queue=0):
+                n_prbs=None, n_embb=None, n_mmtc=None, max_ue=0, max_bursts=0, max_mtc_queue=0, L1_level=True):
     """Build the rs_config for scenario index `scenario` exactly as create_env would wire it
     (reference scenario_creator.py:100-183)."""
     sc = dict(SCENARIOS[scenario]) if scenario is not None else {}
@@ -120,6 +120,7 @@ def make_config(scenario, n_envs=1, slots_per_step=50, propagation_type='macro_c
     cfg.n_prbs, cfg.n_embb, cfg.n_mmtc = sc['n_prbs'], sc['n_embb'], sc['n_mmtc']
     cfg.slots_per_step = slots_per_step
     cfg.max_ue, cfg.max_bursts, cfg.max_mtc_queue = max_ue, max_bursts, max_mtc_queue
+    cfg.l1_multiplex = 0 if L1_level else 1   # create_env(..., L1_level) (scenario_creator.py:156-177)
     cfg.slot_length = 1e-3
     cfg.penalty = penalty
     cfg.cbr_lambda, cfg.cbr_t_mean, cfg.cbr_bit_rate = (CBR_DESCRIPTION['lambda'], CBR_DESCRIPTION['t_mean'],

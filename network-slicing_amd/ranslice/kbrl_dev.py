@@ -9,6 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from .sharding import replica_seeds
 from .config import KbConfig, KBRL_ALFA, KBRL_ETA, KBRL_GAMMA
 
 _dp = C.POINTER(C.c_double)
@@ -55,7 +56,7 @@ class VecKBRL:
         ia = np.ascontiguousarray(initial_action, dtype=np.int32).reshape(self.n_envs, self.S)
         sf = np.ascontiguousarray(security_factor, dtype=np.int32).reshape(self.n_envs, self.S)
         if seeds is None:
-            seeds = np.arange(self.n_envs, dtype=np.uint64)
+            seeds = replica_seeds(0, self.cfg.first_env, self.n_envs)   # tie-break streams (kernel.py:26-27)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         self._check(self.L.kb_reset(self.h, ia.ctypes.data_as(_ip), sf.ctypes.data_as(_ip), seeds.ctypes.data_as(_up)))
 

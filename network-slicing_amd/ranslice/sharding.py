@@ -18,10 +18,27 @@ def shard_range(global_n, rank, world):
     return first, base + (1 if rank < extra else 0)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def replica_seed(base_seed, replica_id):
+    """64-bit stream seed of global replica `replica_id` of the batch seeded with `base_seed`: a SplitMix64 mix of
+    both, so that batches with nearby base seeds share no trajectories (base + id would make replica 1 of seed 0 the
+    same environment as replica 0 of seed 1)."""
+    return _splitmix64((_splitmix64(int(base_seed) & _M64) + int(replica_id)) & _M64)
+
+
 def replica_seeds(base_seed, first, count):
-    """Stream seed of global replica i is base_seed + i, whatever the number of GPUs: a replica's
-    trajectory does not depend on how the batch is sharded (tests/test_gpu_parity.py)."""
-    return (np.uint64(base_seed) + np.arange(first, first + count, dtype=np.uint64)).astype(np.uint64)
+    """Seeds of the global replicas first .. first+count-1, whatever the number of GPUs: a replica's trajectory
+    does not depend on how the batch is sharded (tests/test_gpu_parity.py)."""
+    return np.array([replica_seed(base_seed, i) for i in range(first, first + count)], dtype=np.uint64)
 
 
 def aggregate_throughput(units_per_rank, world, seconds_max):

@@ -12,6 +12,7 @@ import numpy as np
 from . import _lib
 from .config import RsAllocRec, make_config, n_vars
 from .fading import synth_fading
+from .sharding import replica_seeds
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -30,7 +31,11 @@ class VecRanSlice:
         self.cfg = cfg if cfg is not None else make_config(scenario, n_envs=n_envs, **cfg_kw)
         self.cfg.n_envs = n_envs
         self.n_envs = n_envs
-        self.n_slices = self.cfg.n_embb + self.cfg.n_mmtc
+        self.n_ran = self.cfg.n_embb + self.cfg.n_mmtc
+        # action / label entries per replica: one per L1 slice (with L1_level=False all eMBB RAN slices share one L1
+        # slice and all mMTC ones another, scenario_creator.py:168-177)
+        self.multiplexed = bool(self.cfg.l1_multiplex)
+        self.n_slices = ((self.cfg.n_embb > 0) + (self.cfg.n_mmtc > 0)) if self.multiplexed else self.n_ran
         self.n_variables = n_vars(self.cfg)
         self.n_prbs = self.cfg.n_prbs
         self.penalty = self.cfg.penalty
@@ -67,10 +72,11 @@ class VecRanSlice:
 
     # ---- gym-like surface -------------------------------------------------------------
     def reset(self, seeds=None):
-        """seeds: per-replica 64-bit stream seeds; default base_seed + replica index
-        (the reference seeds run i with default_rng(seed=i), experiments_kbrl.py:46)."""
+        """seeds: per-replica 64-bit stream seeds; default sharding.replica_seeds(base_seed, 0, n_envs), a mix of
+        the batch seed and the replica index (the reference seeds run i with default_rng(seed=i),
+        experiments_kbrl.py:46)."""
         if seeds is None:
-            seeds = self.base_seed + np.arange(self.n_envs, dtype=np.uint64)
+            seeds = replica_seeds(self.base_seed, 0, self.n_envs)
         seeds = np.ascontiguousarray(seeds, dtype=np.uint64)
         assert seeds.shape == (self.n_envs,)
         self._check(self.L.rs_reset(self.h, seeds.ctypes.data_as(_up), self._obs.ctypes.data_as(_fp)))
@@ -110,7 +116,7 @@ class VecRanSlice:
 
     # ---- introspection ------------------------------------------------------------------
     def l1_info(self):
-        info = np.zeros((self.n_envs, self.n_slices, 10), dtype=np.float64)
+        info = np.zeros((self.n_envs, self.n_ran, 10), dtype=np.float64)   # one row per RAN slice
         self._check(self.L.rs_get_info(self.h, info.ctypes.data_as(_dp)))
         return info
 
@@ -126,7 +132,9 @@ class VecRanSlice:
         self._check(self.L.rs_set_alloc_trace(self.h, int(bool(enable))))
 
     def alloc_trace(self):
-        tr = np.zeros((self.n_envs, self.cfg.n_embb, self.cfg.slots_per_step, 32), dtype=np.dtype(RsAllocRec))
+        shape = ((self.n_envs, self.cfg.slots_per_step, 64) if self.multiplexed   # the one shared UE list; type >> 8 = RAN slice
+                 else (self.n_envs, self.cfg.n_embb, self.cfg.slots_per_step, 32))
+        tr = np.zeros(shape, dtype=np.dtype(RsAllocRec))
         self._check(self.L.rs_get_alloc_trace(self.h, tr.ctypes.data_as(C.c_void_p)))
         return tr
 

@@ -36,14 +36,14 @@ def set_fading(tables):
 
 def create_env(rng, n, slots_per_step=50, propagation_type='macro_cell_urban_2GHz', L1_level=True, penalty=100,
                device=0):
-    """scenario_creator.py:100-183.  `rng` seeds the replica's counter-based streams (one draw)."""
-    if not L1_level:
-        raise NotImplementedError('L1_level=False (multiplexed slices) is not built yet (SURVEY.md §8f-3)')
+    """scenario_creator.py:100-183.  `rng` seeds the replica's counter-based streams (one draw).
+    L1_level=False multiplexes the slices in the L1 (scenario_creator.py:168-177): the env then has one action entry
+    per L1 slice -- one for all eMBB RAN slices, one for all mMTC ones."""
     global _FADING
     if _FADING is None:
         _FADING = default_fading()
     cfg = _c.make_config(n, n_envs=1, slots_per_step=slots_per_step, propagation_type=propagation_type,
-                         penalty=penalty)
+                         penalty=penalty, L1_level=L1_level)
     vec = VecRanSlice(n_envs=1, cfg=cfg, fading=_FADING, device=device)
     node = NodeB(vec)
     node.seed(int(rng.integers(0, 2 ** 63 - 1)))

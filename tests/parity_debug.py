@@ -21,7 +21,7 @@ if TR: env.set_alloc_trace(True)
 env.reset()
 ors = []
 for r in range(N):
-    o = po.OracleEnv(mk(1), fading); o.set_seed(7 + r); o.reset(); ors.append(o)
+    o = po.OracleEnv(mk(1), fading); o.set_seed(__import__('ranslice.sharding', fromlist=['x']).replica_seed(7, r)); o.reset(); ors.append(o)
 rng = np.random.default_rng(1)
 for i in range(12):
     acts = rng.multinomial(200, [1/6]*6, size=N)[:, :5].astype(np.int32)

@@ -51,6 +51,7 @@ def test_loaded_traces_drive_the_simulator(tmp_path):
     """files -> loaders -> rs_load_fading: bit-exact against the oracle fed the in-memory tables, through NaN columns"""
     from oracle import pyoracle as po
     from ranslice.config import make_config
+    from ranslice.sharding import replica_seed, replica_seeds  # noqa: F401
     from ranslice.vec_env import VecRanSlice
     tabs = _tables()
     loaded = load_traces(_write(tmp_path, tabs))
@@ -64,7 +65,7 @@ def test_loaded_traces_drive_the_simulator(tmp_path):
     oracles = []
     for r in range(n):
         o = po.OracleEnv(ocfg, tabs)
-        o.set_seed(31 + r)
+        o.set_seed(replica_seed(31, r))
         o.reset()
         oracles.append(o)
     rng = np.random.default_rng(2)

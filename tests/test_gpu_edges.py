@@ -8,6 +8,7 @@ import pytest
 from oracle import pyoracle as po
 from ranslice import _lib
 from ranslice.config import make_config
+from ranslice.sharding import replica_seed, replica_seeds  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -33,7 +34,7 @@ def _run(cfg_fn, n_envs, action_rows, fading, seed=11, group=None):
     ors = []
     for r in range(n_envs):
         o = po.OracleEnv(cfg_fn(1), fading)
-        o.set_seed(seed + r)
+        o.set_seed(replica_seed(seed, r))
         o.reset()
         ors.append(o)
     for i, acts in enumerate(action_rows):
@@ -227,3 +228,80 @@ def test_schedule_hint_does_not_change_results(golden_dir, group):
             assert (o[3]['SLA_labels'] == outs[0][3]['SLA_labels']).all()
             assert (o[3]['violations'] == outs[0][3]['violations']).all()
             assert inf.tobytes() == infos[0].tobytes()
+
+
+def _mux_compare(golden_dir, scenario, n_envs, steps, churn, seed0, trace):
+    from oracle import pyoracle as po
+    from ranslice.vec_env import VecRanSlice
+    fading = _fading(golden_dir)
+
+    def cfgf(n):
+        c = make_config(scenario, n_envs=n, L1_level=False)
+        return _churn(c) if churn else c
+    env = VecRanSlice(n_envs=n_envs, cfg=cfgf(n_envs), fading=fading, seed=seed0)
+    n_l1 = (env.cfg.n_embb > 0) + (env.cfg.n_mmtc > 0)
+    assert env.multiplexed and env.n_slices == n_l1
+    if trace:
+        env.set_alloc_trace(True)
+    env.reset()
+    oracles = []
+    for r in range(n_envs):
+        o = po.OracleEnv(cfgf(1), fading)
+        o.set_seed(replica_seed(seed0, r))
+        o.reset()
+        oracles.append(o)
+    rng = np.random.default_rng(17 + scenario)
+    n_prbs = env.n_prbs
+    for i in range(steps):
+        if i % 4 == 0:
+            acts = np.stack([rng.multinomial(n_prbs, [1.0 / n_l1] * n_l1) for _ in range(n_envs)])
+        elif i % 4 == 2:
+            acts = rng.integers(0, 6, size=(n_envs, n_l1))
+        else:
+            acts = np.stack([rng.multinomial(n_prbs, [1.0 / (n_l1 + 1)] * (n_l1 + 1))[:n_l1] for _ in range(n_envs)])
+        acts = acts.astype(np.int32)
+        obs, rew, _, info = env.step(acts)
+        l1 = env.l1_info()
+        tr = env.alloc_trace() if trace and env.cfg.n_embb else None
+        for r, o in enumerate(oracles):
+            out = o.step(acts[r], trace=tr is not None)
+            assert obs[r].tobytes() == out['obs'].tobytes(), ('obs', i, r)
+            assert rew[r] == out['reward']
+            assert (info['SLA_labels'][r] == out['labels']).all() and (info['violations'][r] == out['violations']).all()
+            assert l1[r].tobytes() == out['info'].tobytes(), ('info', i, r)
+            if tr is not None:
+                a, b = tr[r], out['trace'][0]
+                for f in ('serial', 'type', 'e_snr', 'prbs', 'bits'):
+                    assert (a[f] == b[f]).all(), (f, i, r)
+                for f in ('queue', 'th', 'p'):
+                    assert a[f].tobytes() == b[f].tobytes(), (f, i, r)
+    c = env.counters()
+    tot = np.sum([o.counters() for o in oracles], axis=0)
+    assert c[0] == tot[0] and c[2] == tot[2] and c[3] == tot[3], (c, tot)
+    env.close()
+
+
+@pytest.mark.parametrize('scenario', [0, 1, 2])
+def test_multiplexed_l1_matches_oracle(golden_dir, scenario):
+    """create_env(..., L1_level=False) (scenario_creator.py:168-177; the oracle's multiplexed mode is pinned to the
+    reference by fixtures G13): one UE list / PF scheduler for all eMBB RAN slices, one FIFO for all mMTC ones.
+    Bit-exact: observations, rewards, labels / violations per L1 slice, info rows per RAN slice, and every UE of the
+    shared list in every slot (RAN slice, e_snr, RBs, bits, queue, throughput, reception probability)."""
+    _mux_compare(golden_dir, scenario, n_envs=12, steps=14, churn=True, seed0=640, trace=True)
+    _mux_compare(golden_dir, scenario, n_envs=20, steps=10, churn=False, seed0=7, trace=False)
+
+
+def test_multiplexed_drop_in_env(golden_dir):
+    """the drop-in surface: create_env(rng, n, L1_level=False) -> gym env with one action entry per L1 slice and the
+    reference's info layout (l1_info[l1][ran index])"""
+    import scenario_creator as sc
+    sc.set_fading(_fading(golden_dir))
+    env = sc.create_env(np.random.default_rng(3), 1, L1_level=False)
+    assert env.n_slices == 2 and env.n_variables == 3 * 10 + 2 * 3
+    st = env.reset()
+    assert st.shape == (36,)
+    st, r, done, info = env.step(np.array([100, 20]))
+    assert len(info['l1_info']) == 2 and sorted(info['l1_info'][0]) == [0, 1, 2] and sorted(info['l1_info'][1]) == [0, 1]
+    assert set(info['l1_info'][0][0]) == set(sc.state_variables_embb) and 'delay' in info['l1_info'][1][1]
+    assert info['SLA_labels'].shape == (2,) and isinstance(r, float)
+    sc.set_fading(None)

@@ -11,6 +11,7 @@ import pytest
 
 from oracle import pyoracle as po
 from ranslice.config import make_config
+from ranslice.sharding import replica_seed, replica_seeds  # noqa: F401
 from ranslice.fading import synth_fading
 
 pytestmark = pytest.mark.gpu
@@ -84,7 +85,7 @@ def test_bench_path_steady_state_vs_oracle():
     steps = 500
     cfg = make_config(0, n_envs=N_FULL)
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
-        fut = ex.map(_oracle_script_run, [(0, r, r, steps, COLS) for r in SAMPLE], chunksize=1)
+        fut = ex.map(_oracle_script_run, [(0, replica_seed(0, r), r, steps, COLS) for r in SAMPLE], chunksize=1)
         env = VecRanSlice(n_envs=N_FULL, cfg=cfg, fading=_fading())
         env.reset()
         hip = []
@@ -141,7 +142,7 @@ def test_soak_every_replica(golden_dir, scenario, n, steps):
     ns = cfg.n_embb + cfg.n_mmtc
     acts = [_actions(rng, n, ns, cfg.n_prbs, i) for i in range(steps)]
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
-        fut = ex.map(_oracle_acts_run, [(scenario, seed0 + r, [a[r] for a in acts], True) for r in range(n)],
+        fut = ex.map(_oracle_acts_run, [(scenario, replica_seed(seed0, r), [a[r] for a in acts], True) for r in range(n)],
                      chunksize=8)
         env = VecRanSlice(n_envs=n, cfg=cfg, fading=[g['t0'], g['t1'], g['t2']], seed=seed0)
         env.set_group_size(16)

@@ -11,6 +11,7 @@ import pytest
 
 from oracle import pyoracle as po
 from ranslice.config import make_config
+from ranslice.sharding import replica_seed, replica_seeds  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 # oracle workers are SPAWNED: forking a process whose HIP runtime is already initialised is not safe
@@ -108,7 +109,7 @@ def test_batched_agents_vs_oracle(golden_dir):
     oe, oa = [], []
     for r in range(N):
         e = po.OracleEnv(make_config(scenario), fading)
-        e.set_seed(50 + r)
+        e.set_seed(replica_seed(50, r))
         e.reset()
         a = po.OracleKBRL(dims, n_prbs, ia[r], sf[r], capacity=256)
         a.set_seed(7 + r)
@@ -258,7 +259,7 @@ def test_full_size_closed_loop_vs_oracle():
     sample = [0, 1, 2, 3, 15, 16, 63, 64, 100, 255, 256, 777, 1023, 1024, 2000, 2047, 2048, 3000, 3333, 4000, 4093,
               4094, 4095, 1234]
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
-        fut = ex.map(_oracle_closed_loop, [(scenario, 300 + r, 7 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
+        fut = ex.map(_oracle_closed_loop, [(scenario, replica_seed(300, r), 7 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
                      chunksize=1)
         env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)],
                           seed=300)

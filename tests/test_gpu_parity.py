@@ -12,6 +12,7 @@ import pytest
 
 from oracle import pyoracle as po
 from ranslice.config import make_config
+from ranslice.sharding import replica_seed, replica_seeds  # noqa: F401
 from ranslice.fading import synth_fading
 
 pytestmark = pytest.mark.gpu
@@ -64,7 +65,7 @@ def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sa
     oracles = []
     for r in reps:
         o = po.OracleEnv(ocfg, fading)
-        o.set_seed(seed0 + r)
+        o.set_seed(replica_seed(seed0, r))
         o.reset()
         oracles.append(o)
     rng = np.random.default_rng(99 + scenario)
@@ -151,7 +152,7 @@ def test_crowded_slices_replay(golden_dir):
         e.reset()
         envs[g] = e
     o = po.OracleEnv(cfgf(1), fading)
-    o.set_seed(3 + 5)
+    o.set_seed(replica_seed(3, 5))
     o.reset()
     rng = np.random.default_rng(1)
     peak = 0
@@ -199,9 +200,9 @@ def test_full_size_invariants(scenario):
     N = 4096
     cfg = make_config(scenario, n_envs=N)
     env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading, seed=123)
-    half = VecRanSlice(n_envs=N // 8, cfg=make_config(scenario, n_envs=N // 8), fading=fading, seed=123 + 1024)
+    half = VecRanSlice(n_envs=N // 8, cfg=make_config(scenario, n_envs=N // 8), fading=fading)
     env.reset()
-    half.reset()
+    half.reset(seeds=replica_seeds(123, 1024, N // 8))   # the same global replicas 1024.. in a smaller batch
     rng = np.random.default_rng(8)
     S = cfg.n_embb + cfg.n_mmtc
     for i in range(30):

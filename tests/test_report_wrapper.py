@@ -29,6 +29,7 @@ def test_vec_report_wrapper_on_the_batched_env(golden_dir, tmp_path):
     simulator's (checked against the oracle replica by replica)."""
     from oracle import pyoracle as po
     from ranslice.config import make_config
+    from ranslice.sharding import replica_seed
     from ranslice.report import VecReportWrapper, normalise_obs, simplex_to_prbs
     from ranslice.vec_env import VecRanSlice
     g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
@@ -41,7 +42,7 @@ def test_vec_report_wrapper_on_the_batched_env(golden_dir, tmp_path):
     oracles = []
     for r in range(n):
         o = po.OracleEnv(make_config(0, n_envs=1), fading)
-        o.set_seed(77 + r)
+        o.set_seed(replica_seed(77, r))
         o.reset()
         oracles.append(o)
     rng = np.random.default_rng(9)
