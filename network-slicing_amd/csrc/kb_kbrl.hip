@@ -213,7 +213,7 @@ __device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
 // Projectron.update (projectron.py:39-60) for x = (sm.x[0..d-2], t_last), given its kernel column in sm.kf.
 // Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.
 __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, double t_last, int y,
-                            Lds& sm, int* branch, double* delta_out) {
+                            Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
     const int cap = D.cap;
     double* Kinv = K.Kinv + (size_t)dict * cap * cap;
     double* coeffg = K.coeff + (size_t)dict * cap;
@@ -250,6 +250,7 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     // and by the host classes as a warning, not as an error).
     const bool full = m >= cap;
     if (delta > D.eta && full && threadIdx.x == 0) atomicOr(&K.err[err_env], 8);
+    if (saturated) *saturated = delta > D.eta && full;
     if (delta <= D.eta || full) {
         *branch = 1;
         for (int j = threadIdx.x; j < m; j += blockDim.x) {
@@ -399,7 +400,12 @@ __global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
         kernel_column(D, m, cstar, sm);
         int branch;
         double delta;
-        const int m_new = apply_update(D, K, dict, env, m, d, (double)cstar / (double)n, y, sm, &branch, &delta);
+        bool saturated;
+        const int m_new = apply_update(D, K, dict, env, m, d, (double)cstar / (double)n, y, sm, &branch, &delta, &saturated);
+        // A FULL dictionary that met a sample it would have added cannot represent this region: the remaining
+        // candidates would meet the same wall one O(m^2) projection at a time, so the augmentation of this learner
+        // stops for this step (build-defined; the reference's dictionary is unbounded; the oracle does the same)
+        if (saturated) break;
         c_from = cstar + 1;
         rescore = true;
         if (branch == 2 && m_new > m) {

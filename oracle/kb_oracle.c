@@ -38,6 +38,7 @@ struct kb_oracle {
     int use_tape;
     int64_t n_predict, n_mistakes;
     int err;
+    int saturated_now; /* set by kbo_update when a full dictionary had to project a sample it would have added */
 };
 
 kb_oracle* kbo_create(int n_slices, const int32_t* dims, int n_prbs, double alfa, double acc_lo, double acc_hi,
@@ -193,7 +194,10 @@ int kbo_update(kb_oracle* a, int s, const double* x, int y, double* delta_out) {
     if (delta_out) *delta_out = delta;
     /* build-defined: a dictionary at its capacity projects every further sample onto its span instead of growing
      * (the reference's SVvariable grows without bound); err = 2 records that it happened */
-    if (delta > a->eta && m >= l->cap) a->err = 2;
+    if (delta > a->eta && m >= l->cap) {
+        a->err = 2;
+        a->saturated_now = 1; /* tells update_control to stop augmenting this learner for this step */
+    }
     if (delta <= a->eta || m >= l->cap) {
         /* SVvariable.update (projectron.py:13-14); the single-landmark coeff array is float32 */
         if (m == 1)
@@ -320,7 +324,12 @@ void kbo_update_control(kb_oracle* a, const float* state, const int32_t* action,
         for (int c = from; c <= to; ++c) {
             make_x(a, i, state, c, x);
             (void)kbo_predict(a, i, x, NULL);
+            a->saturated_now = 0;
             (void)kbo_update(a, i, x, y, NULL);
+            /* build-defined: a FULL dictionary that met a sample it would have added cannot represent this region;
+             * the remaining candidates of the range would meet the same wall one O(m^2) projection at a time, so
+             * the augmentation of this learner stops for this step (the reference's dictionary is unbounded) */
+            if (a->saturated_now) break;
         }
     }
 }
