@@ -41,7 +41,7 @@ typedef struct rs_config {
     int32_t n_mmtc;
     int32_t slots_per_step; /* scenario_creator.py:100 (50) */
     int32_t max_ue;         /* capacity: UEs per eMBB slice (0 -> 32) */
-    int32_t max_bursts;     /* capacity: active VBR bursts per UE (0 -> 8) */
+    int32_t max_bursts;     /* capacity: VBR bursts running at once per UE (0 -> 16) */
     int32_t max_mtc_queue;  /* capacity: backlogged mMTC devices per slice (0 -> 1024) */
     double slot_length;     /* 1e-3 s */
     double penalty;         /* ran_slice.py:19 */

@@ -776,7 +776,9 @@ static int check_errors(rs_handle* h) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     for (size_t i = 0; i < e.size(); ++i)
         if (e[i]) {
-            h->err = "capacity exceeded (UEs per slice, bursts per UE or mMTC queue) in replica " + std::to_string(i);
+            h->err = std::string("capacity exceeded in replica ") + std::to_string(i) + ":" +
+                     ((e[i] & 1) ? " UEs per slice" : "") + ((e[i] & 2) ? " active VBR bursts per UE" : "") +
+                     ((e[i] & 4) ? " backlogged mMTC devices" : "");
             return RS_EOVERFLOW;
         }
     return RS_OK;

@@ -11,10 +11,17 @@
 #include <stdint.h>
 
 #define RS_GROUP 32          // lanes per task == UE capacity per slice
-#define RS_BURSTS 8          // VBR burst slots per UE
+#define RS_BURSTS 16         // VBR bursts that can run at once per UE (8 overflowed once per ~1e11 UE-slots: a bench run)
+#define RS_BURST_MAX_LEN 16000  // longest burst the 15-bit end-time code holds (P(Exp(500) >= 16000) = 1e-14)
 #define RS_LUT_MAX 64
 #define RS_NEVER 0x7fffffff  // absolute slot time that never arrives (reference quirk Q5)
 #define RS_MAX_PRBS 256
+
+// End slot of a running VBR burst in 16 bits: bit 15 = occupied, bits 0-14 = absolute end slot modulo 2^15.  A burst is
+// freed in the very slot it ends, so an occupied entry is always within RS_BURST_MAX_LEN slots of its end and the
+// signed 15-bit difference to the clock is its remaining life.
+#define rs_burst_code(end_abs) (0x8000u | ((unsigned)(end_abs) & 0x7fffu))
+#define rs_burst_rel(code, now) ((int)(((((unsigned)(code)) - (unsigned)(now)) & 0x7fffu) ^ 0x4000u) - 0x4000)
 
 // Immutable parameters, one copy in HBM, read through scalar loads.
 struct RsDev {
@@ -72,8 +79,9 @@ struct RsState {
     int32_t* u_vbr_at;      // absolute slot of the source's next burst arrival
     uint32_t* u_ctr;
     uint32_t* u_serial;
-    int32_t* u_flags;       // bit0 type (0 CBR, 1 VBR), bits1-2 fading trace, bit3 step sign (+1 if set)
-    int32_t* u_burst;       // [task][RS_BURSTS][RS_GROUP] absolute end slots, 0 = free
+    int32_t* u_flags;       // bit0 type (0 CBR, 1 VBR), bits1-2 fading trace, bit3 step sign (+1 if set), bits4-6 RAN slice
+                            // (multiplexed L1 only), bits8-15 VBR bursts that never end (Q5)
+    uint16_t* u_burst;      // [task][RS_BURSTS][RS_GROUP] end slots as rs_burst_code, 0 = free
     // per replica
     uint64_t* seeds;
     int32_t* err;           // [n_envs] sticky error flags (RS_EOVERFLOW ...)

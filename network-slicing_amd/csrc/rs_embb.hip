@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     // Cold per-UE state lives in LDS (one slot per thread, conflict-free), so that the hot loop keeps few
     // enough VGPRs for 5 resident waves per SIMD.  Timers are absolute slot numbers; `evt_at` (a VGPR)
     // is the earliest of them, so these arrays are touched only in slots where something happens.
-    __shared__ int L_burst[RS_BURSTS][256];  // VBR burst end times, 0 = free
+    __shared__ unsigned short L_burst[RS_BURSTS][256];  // VBR burst end times (rs_burst_code), 0 = free
     __shared__ int L_hold[256];              // departure time
     __shared__ int L_uvbr[256];              // next burst arrival of the UE's VBR source
     __shared__ unsigned L_serial[256], L_ctr[256];
@@ -644,13 +644,15 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
         evt_at = hold_at < uvbr_at ? hold_at : uvbr_at;
 #pragma unroll
         for (int k = 0; k < RS_BURSTS; ++k) {
-            const int e = active ? S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] : 0;
-            L_burst[k][tid] = e;
-            if (e > clock0) {
+            const unsigned e = active ? S.u_burst[(task * RS_BURSTS + k) * RS_GROUP + gl] : 0u;
+            L_burst[k][tid] = (unsigned short)e;
+            if (e != 0u) {  // occupied entries are always still running (they are freed in the slot they end)
                 n_act += 1;
-                evt_at = e < evt_at ? e : evt_at;
+                const int endt = clock0 + rs_burst_rel(e, clock0);
+                evt_at = endt < evt_at ? endt : evt_at;
             }
         }
+        n_act += (flags >> 8) & 0xff;  // bursts that never end (Q5) are only counted
         L_hold[tid] = hold_at;
         L_uvbr[tid] = uvbr_at;
         L_serial[tid] = userial;
@@ -931,7 +933,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                 const int m_hold = L_hold[st_], m_uvbr = L_uvbr[st_];
                 const unsigned m_ser = L_serial[st_], m_ctr = L_ctr[st_];
                 const double m_nom = L_nom[st_];
-                int m_b[RS_BURSTS];
+                unsigned short m_b[RS_BURSTS];
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) m_b[k] = L_burst[k][st_];
                 int m_e[CH / 2];
@@ -954,32 +956,40 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
             }
             // ---- VbrSource.step events (traffic_generators.py:70-99) on absolute end times
             if (active && evt_at == now) {
-                int cnt = 0, nxt = RS_NEVER;
-                int b[RS_BURSTS];
+                int cnt = (flags >> 8) & 0xff, nxt = RS_NEVER;  // the never-ending bursts (Q5) always emit
+                unsigned freek = RS_BURSTS;                      // a free entry for a burst that may start now
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) {
-                    b[k] = L_burst[k][tid];
-                    if (b[k] > now) {
+                    const unsigned e = L_burst[k][tid];
+                    const int rel = e != 0u ? rs_burst_rel(e, now) : 0;
+                    if (e != 0u && rel <= 0) L_burst[k][tid] = 0;  // ends exactly now: dropped without emitting
+                    if (rel > 0) {
                         cnt += 1;
-                        nxt = b[k] < nxt ? b[k] : nxt;
+                        nxt = now + rel < nxt ? now + rel : nxt;
+                    } else if (freek == RS_BURSTS) {
+                        freek = (unsigned)k;
                     }
                 }
-                n_cur = cnt;  // bursts ending exactly now are dropped without emitting
+                n_cur = cnt;
                 int uvbr_at = L_uvbr[tid];
                 if (uvbr_at == now) {
                     rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
-                    int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
-                    int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
+                    const int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
+                    const int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
                     L_ctr[tid] = st.ctr;
-                    const int endt = d >= 1 ? now + d : RS_NEVER;  // Q5: immortal burst
-                    bool placed = false;
+                    if (d < 1) {  // Q5: a duration that rounds to 0 never counts down to 0: the burst emits for ever
+                        if (((flags >> 8) & 0xff) == 0xff) err |= 2;
+                        else flags += 1 << 8;
+                        cnt += 1;
+                    } else if (freek == RS_BURSTS || d >= RS_BURST_MAX_LEN) {
+                        err |= 2;  // RS_EOVERFLOW: more than RS_BURSTS bursts running, or one longer than the 15-bit clock can hold
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < RS_BURSTS; ++k) {
-                        if (!placed && b[k] <= now) { L_burst[k][tid] = endt; placed = true; }
+                        for (int k = 0; k < RS_BURSTS; ++k)
+                            if ((unsigned)k == freek) L_burst[k][tid] = (unsigned short)rs_burst_code(now + d);
+                        cnt += 1;
+                        nxt = now + d < nxt ? now + d : nxt;
                     }
-                    if (!placed) err |= 2;  // RS_EOVERFLOW: burst capacity
-                    cnt += placed ? 1 : 0;
-                    nxt = (placed && endt < nxt) ? endt : nxt;
                     uvbr_at = v >= 1 ? now + v : RS_NEVER;
                     L_uvbr[tid] = uvbr_at;
                 }
@@ -1288,7 +1298,6 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     const double i6 = bperm(infok, gbase + 6), i7 = bperm(infok, gbase + 7);
     // info[8], info[9] live in lanes 8, 9: a G = 8 group keeps them in lanes 0, 1 of a second register
     const double i8 = G >= 16 ? bperm(infok, gbase + 8) : bperm(infok_hi, gbase + 0);
-    const unsigned e_any = group_ballot<G>(err != 0, gbase);
     if (selected && gl == 0) A.redo[task] = aborted ? 1 : 0;
     if (valid) {
         if (gl < RS_N_EMBB_VARS && gl < G) {
@@ -1317,8 +1326,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
             c[0] += cnt_ue * (unsigned)n_prb;  // every UE reads n_prb fading samples per slot (n_prb is fixed for the step)
             c[2] += n_sched * (unsigned)((n_prb + gran - 1) / gran);  // RB pairs per scheduled slot
             c[3] += cnt_ue;
-            if (e_any != 0u) atomicOr(&SE.err[rep], 1);
         }
+        if (err != 0) atomicOr(&SE.err[rep], err);  // bit 0: UE capacity, bit 1: VBR burst capacity
         if (active) {
             SE.u_queue[ui] = queue;
             SE.u_th[ui] = th;

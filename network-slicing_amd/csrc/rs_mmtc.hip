@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void mtc_step_kernel(MtcArgs A) {
         const bool ok = i_delay / slots < D->sla_mtc_delay;
         A.violations[rep * D->n_slices + sl] = ok ? 0 : 1;
         A.labels[rep * D->n_slices + sl] = ok ? 1 : -1;
-        if (any_err) atomicOr(&A.err[rep], 1);
+        if (any_err) atomicOr(&A.err[rep], 4);  // bit 2: mMTC queue capacity
     }
 }
 

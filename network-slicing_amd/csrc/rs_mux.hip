@@ -60,7 +60,7 @@ __device__ __forceinline__ size_t mux_bi(int rep, int n_embb, int u, int k) {
 
 template <bool TRACE>
 __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
-    __shared__ int L_burst[RS_BURSTS][64];
+    __shared__ unsigned short L_burst[RS_BURSTS][64];  // VBR burst end times (rs_burst_code), 0 = free
     __shared__ int L_hold[64], L_uvbr[64];
     __shared__ unsigned L_serial[64], L_ctr[64];
     __shared__ int L_acc_traf[64], L_acc_bits[64], L_acc_prbs[64];
@@ -130,13 +130,15 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
         evt_at = hold_at < uvbr_at ? hold_at : uvbr_at;
 #pragma unroll
         for (int k = 0; k < RS_BURSTS; ++k) {
-            const int e = active ? S.u_burst[mux_bi(rep, M, lane, k)] : 0;
-            L_burst[k][lane] = e;
-            if (e > clock0) {
+            const unsigned e = active ? S.u_burst[mux_bi(rep, M, lane, k)] : 0u;
+            L_burst[k][lane] = (unsigned short)e;
+            if (e != 0u) {  // occupied entries are always still running (they are freed in the slot they end)
                 n_act += 1;
-                evt_at = e < evt_at ? e : evt_at;
+                const int endt = clock0 + rs_burst_rel(e, clock0);
+                evt_at = endt < evt_at ? endt : evt_at;
             }
         }
+        n_act += (flags >> 8) & 0xff;  // bursts that never end (Q5) are only counted
         L_hold[lane] = hold_at;
         L_uvbr[lane] = uvbr_at;
         L_serial[lane] = userial;
@@ -227,7 +229,7 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
                 const int m_hold = L_hold[src], m_uvbr = L_uvbr[src];
                 const unsigned m_ser = L_serial[src], m_ctr = L_ctr[src];
                 const double m_nom = L_nom[src];
-                int m_b[RS_BURSTS];
+                unsigned short m_b[RS_BURSTS];
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) m_b[k] = L_burst[k][src];
                 __builtin_amdgcn_wave_barrier();
@@ -301,7 +303,7 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
                     const int m_hold = L_hold[src], m_uvbr = L_uvbr[src];
                     const unsigned m_ser = L_serial[src], m_ctr = L_ctr[src];
                     const double m_nom = L_nom[src];
-                    int m_b[RS_BURSTS];
+                    unsigned short m_b[RS_BURSTS];
 #pragma unroll
                     for (int k = 0; k < RS_BURSTS; ++k) m_b[k] = L_burst[k][src];
                     __builtin_amdgcn_wave_barrier();
@@ -330,14 +332,18 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
         // ================= VbrSource.step events (traffic_generators.py:70-99) on absolute end times
         int n_cur = n_act;
         if (active && evt_at == now) {
-            int cnt = 0, nxt = RS_NEVER;
-            int b[RS_BURSTS];
+            int cnt = (flags >> 8) & 0xff, nxt = RS_NEVER;  // the never-ending bursts (Q5) always emit
+            unsigned freek = RS_BURSTS;                      // a free entry for a burst that may start now
 #pragma unroll
             for (int k = 0; k < RS_BURSTS; ++k) {
-                b[k] = L_burst[k][lane];
-                if (b[k] > now) {
+                const unsigned e = L_burst[k][lane];
+                const int rel = e != 0u ? rs_burst_rel(e, now) : 0;
+                if (e != 0u && rel <= 0) L_burst[k][lane] = 0;  // ends exactly now: dropped without emitting
+                if (rel > 0) {
                     cnt += 1;
-                    nxt = b[k] < nxt ? b[k] : nxt;
+                    nxt = now + rel < nxt ? now + rel : nxt;
+                } else if (freek == RS_BURSTS) {
+                    freek = (unsigned)k;
                 }
             }
             n_cur = cnt;
@@ -347,14 +353,19 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
                 const int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
                 const int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
                 L_ctr[lane] = st.ctr;
-                const int endt = d >= 1 ? now + d : RS_NEVER;  // Q5
-                bool placed = false;
+                if (d < 1) {  // Q5: a duration that rounds to 0 never counts down to 0: the burst emits for ever
+                    if (((flags >> 8) & 0xff) == 0xff) err |= 2;
+                    else flags += 1 << 8;
+                    cnt += 1;
+                } else if (freek == RS_BURSTS || d >= RS_BURST_MAX_LEN) {
+                    err |= 2;  // RS_EOVERFLOW: more than RS_BURSTS bursts running, or one longer than the 15-bit clock can hold
+                } else {
 #pragma unroll
-                for (int k = 0; k < RS_BURSTS; ++k)
-                    if (!placed && b[k] <= now) { L_burst[k][lane] = endt; placed = true; }
-                if (!placed) err |= 2;
-                cnt += placed ? 1 : 0;
-                nxt = (placed && endt < nxt) ? endt : nxt;
+                    for (int k = 0; k < RS_BURSTS; ++k)
+                        if ((unsigned)k == freek) L_burst[k][lane] = (unsigned short)rs_burst_code(now + d);
+                    cnt += 1;
+                    nxt = now + d < nxt ? now + d : nxt;
+                }
                 uvbr_at = v >= 1 ? now + v : RS_NEVER;
                 L_uvbr[lane] = uvbr_at;
             }
@@ -516,7 +527,6 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
 
     // ---- outputs: get_state of every RAN slice (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319,
     // slice_l1.py:160-171: the L1 slice reports how many of its RAN slices are in breach)
-    const bool any_err = wave_any(err != 0);
     for (int i = lane; i < M * 10; i += 64) {
         const int m = i / 10, k = i % 10;
         A.obs[(size_t)rep * D->n_vars + m * RS_N_EMBB_VARS + k] = (float)(L_info[m][k] / D->norm[k]);
@@ -539,7 +549,6 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
         c[0] += (uint64_t)stat_ue * (unsigned)n_prb;
         c[2] += (uint64_t)stat_sched * (unsigned)((n_prb + gran - 1) / gran);
         c[3] += stat_ue;
-        if (any_err) atomicOr(&S.err[rep], 1);
     }
     if (lane < M) {
         const int task = rep * M + lane;
@@ -548,6 +557,7 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
         S.t_ctr[task] = (uint32_t)L_slice[lane][2];
         S.t_serial[task] = (uint32_t)L_slice[lane][3];
     }
+    if (err != 0) atomicOr(&S.err[rep], err);
     if (active) {
         const size_t ui = mux_ui(rep, M, lane);
         S.u_queue[ui] = queue;
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(64) void mtc_mux_step_kernel(MtcArgs A) {
         const int a = D->n_embb > 0 ? 1 : 0;
         A.violations[rep * n_act_entries + a] = viol;
         A.labels[rep * n_act_entries + a] = viol == 0 ? 1 : -1;
-        if (any_err) atomicOr(&A.err[rep], 1);
+        if (any_err) atomicOr(&A.err[rep], 4);
     }
 }
 

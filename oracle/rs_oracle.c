@@ -849,7 +849,7 @@ static void mux_mmtc_slot(rs_oracle* o) {
 static void set_defaults(rs_oracle* o) {
     o->mux = o->cfg.l1_multiplex != 0;
     o->max_ue = o->cfg.max_ue > 0 ? o->cfg.max_ue : (o->mux ? 64 : 32);
-    o->max_bursts = o->cfg.max_bursts > 0 ? o->cfg.max_bursts : 8;
+    o->max_bursts = o->cfg.max_bursts > 0 ? o->cfg.max_bursts : 16;
     o->max_queue = o->cfg.max_mtc_queue > 0 ? o->cfg.max_mtc_queue : 1024;
 }
 
