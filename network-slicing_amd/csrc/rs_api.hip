@@ -84,7 +84,7 @@ struct rs_handle {
     uint64_t* d_counter_sum = nullptr;  // [4]
     rs_alloc_rec* d_trace = nullptr;
     uint64_t* d_sections = nullptr;
-    double* d_mi_wide = nullptr;
+    unsigned long long* d_pace = nullptr;  // [4] wave pace accumulators of the eMBB step kernel (dynamic priority)
     int32_t* d_redo = nullptr;   // [n_tasks] tasks the fast (G < 32) launch handed to the G = 32 replay
     int32_t* d_order = nullptr;  // [n_tasks] launch order of the step tasks (rs_order.hip)
     uint64_t* d_oslot = nullptr; // [n_tasks] counting-sort scratch
@@ -483,7 +483,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     if (const char* e = getenv("RANSLICE_GRANT_DIV")) h->grant_div = atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
     DA(h->d_st, 1);
     DA(h->d_run, 4);
-    DA(h->d_mi_wide, (T ? T : 1) * RS_MAX_PRBS);
+    DA(h->d_pace, 4);
     if ((rc = mtc_alloc(h, &h->mst, N * (size_t)cfg->n_mmtc, d)) != RS_OK) return rc;
 #undef DA
     HIPCHK(h, hipMemcpyAsync(h->d_st, &h->st, sizeof(RsState), hipMemcpyHostToDevice, h->stream));
@@ -708,7 +708,7 @@ static int launch_step(rs_handle* h) {
         a.trace = h->d_trace;
         a.sections = h->d_sections;
         a.redo = h->d_redo;
-        a.mi_wide = h->d_mi_wide;
+        a.pace = h->d_pace;
         a.replay = 0;
         a.order = nullptr;
         hipEvent_t e0 = nullptr, e1 = nullptr;

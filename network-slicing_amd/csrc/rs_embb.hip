@@ -63,6 +63,9 @@ namespace rs {
 #ifndef RS_OCC
 #define RS_OCC 5
 #endif
+#ifndef RS_DYN_PRIO
+#define RS_DYN_PRIO 1
+#endif
 #ifndef RS_LPU
 #define RS_LPU 4
 #endif
@@ -90,9 +93,12 @@ namespace rs {
         unsigned long long tot_ = 0;                                                                    \
         for (int i_ = 0; i_ < 13; ++i_) tot_ += sec_acc[i_];                                            \
         (buf)[16 + task * 4 + 0] = tot_;                                                                \
-        (buf)[16 + task * 4 + 1] = (unsigned long long)S.t_n_ue[task];                                  \
-        (buf)[16 + task * 4 + 2] = (unsigned long long)A.actions[rep * n_slices + sl];                  \
-        (buf)[16 + task * 4 + 3] = (unsigned long long)(stat >> 18);                                        \
+        /* upper halves: where the wave ran (HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID) */ \
+        (buf)[16 + task * 4 + 1] = (unsigned long long)S.t_n_ue[task] |                                 \
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);        \
+        (buf)[16 + task * 4 + 2] = (unsigned long long)A.actions[rep * n_slices + sl] |                 \
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg(63492) << 32);        \
+        (buf)[16 + task * 4 + 3] = (unsigned long long)(stat >> 18) | ((sec_t0 - tot_) << 24); /* start time */ \
     }
 #else
 #define SEC_DECL
@@ -435,7 +441,8 @@ struct StepArgs {
     uint64_t* sections;       // [16] cycle sums per code section (RS_SECTION_PROFILE builds)
     int32_t* redo;            // [n_tasks] set by a G < 32 launch for tasks it could not hold; consumed by the G = 32 replay
     int32_t replay;           // 1: process only tasks whose redo flag is set
-    double* mi_wide;          // [n_tasks][RS_MAX_PRBS] scratch rows for slices wider than the LDS slice
+    unsigned long long* pace; // [0] sum, [1] count of the wave paces (cycles per slot) of the launch in flight,
+                              // [2] mean pace of the previous launch: the reference of the dynamic issue priority
     const int32_t* order;     // [n_tasks] launch order of the tasks (rs_order.hip) or null = task index order
 };
 
@@ -732,7 +739,33 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     const int n_pairs_full = n_prb / gran;  // RB pairs of full size in this slice
     int t0 = 0, CL = 0;                     // current chunk of channel estimates: slots [t0, t0 + CL)
     SEC_DECL
+    // Dynamic issue priority.  All waves of the batch are co-resident (five per SIMD) and the launch ends with its
+    // slowest wave, whose cost last step's statistics predict poorly.  So every wave paces itself against the mean
+    // pace of the previous launch: behind schedule -> it issues ahead of its SIMD neighbours, ahead -> it yields.
+    // (Timing only; no result depends on it.)
+    unsigned long long pace_ref = 0ull;
+    const unsigned long long pace_t0 = __builtin_amdgcn_s_memtime();
+    if (RS_DYN_PRIO && A.pace) {
+        pace_ref = __builtin_nontemporal_load(&A.pace[2]);
+        if (blockIdx.x == 0 && tid == 0) {  // nobody adds to [0], [1] before the end of its 50 slots
+            const unsigned long long s_ = A.pace[0], c_ = A.pace[1];
+            if (c_ != 0ull) {
+                A.pace[2] = (unsigned long long)((double)s_ / (double)c_);
+                A.pace[0] = 0ull;
+                A.pace[1] = 0ull;
+            }
+        }
+        pace_ref = __builtin_amdgcn_readfirstlane((unsigned)pace_ref);  // < 2^32 cycles per slot
+    }
     for (int t = 0; t < slots; ++t) {
+        if (RS_DYN_PRIO && pace_ref != 0ull && t >= 2) {
+            const unsigned long long el = (__builtin_amdgcn_s_memtime() - pace_t0) * 32ull;
+            const unsigned long long due = (unsigned long long)t * pace_ref;
+            if (el > due * 36ull) __builtin_amdgcn_s_setprio(3);       // > 1.125 x the reference pace
+            else if (el > due * 33ull) __builtin_amdgcn_s_setprio(2);  // > 1.03
+            else if (el > due * 30ull) __builtin_amdgcn_s_setprio(1);  // > 0.94
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const int now = clock0 + t + 1;
         const int slot_counter = t + 1;
         const bool chunk_start = t == t0 + CL;  // wave-uniform
@@ -1143,13 +1176,26 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                                     rr += gran;
                                     if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
                                         thl = pf_a * thl + pf_share(bits);
-                                        m = rate_d / thl;
-                                        keep = m > m2 || (m == m2 && gl < idx2);
+                                        // fl(rate / thl) against the runner-up WITHOUT the IEEE divide (a dozen dependent
+                                        // instructions) on the run's critical path: t = fl(m2 * thl) is within 2^-53 of
+                                        // m2 * thl, so rate > t (1 + 2^-40) puts the exact quotient above the double
+                                        // after m2, rate < t (1 - 2^-40) below the one before it; rounding is monotone,
+                                        // so the rounded quotient compares the same way.  Anything closer (ties between
+                                        // equal UEs included) takes the divide.
+                                        const double tm2 = m2 * thl;
+                                        if (rate_d > tm2 * 0x1.0000000001p+0) {
+                                            keep = true;
+                                        } else if (rate_d < tm2 * 0x1.fffffffffep-1) {
+                                            keep = false;
+                                        } else {
+                                            const double mm = rate_d / thl;
+                                            keep = mm > m2 || (mm == m2 && gl < idx2);
+                                        }
                                     } else {
-                                        m = 0.0;
                                         keep = false;  // m2 > 0 here
                                     }
                                 } while (keep && rr < n_prb);
+                                m = q > 0 ? rate_d / thl : 0.0;
                                 take = rr - r;
                             }
                         }
@@ -1287,6 +1333,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     }
     flush();
     SEC_FLUSH(A.sections)
+    const bool wave_worked = wave_any(valid);
+    if (RS_DYN_PRIO && A.pace && (tid & 63) == 0 && wave_worked) {
+        atomicAdd(&A.pace[0], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
+        atomicAdd(&A.pace[1], 1ull);
+    }
 
     // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)
     // (the state pointers are fetched again here, through a pointer the compiler cannot see through, instead of

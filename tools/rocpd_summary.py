@@ -37,6 +37,17 @@ def main(path, last=0):
         print('\n# PMC counters: kernel, counter, mean per dispatch, sum, dispatches')
         for r in pm:
             print('   %-48s %-28s %16.1f %18.1f %6d' % (r[0][:48], r[1], r[2], r[3], r[4]))
+        if last:
+            # the population is still growing during the burn-in: what belongs beside the bench line is the
+            # mean over the LAST dispatches of each kernel (the timed region)
+            print('\n# PMC counters, mean over the last %d dispatches of each kernel' % last)
+            names = sorted({(r[0], r[1]) for r in pm})
+            for kn, cn in names:
+                v = [x[0] for x in c.execute(
+                    "select sum(value) from counters_collection where kernel_name = ? and counter_name = ? "
+                    "group by dispatch_id order by dispatch_id desc limit ?", (kn, cn, last))]
+                if v:
+                    print('   %-48s %-28s %16.1f   (last %d)' % (kn[:48], cn, sum(v) / len(v), len(v)))
 
 
 if __name__ == '__main__':

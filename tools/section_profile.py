@@ -71,7 +71,13 @@ print('total %.0f cycles/wave/slot; PF loop trips per wave per slot: %.2f' % (to
 import numpy as np
 raw = np.zeros(N * 5 * 4 + 16, dtype=np.uint64)
 env.L.rs_get_task_profile(env.h, raw.ctypes.data_as(C.POINTER(C.c_uint64)))
-tp = raw[:N * 5 * 4].reshape(N * 5, 4)
+tp = raw[:N * 5 * 4].reshape(N * 5, 4).copy()
+xcc = (tp[:, 1] >> np.uint64(32)).astype(np.int64) & 0xf
+hwid = (tp[:, 2] >> np.uint64(32)).astype(np.int64)
+start = (tp[:, 3] >> np.uint64(24)).astype(np.float64)
+tp[:, 3] &= np.uint64(0xffffff)
+tp[:, 1] &= np.uint64(0xffffffff)
+tp[:, 2] &= np.uint64(0xffffffff)
 sw = raw[N * 5 * 4:].astype(np.float64)
 print('section split of the slowest wave of the run (cycles/slot):')
 for i in (9, 7, 0, 1, 2, 8, 11, 12, 3, 10, 4, 5, 6):
@@ -93,3 +99,49 @@ for i in idx:
 # how well do simple predictors explain a task's wave time?
 for name, v in (('n_ue*n_prb', tp[:, 1] * tp[:, 2]), ('pf_trips', tp[:, 3]), ('n_ue', tp[:, 1]), ('n_prb', tp[:, 2])):
     print('corr(wave cycles, %s) = %.3f' % (name, np.corrcoef(cyc, v.astype(np.float64))[0, 1]))
+
+# where did the time go: is a wave slow because of its own tasks or because of the SIMD it shared?
+simd = (hwid >> 4) & 3
+cu = (hwid >> 8) & 0xf
+se = (hwid >> 12) & 0xf  # sh + se bits
+slot = ((xcc * 16 + se) * 16 + cu) * 4 + simd
+# one entry per wave: the tasks of a wave (not consecutive under the cost-ranked order) share start time and place
+_, wave_first = np.unique(np.stack([start, hwid.astype(np.float64), xcc.astype(np.float64)], axis=1), axis=0, return_index=True)
+wc, ws = cyc[wave_first], slot[wave_first]
+print('distinct SIMDs used: %d, waves %d' % (len(np.unique(ws)), len(wc)))
+means = {}
+for k in np.unique(ws):
+    means[k] = wc[ws == k]
+between = np.var([v.mean() for v in means.values()])
+within = np.mean([v.var() for v in means.values()])
+print('wave cycles/slot: overall var %.3g = between-SIMD %.3g + within-SIMD %.3g' % (wc.var(), between, within))
+sm = np.array([v.mean() for v in means.values()])
+smax = np.array([v.max() for v in means.values()])
+cnt = np.array([len(v) for v in means.values()])
+print('waves per SIMD: min %d max %d; per-SIMD mean cycles/slot pct 5/50/95/max: %s; per-SIMD max pct 5/50/95: %s' % (
+    cnt.min(), cnt.max(), np.percentile(sm, [5, 50, 95, 100]).round(0), np.percentile(smax, [5, 50, 95]).round(0)))
+cum = {}
+for k in np.unique(slot // 4):
+    cum[k] = wc[(ws // 4) == k]
+cm = np.array([v.mean() for v in cum.values()])
+print('per-CU mean cycles/slot pct 5/50/95/max: %s (CUs %d)' % (np.percentile(cm, [5, 50, 95, 100]).round(0), len(cm)))
+xm = [wc[(ws // 1024) == x].mean() for x in np.unique(ws // 1024)]
+print('per-XCC mean cycles/slot: %s' % np.round(xm, 0))
+
+st = start[wave_first].copy()
+wx = xcc[wave_first]
+for x in np.unique(wx):  # the clock s_memtime reads is per XCD
+    st[wx == x] -= st[wx == x].min()
+en = st + wc * 50
+print('wave start offsets (cycles) pct 50/90/99/max: %s; end pct 1/10/50/90/99/max: %s' % (
+    np.percentile(st, [50, 90, 99, 100]).round(0), np.percentile(en, [1, 10, 50, 90, 99, 100]).round(0)))
+late = st > 0.2 * en.max()
+print('waves starting after 20%% of the kernel: %d' % late.sum())
+for x in np.unique(wx):
+    e = en[wx == x]
+    print('  XCC %d: waves %d, late starters %d, end pct 50/max: %s' % (x, (wx == x).sum(), (late & (wx == x)).sum(), np.percentile(e, [50, 100]).round(0)))
+cnt_by_cu = {}
+for k in np.unique(ws // 4):
+    cnt_by_cu[k] = ((ws // 4) == k).sum()
+v = np.array(list(cnt_by_cu.values()))
+print('waves per CU: min %d median %d max %d' % (v.min(), np.median(v), v.max()))
