@@ -91,6 +91,7 @@ struct rs_handle {
     int* d_ohist = nullptr;      // [2][RS_ORDER_BINS] bin counters, alternating between steps
     int order_par = 0;           // which half of d_ohist the next step counts into
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
+    int order_pair = 256;        // modes 4..: share (/256) of the waves led by one heavy task (RANSLICE_PAIR)
     int grant_mode = 0;          // 1: the heaviest waves schedule one RB pair per trip (rs_set_schedule_hint)
     uint32_t grant_div = 8;      // share of the waves that take the one-trip-per-pair loop (RANSLICE_GRANT_DIV, tests)
     bool grant_auto = true;      // grant_mode follows the batch size / the driving agent until the caller sets it
@@ -471,6 +472,18 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_ohist, 2 * RS_ORDER_BINS);
     HIPCHK(h, hipMemset(h->d_ohist, 0, sizeof(int) * 2 * RS_ORDER_BINS));
     if (const char* e = getenv("RANSLICE_ORDER")) h->order_mode = atoi(e);
+    {
+        // One heavy task per wave pays while the whole batch is co-resident (the launch ends with its heaviest wave;
+        // 1.13 vs 1.27 ms at 4096 replicas).  A batch of several rounds of waves is bound by the instructions issued
+        // instead, and waves of like tasks issue a sixth fewer (3.9 vs 3.4 M env-steps/s at 8192 replicas, 4.3 vs 3.6
+        // at 16384; tools/pair_sweep.sh).
+        int cus = 256;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
+        (void)hipGetLastError();
+        const long long resident_waves = (long long)cus * 4 * RS_OCC;
+        h->order_pair = (long long)h->n_tasks / 4 > resident_waves + resident_waves / 4 ? 0 : 256;
+    }
+    if (const char* e = getenv("RANSLICE_PAIR")) h->order_pair = atoi(e);
     // Lanes per task: with few tasks the step is pure latency and the 32-lane instance (more lanes per sum and per
     // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
     // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
@@ -748,7 +761,7 @@ static int launch_step(rs_handle* h) {
                                h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
-                               h->d_order, h->order_mode > 3 ? 1 : 0, 64 / h->group);  // modes 4.. = keys 1.. with heavy+light pairing
+                               h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group);  // modes 4.. = keys 1.. with heavy+light pairing
             a.order = h->d_order;
         }
         // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)

@@ -66,6 +66,11 @@ namespace rs {
 #ifndef RS_DYN_PRIO
 #define RS_DYN_PRIO 1
 #endif
+#ifndef RS_PACE_3
+#define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, tools/occ_sweep.sh)
+#define RS_PACE_2 35ull  // > 1.09: 2
+#define RS_PACE_1 28ull  // > 0.875: 1
+#endif
 #ifndef RS_LPU
 #define RS_LPU 4
 #endif
@@ -761,9 +766,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
         if (RS_DYN_PRIO && pace_ref != 0ull && t >= 2) {
             const unsigned long long el = (__builtin_amdgcn_s_memtime() - pace_t0) * 32ull;
             const unsigned long long due = (unsigned long long)t * pace_ref;
-            if (el > due * 36ull) __builtin_amdgcn_s_setprio(3);       // > 1.125 x the reference pace
-            else if (el > due * 33ull) __builtin_amdgcn_s_setprio(2);  // > 1.03
-            else if (el > due * 30ull) __builtin_amdgcn_s_setprio(1);  // > 0.94
+            if (el > due * RS_PACE_3) __builtin_amdgcn_s_setprio(3);       // in 32nds of the reference pace
+            else if (el > due * RS_PACE_2) __builtin_amdgcn_s_setprio(2);
+            else if (el > due * RS_PACE_1) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
         const int now = clock0 + t + 1;
@@ -1337,6 +1342,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
     if (RS_DYN_PRIO && A.pace && (tid & 63) == 0 && wave_worked) {
         atomicAdd(&A.pace[0], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
         atomicAdd(&A.pace[1], 1ull);
+#ifdef RS_PACE_XCC  // developer build (tools/xcc_pace.py): wave paces per XCD through the section-profile buffer
+        const unsigned xcc_ = __builtin_amdgcn_s_getreg(63508) & 7u;
+        atomicAdd((unsigned long long*)&A.sections[2 * xcc_], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
+        atomicAdd((unsigned long long*)&A.sections[2 * xcc_ + 1], 1ull);
+#endif
     }
 
     // ---- outputs: get_state (slice_ran.py:321-325), compute_reward (slice_ran.py:307-319)

@@ -94,14 +94,19 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restr
     if (task >= n_tasks) return;
     const uint64_t v = slot[task];
     int p = start[(int)(v & (RS_ORDER_BINS - 1))] + (int)(v >> 11);  // rank, heaviest first
-    if (pair && tpw > 1 && n_tasks % tpw == 0) {
-        // one heavy task per wave (tpw tasks), filled up with tpw - 1 from the light end: the heavy task's
-        // trip counts then set the wave's pace alone instead of adding up with other heavy tasks' peaks
+    if (pair > 0 && tpw > 1 && n_tasks % tpw == 0) {
+        // The heaviest `pair`/256 of the waves get ONE task from the heavy end of the ranking, filled up with
+        // tpw - 1 from the light end: the heavy task's trip counts then set the wave's pace alone instead of adding
+        // up with other heavy tasks' peaks (those waves end the launch).  The waves after them take the middle of
+        // the ranking in order: tasks of similar cost run their loops in lockstep with the least idle trips.
         const int W = n_tasks / tpw;
-        if (p < W) p = tpw * p;
-        else {
+        const int Hw = (int)(((long long)W * pair) >> 8);
+        if (p < Hw) p = tpw * p;
+        else if (p >= n_tasks - (tpw - 1) * Hw) {
             const int q = n_tasks - 1 - p;
             p = tpw * (q / (tpw - 1)) + 1 + q % (tpw - 1);
+        } else {
+            p = tpw * Hw + (p - Hw);
         }
     }
     order[p] = task;

@@ -1,6 +1,7 @@
-for g in ${GROUPS_:-8 16 32}; do
-echo "== group $g"
-RANSLICE_GROUP=$g python bench.py --steps 300 --warmup 30 --burn-in 1500 --no-cpu-baseline --no-kbrl 2>&1 | tail -1 | python -c "
+# developer sweep: bench the listed builds of libranslice (LIBS="a.so b.so") at the stationary population
+for lib in ${LIBS:-libranslice.so}; do
+echo "== $lib"
+RANSLICE_LIB=network-slicing_amd/csrc/build/$lib timeout 300 python bench.py --steps 300 --warmup 30 --burn-in 1500 --no-cpu-baseline --no-kbrl 2>&1 | tail -1 | python -c "
 import json,sys
 l=json.loads(sys.stdin.readline()); r=l['roofline']
 print('env-steps/s %.0f  ms/step %.3f  kernel_ms %.3f  mean_ue %.2f' % (l['value'], l['ms_per_step'], r['kernel_ms'], r['mean_ues_per_slice']))"
