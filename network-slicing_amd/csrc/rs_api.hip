@@ -92,9 +92,8 @@ struct rs_handle {
     int order_par = 0;           // which half of d_ohist the next step counts into
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
     int order_pair = 256;        // modes 4..: share (/256) of the waves led by one heavy task (RANSLICE_PAIR)
-    int grant_mode = 0;          // 1: the heaviest waves schedule one RB pair per trip (rs_set_schedule_hint)
-    uint32_t grant_div = 8;      // share of the waves that take the one-trip-per-pair loop (RANSLICE_GRANT_DIV, tests)
-    bool grant_auto = true;      // grant_mode follows the batch size / the driving agent until the caller sets it
+    int grant_mode = 0;          // 1: wide contested slices are expected, the 16-lane step uses its BLOCK instance (rs_set_schedule_hint)
+    bool grant_auto = true;      // grant_mode follows the scenario / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
@@ -114,6 +113,8 @@ struct rs_handle {
     size_t ev_used = 0;
     std::string err;
 };
+
+static int auto_hint(const rs_handle* h);
 
 static void drop_graph(rs_handle* h);
 
@@ -492,8 +493,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         const int g = atoi(e);
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
-    h->grant_mode = h->n_tasks <= 6144 ? 1 : 0;  // latency-bound batches: the shorter PF chain wins
-    if (const char* e = getenv("RANSLICE_GRANT_DIV")) h->grant_div = atoi(e) > 0 ? (uint32_t)atoi(e) : 8u;
+    h->grant_mode = auto_hint(h);
     DA(h->d_st, 1);
     DA(h->d_run, 4);
     DA(h->d_pace, 4);
@@ -740,15 +740,18 @@ static int launch_step(rs_handle* h) {
             const int per_block = 256 / g;
             dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
+            // BLOCK instances hand out the RB pairs of wide contested slices in block rounds; the plain 16-lane one
+            // carries the trip loop alone (rs_set_schedule_hint)
             if (g == 8) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<8, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<8, false, true>), grid, block, 0, h->stream, a);
             } else if (g == 16) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<16, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, true>), grid, block, 0, h->stream, a);
+                else if (h->grant_mode) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
             } else {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<32, false>), grid, block, 0, h->stream, a);
+                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, true>), grid, block, 0, h->stream, a);
+                else hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
             }
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
@@ -783,6 +786,14 @@ static int launch_step(rs_handle* h) {
     return RS_OK;
 }
 
+// Default of the scheduling hint: an even split of the carrier (what the on-device random script deals out on average)
+// gives slices wide enough for block rounds?  rs_step looks at the allocations it is handed, kb_step_resident asks for
+// the BLOCK instance outright.
+static int auto_hint(const rs_handle* h) {
+    const int gran = h->cfg.pf_granularity > 0 ? h->cfg.pf_granularity : 1;
+    return h->cfg.n_prbs / (h->n_slices + 1) >= RS_BLOCK_PAIRS * gran ? 1 : 0;
+}
+
 static int check_errors(rs_handle* h) {
     std::vector<int32_t> e((size_t)h->cfg.n_envs);
     HIPCHK(h, hipMemcpyAsync(e.data(), h->st.err, sizeof(int32_t) * e.size(), hipMemcpyDeviceToHost, h->stream));
@@ -815,6 +826,8 @@ extern "C" int rs_step(rs_handle* h, const int32_t* actions, float* obs, double*
     if (!h || !actions) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.n_envs, S = (size_t)h->n_slices;
+    size_t wide = 0;  // eMBB slices wide enough for block rounds of the PF allocation
+    const int wide_prbs = RS_BLOCK_PAIRS * (h->cfg.pf_granularity > 0 ? h->cfg.pf_granularity : 1);
     for (size_t r = 0; r < N; ++r) {  // Q9: the reference silently mis-slices; the build rejects
         long tot = 0;
         for (size_t s = 0; s < S; ++s) {
@@ -823,10 +836,18 @@ extern "C" int rs_step(rs_handle* h, const int32_t* actions, float* obs, double*
                 return RS_EINVAL;
             }
             tot += actions[r * S + s];
+            wide += actions[r * S + s] >= wide_prbs;
         }
         if (tot > h->cfg.n_prbs) {
             h->err = "rs_step: sum(action) > n_prbs in replica " + std::to_string(r);
             return RS_EINVAL;
+        }
+    }
+    if (h->grant_auto) {  // these allocations are in plain sight: pick the instance for them (a hint, same results)
+        const int want = wide * 16 >= N ? 1 : 0;
+        if (want != h->grant_mode) {
+            h->grant_mode = want;
+            drop_graph(h);
         }
     }
     HIPCHK(h, hipMemcpyAsync(h->d_actions, actions, sizeof(int32_t) * N * S, hipMemcpyHostToDevice, h->stream));
@@ -978,7 +999,7 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
 extern "C" int rs_set_schedule_hint(rs_handle* h, int mode) {
     if (!h) return RS_EINVAL;
     h->grant_auto = mode < 0;
-    h->grant_mode = mode < 0 ? (h->n_tasks <= 6144 ? 1 : 0) : (mode ? 1 : 0);
+    h->grant_mode = mode < 0 ? auto_hint(h) : (mode ? 1 : 0);
     drop_graph(h);
     return RS_OK;
 }

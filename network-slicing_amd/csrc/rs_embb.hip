@@ -66,6 +66,12 @@ namespace rs {
 #ifndef RS_DYN_PRIO
 #define RS_DYN_PRIO 1
 #endif
+#ifndef RS_BLOCK_MIN
+#define RS_BLOCK_MIN 4     // PF: block rounds while a contender's share of the free RB pairs is at least this ...
+#endif
+#ifndef RS_BLOCK_PAIRS
+#define RS_BLOCK_PAIRS 24  // ... in slices of at least this many RB pairs (tools/block_sweep.sh)
+#endif
 #ifndef RS_PACE_3
 #define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, tools/occ_sweep.sh)
 #define RS_PACE_2 35ull  // > 1.09: 2
@@ -547,7 +553,9 @@ __device__ __noinline__ double wide_response(const RsDev* D, const double* fad, 
 
 // 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
 // instances are test tooling: they keep the register budget of 3 waves per SIMD.
-template <int G, bool TRACE>
+// BLOCK: the contested PF allocation may hand out RB pairs in block rounds (wide slices); without it the instance
+// carries only the trip loop (fewer live registers: the whole point at 5 waves per SIMD).
+template <int G, bool TRACE, bool BLOCK>
 __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_step_kernel(StepArgs A) {
     static_assert(G == 8 || G == 16 || G == 32, "lanes per task");
     constexpr int TPB = 256 / G;                     // tasks per block
@@ -1113,113 +1121,218 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
             }
             SEC_MARK(8)
             if (wave_any(sched && r < n_prb)) {
+                // Contested slot.  The reference hands out one RB pair per iteration to the first UE of maximal
+                // metric m_u = rate_u / th_u and updates only that UE's local average (schedulers.py:44-62).  A
+                // UE's sequence of head metrics h_u0, h_u1, ... (after 0, 1, ... pairs) therefore depends on
+                // nobody else, and the greedy loop is a merge of those sequences: the pair a UE takes with j
+                // pairs already in hand comes in the order of its key k_uj = min(h_u0..h_uj) (descending, equal
+                // keys by UE index).  Pick any target pair g* = (u*, j*) with key L: the pairs handed out up to
+                // and including g* are u*'s first j* + 1 and, for every other UE, those with k_uj > L, or = L
+                // and u < u* -- a prefix of its sequence, which it can count ALONE.  (At the moment u* shows the
+                // head that sets L it is the first maximum, so every other head is below (L, u*) and stays there
+                // while u* runs on to j*; and a UE that has ever shown a head below (L, u*) before that moment
+                // would not have been served past it.)  Two kinds of rounds use this:
+                //  - a TRIP: the target is the runner-up's current head, so only the leader has pairs above it
+                //    and runs the reference loop alone until it stops being the argmax;
+                //  - a BLOCK round (BLOCK instances, slices of >= RS_BLOCK_PAIRS pairs while B = full pairs left /
+                //    contenders >= RS_BLOCK_MIN): every contender steps B - 1 pairs ahead on a copy of its state,
+                //    e_u = its B-th key, L = max e_u at u* (first maximum); then every contender takes its pairs
+                //    above (L, u*) -- at most B each, so the round cannot overdraw the slice -- and u* exactly B.
+                //    All UEs of all tasks of the wave step at once: between B and contenders x B pairs for
+                //    2 B - 1 steps, where trips pay a round of reductions for every two or three pairs.
                 double m = active ? ((q > 0 ? rate_d : 0.0) / thl) : -1.0;
                 bool need_full = true;
                 double mx = 0.0;
                 int idx = 0;
-                // leader (first maximum) and runner-up of the group's metrics.  After a contested run only the
-                // leader's metric has changed and it ended below the runner-up, so the runner-up is the next leader
-                // and only the new runner-up needs a reduction; `need_full` (group-uniform) asks for both.
+                int rf = r == 0 ? n_pairs_full : 0;  // full pairs still free (the closed forms above hand out all or nothing)
+                bool blk = BLOCK && n_pairs_full >= RS_BLOCK_PAIRS;  // this task may still take block rounds (one way)
                 for (;;) {
                     const bool more = sched && r < n_prb;
                     if (!wave_any(more)) break;
                     if (more) stat += 1u << 18;
     #ifdef RS_SECTION_PROFILE
-                    sec_acc[15] += 1;  // PF loop trips (not cycles)
+                    sec_acc[15] += 1;  // PF rounds (not cycles)
     #endif
-                    if (wave_any(more && need_full)) {
-                        const double fm = group_max<G>(m);
-                        const unsigned eq = group_ballot<G>(m == fm, gbase);
-                        if (need_full) {
-                            mx = fm;
-                            idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                    bool bmode = false;
+                    if (BLOCK && wave_any(more && blk)) {
+                        const int per_it = gran * rate;
+                        const int uc = __popc(group_ballot<G>(more && m > 0.0, gbase));
+                        // an under-estimate of rf / uc serves as well as the quotient (float reciprocal, rounded down)
+                        const int B = (int)((float)rf * __builtin_amdgcn_rcpf((float)(uc > 1 ? uc : 1)) * 0.999f);
+                        blk = blk && uc >= 2 && B >= RS_BLOCK_MIN;
+                        bmode = more && blk;
+                        const bool cont = bmode && m > 0.0;
+                        // ---- pass 1: my key after B - 1 more pairs (largest th seen <=> smallest metric)
+                        double e = m;
+                        {
+                            int q1 = q, b1 = bits;
+                            double t1 = thl, tmax1 = thl;
+                            bool alive = cont, dead = false;
+                            for (int j = 1;; ++j) {
+                                alive = alive && j < B;
+                                if (!wave_any(alive)) break;
+                                if (alive) {
+                                    const int tx = per_it < q1 ? per_it : q1;
+                                    q1 -= tx;
+                                    b1 += tx;
+                                    if (q1 > 0) {
+                                        t1 = pf_a * t1 + pf_share(b1);
+                                        tmax1 = max_finite(tmax1, t1);
+                                    } else {
+                                        dead = true;  // drained: every later head is 0
+                                        alive = false;
+                                    }
+                                }
+                            }
+                            if (cont) e = dead ? 0.0 : rate_d / tmax1;
                         }
-                    }
-                    const double m_rest = gl == idx ? -2.0 : m;
-                    const double m2 = group_max<G>(m_rest);
-                    const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
-                    const int idx2 = __ffs((int)eq2) - 1;
-                    int take = 0;
-                    SEC_MARK(11)
-                    if (more) {
-                        if (mx == 0.0) {
-                            // every queue is empty: argmax of an all-zero metric is UE 0 for all the
-                            // remaining RB pairs (Q4); its local th is discarded afterwards
-                            if (gl == 0) rbs += n_prb - r;
-                        } else if (gl == idx) {
-                            // Only the leader's metric changes while it keeps winning, so the leader's lane
-                            // runs the reference loop alone until it stops being the argmax.
-                            if (m2 <= 0.0) {
-                                // nobody else has data: it wins every RB pair until drained -> closed form
-                                const int R = n_prb - r;
-                                const int per_it = gran * rate;
-                                // ceil divisions through one IEEE f64 divide each (exact: operands < 2^31 and the
-                                // quotient of two integers is never within rounding distance of the next integer);
-                                // the 32-bit integer divide costs ~40 VALU instructions on this ISA
-                                const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
-                                const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
-                                const bool all = k_full >= K;
-                                const int cap_bits = R * rate;
-                                const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
-                                take = all ? K * gran : k_full * gran;
-                                rbs += all ? R : take;
-                                q -= tx;
-                                bits += tx;
-                                m = 0.0;  // drained, or no RBs left
-                            } else {
-                                int rr = r;
-                                bool keep;
-                                do {
-    #ifdef RS_SECTION_PROFILE
-                                    sec_acc[13] += 1;  // leader-run iterations (all lanes are summed)
-    #endif
-                                    const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
-                                    rbs += prbs;
-                                    const int tx = prbs * rate < q ? prbs * rate : q;
+                        SEC_MARK(11)
+                        const double Lk = group_max<G>(e);
+                        const int ustar = __ffs((int)group_ballot<G>(e == Lk, gbase)) - 1;
+                        // ---- pass 2: take my pairs above (L, u*)
+                        int cnt = 0;
+                        {
+                            const bool target = cont && gl == ustar;  // takes exactly B (fewer if it drains: L = 0 then)
+                            const bool low = gl < ustar;
+                            // fl(rate / tmax) against L without the IEEE divide: fl(L (1 +- 2^-40) tmax) is within
+                            // 2^-51 of the product, so rate above the upper one puts the exact quotient above the
+                            // double after L, rate below the lower one under the double before it, and rounding is
+                            // monotone.  Anything closer (ties between equal UEs included) takes the divide.
+                            const double L_hi = Lk * 0x1.0000000001p+0, L_lo = Lk * 0x1.fffffffffep-1;
+                            double tmax = thl;
+                            bool open_ = cont && (target || m > Lk || (m == Lk && low));
+                            for (;;) {
+                                if (!wave_any(open_)) break;
+                                if (open_) {
+                                    const int tx = per_it < q ? per_it : q;
                                     q -= tx;
                                     bits += tx;
-                                    rr += gran;
-                                    if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
+                                    rbs += gran;
+                                    cnt += 1;
+                                    if (q > 0) {
                                         thl = pf_a * thl + pf_share(bits);
-                                        // fl(rate / thl) against the runner-up WITHOUT the IEEE divide (a dozen dependent
-                                        // instructions) on the run's critical path: t = fl(m2 * thl) is within 2^-53 of
-                                        // m2 * thl, so rate > t (1 + 2^-40) puts the exact quotient above the double
-                                        // after m2, rate < t (1 - 2^-40) below the one before it; rounding is monotone,
-                                        // so the rounded quotient compares the same way.  Anything closer (ties between
-                                        // equal UEs included) takes the divide.
-                                        const double tm2 = m2 * thl;
-                                        if (rate_d > tm2 * 0x1.0000000001p+0) {
-                                            keep = true;
-                                        } else if (rate_d < tm2 * 0x1.fffffffffep-1) {
-                                            keep = false;
-                                        } else {
-                                            const double mm = rate_d / thl;
-                                            keep = mm > m2 || (mm == m2 && gl < idx2);
+                                        tmax = max_finite(tmax, thl);
+                                        bool pass = target;
+                                        if (!target) {
+                                            pass = rate_d > L_hi * tmax;
+                                            if (!pass && !(rate_d < L_lo * tmax)) {
+                                                const double kk = rate_d / tmax;
+                                                pass = kk > Lk || (kk == Lk && low);
+                                            }
                                         }
+                                        open_ = pass && cnt < B;
                                     } else {
-                                        keep = false;  // m2 > 0 here
+                                        open_ = false;  // drained: the next head is 0
                                     }
-                                } while (keep && rr < n_prb);
-                                m = q > 0 ? rate_d / thl : 0.0;
-                                take = rr - r;
+                                }
                             }
                         }
-                    }
-                    SEC_MARK(12)
-                    const int tk = bperm(take, gbase + idx);
-                    if (more) {
-                        r = mx == 0.0 ? n_prb : r + tk;
-                        if (mx != 0.0 && m2 > 0.0) {
-                            // the run ended below the runner-up (or the RBs ran out): next leader is known
-                            need_full = false;
-                            mx = m2;
-                            idx = idx2;
-                        } else {
+                        SEC_MARK(12)
+                        const int T = group_sum<G>(cnt);
+                        if (cnt > 0) m = q > 0 ? rate_d / thl : 0.0;
+                        if (bmode) {
+                            r += T * gran;
+                            rf -= T;
                             need_full = true;
+                        }
+                    }
+                    const bool tm = more && !bmode;  // tasks on a trip this round
+                    if (!BLOCK || wave_any(tm)) {  // (without BLOCK, tm == more: some lane is on a trip)
+                        if (wave_any(tm && need_full)) {
+                            const double fm = group_max<G>(m);
+                            const unsigned eq = group_ballot<G>(m == fm, gbase);
+                            if (need_full) {
+                                mx = fm;
+                                idx = __ffs((int)eq) - 1;  // np.argmax: first maximum
+                            }
+                        }
+                        const double m_rest = gl == idx ? -2.0 : m;
+                        const double m2 = group_max<G>(m_rest);
+                        const unsigned eq2 = group_ballot<G>(m_rest == m2, gbase);
+                        const int idx2 = __ffs((int)eq2) - 1;
+                        int take = 0;
+                        SEC_MARK(11)
+                        if (tm) {
+                            if (mx == 0.0) {
+                                // every queue is empty: argmax of an all-zero metric is UE 0 for all the
+                                // remaining RB pairs (Q4); its local th is discarded afterwards
+                                if (gl == 0) rbs += n_prb - r;
+                            } else if (gl == idx) {
+                                // Only the leader's metric changes while it keeps winning, so the leader's lane
+                                // runs the reference loop alone until it stops being the argmax.
+                                if (m2 <= 0.0) {
+                                    // nobody else has data: it wins every RB pair until drained -> closed form
+                                    const int R = n_prb - r;
+                                    const int per_it = gran * rate;
+                                    // ceil divisions through one IEEE f64 divide each (exact: operands < 2^31 and the
+                                    // quotient of two integers is never within rounding distance of the next integer);
+                                    // the 32-bit integer divide costs ~40 VALU instructions on this ISA
+                                    const int k_full = (int)((double)(q + per_it - 1) / (double)per_it);  // RB pairs to drain
+                                    const int K = (int)((double)(R + gran - 1) / (double)gran);          // RB pairs left
+                                    const bool all = k_full >= K;
+                                    const int cap_bits = R * rate;
+                                    const int tx = all ? (q < cap_bits ? q : cap_bits) : q;
+                                    take = all ? K * gran : k_full * gran;
+                                    rbs += all ? R : take;
+                                    q -= tx;
+                                    bits += tx;
+                                    m = 0.0;  // drained, or no RBs left
+                                } else {
+                                    int rr = r;
+                                    bool keep;
+                                    do {
+    #ifdef RS_SECTION_PROFILE
+                                        sec_acc[13] += 1;  // leader-run iterations (all lanes are summed)
+    #endif
+                                        const int prbs = n_prb - rr < gran ? n_prb - rr : gran;
+                                        rbs += prbs;
+                                        const int tx = prbs * rate < q ? prbs * rate : q;
+                                        q -= tx;
+                                        bits += tx;
+                                        rr += gran;
+                                        if (q > 0) {  // a drained UE's metric is 0 whatever its (discarded) local th
+                                            thl = pf_a * thl + pf_share(bits);
+                                            // fl(rate / thl) against the runner-up WITHOUT the IEEE divide (a dozen dependent
+                                            // instructions) on the run's critical path: t = fl(m2 * thl) is within 2^-53 of
+                                            // m2 * thl, so rate > t (1 + 2^-40) puts the exact quotient above the double
+                                            // after m2, rate < t (1 - 2^-40) below the one before it; rounding is monotone,
+                                            // so the rounded quotient compares the same way.  Anything closer (ties between
+                                            // equal UEs included) takes the divide.
+                                            const double tm2 = m2 * thl;
+                                            if (rate_d > tm2 * 0x1.0000000001p+0) {
+                                                keep = true;
+                                            } else if (rate_d < tm2 * 0x1.fffffffffep-1) {
+                                                keep = false;
+                                            } else {
+                                                const double mm = rate_d / thl;
+                                                keep = mm > m2 || (mm == m2 && gl < idx2);
+                                            }
+                                        } else {
+                                            keep = false;  // m2 > 0 here
+                                        }
+                                    } while (keep && rr < n_prb);
+                                    m = q > 0 ? rate_d / thl : 0.0;
+                                    take = rr - r;
+                                }
+                            }
+                        }
+                        SEC_MARK(12)
+                        const int tk = bperm(take, gbase + idx);
+                        if (tm) {
+                            r = mx == 0.0 ? n_prb : r + tk;
+                            if (mx != 0.0 && m2 > 0.0) {
+                                // the run ended below the runner-up (or the RBs ran out): next leader is known
+                                need_full = false;
+                                mx = m2;
+                                idx = idx2;
+                            } else {
+                                need_full = true;
+                            }
                         }
                     }
                 }
             }
+
             SEC_MARK(3)
             // RBs are laid out contiguously in UE order (schedulers.py:66-76)
             const int prb_i = group_excl_scan<G>(rbs, gl);

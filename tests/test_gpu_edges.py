@@ -190,28 +190,22 @@ def test_graph_captured_loop_equals_step_by_step(golden_dir, scenario):
 
 @pytest.mark.parametrize('group', [16, 32])
 def test_schedule_hint_does_not_change_results(golden_dir, group):
-    """agent-like allocations (most of the carrier on one or two slices, so that slices wider than the LDS row
-    and long contested PF loops occur): the plain instance, the GRANT instance (one-trip-per-pair PF loop on its
-    heaviest waves, whole-wave R1 for wide slices) and the GRANT instance with every wave on that loop leave
-    identical observations, rewards, labels and info sums behind"""
-    import os
+    """agent-like allocations (most of the carrier on one or two slices, so that spans wider than the per-wave LDS
+    buffer and long contested PF allocations occur): the plain instance (trip loop), the BLOCK instance (block rounds
+    on wide slices) and the automatic choice (rs_step looks at the allocations it is handed) leave identical
+    observations, rewards, labels and info sums behind"""
     from ranslice.vec_env import VecRanSlice
     fading = _fading(golden_dir)
     N = 640
 
-    def make(hint, div=None):
-        if div is not None:
-            os.environ['RANSLICE_GRANT_DIV'] = str(div)
-        try:
-            e = VecRanSlice(n_envs=N, cfg=_churn(make_config(0, n_envs=N)), fading=fading, seed=21)
-        finally:
-            os.environ.pop('RANSLICE_GRANT_DIV', None)
+    def make(hint):
+        e = VecRanSlice(n_envs=N, cfg=_churn(make_config(0, n_envs=N)), fading=fading, seed=21)
         e.set_group_size(group)
         e.set_schedule_hint(hint)
         e.reset()
         return e
 
-    envs = [make(0), make(1), make(1, div=1)]
+    envs = [make(0), make(1), make(-1)]
     rng = np.random.default_rng(5)
     for i in range(25):
         a = rng.integers(0, 6, size=(N, 5))

@@ -44,7 +44,21 @@ def _actions(rng, n_envs, n_slices, n_prbs, step):
     return a.astype(np.int32)
 
 
-def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None, group=None, hint=None):
+def _wide_actions(rng, n_envs, n_slices, n_prbs, step):
+    """agent-like allocations: most of the carrier on one slice (long contested PF allocations over 60-85 RB pairs),
+    a few RBs on the others, sometimes a second wide slice"""
+    a = rng.integers(0, 6, size=(n_envs, n_slices))
+    big = rng.integers(0, n_slices, size=n_envs)
+    a[np.arange(n_envs), big] = rng.integers(n_prbs // 2, n_prbs - 5 * n_slices - 10, size=n_envs)
+    if step % 3 == 2:  # two wide slices
+        a[np.arange(n_envs), big] //= 2
+        a[np.arange(n_envs), (big + 1) % n_slices] = a[np.arange(n_envs), big] - (step % 2)
+    assert (a.sum(axis=1) <= n_prbs).all()
+    return a.astype(np.int32)
+
+
+def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None, group=None, hint=None,
+             actions=None):
     from ranslice.vec_env import VecRanSlice
     cfg = make_config(scenario, n_envs=n_envs)
     if churn:
@@ -71,7 +85,7 @@ def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sa
     rng = np.random.default_rng(99 + scenario)
     n_slices = cfg.n_embb + cfg.n_mmtc
     for i in range(steps):
-        acts = _actions(rng, n_envs, n_slices, cfg.n_prbs, i)
+        acts = (actions or _actions)(rng, n_envs, n_slices, cfg.n_prbs, i)
         obs, rew, done, info = env.step(acts)
         l1 = env.l1_info()
         tr = env.alloc_trace() if check_trace else None
@@ -99,15 +113,18 @@ def test_scenario0_small_trace(golden_dir):
     _compare(0, n_envs=24, steps=8, fading=_small_fading(golden_dir), churn=False, seed0=1)
 
 
-@pytest.mark.parametrize('share', [1, 8])
-def test_grant_loop_allocations(golden_dir, share, monkeypatch):
-    """per-slot allocations of the one-trip-per-RB-pair PF loop (GRANT instances; small batches select them by
-    default) against the oracle, for 16 and 32 lanes per task; share 1 puts every wave on that loop, 8 is the
-    production split between the two loops"""
-    monkeypatch.setenv('RANSLICE_GRANT_DIV', str(share))
-    for group in (16, 32):
-        _compare(0, n_envs=64, steps=20, fading=_small_fading(golden_dir), churn=True, seed0=4000 + share,
-                 group=group, hint=1)
+@pytest.mark.parametrize('group', [8, 16, 32])
+def test_block_round_allocations(golden_dir, group):
+    """Wide contested slices (agent-like allocations, high-churn traffic): the PF allocation of the BLOCK instances
+    (block rounds: every contender steps ahead, the largest B-th key is the target, everybody takes the pairs above
+    it) against the reference loop of the oracle -- per slot and per UE (RBs, bits, queue, throughput average,
+    reception probability) on every replica, then the step outputs of the production (non-tracing) BLOCK instance
+    and of the plain trip-loop instance."""
+    _compare(0, n_envs=40, steps=14, fading=_small_fading(golden_dir), churn=True, seed0=4100 + group, group=group,
+             hint=1, actions=_wide_actions)
+    for hint in (1, 0):
+        _compare(0, n_envs=40, steps=14, fading=_small_fading(golden_dir), churn=True, seed0=4200 + group, group=group,
+                 hint=hint, actions=_wide_actions, check_trace=False)
 
 
 @pytest.mark.parametrize('group', [8, 16, 32])

@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG = os.path.join(ROOT, 'network-slicing_amd', 'csrc', 'build', 'resources.log')
 LIMIT = 240
-PRODUCTION = ('embb_step_kernelILi16ELb0E',)
+PRODUCTION = ["embb_step_kernelILi16ELb0ELb0E", "embb_step_kernelILi16ELb0ELb1E"]
 
 
 def parse(path=LOG):
