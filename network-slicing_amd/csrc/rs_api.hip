@@ -494,6 +494,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
     h->grant_mode = auto_hint(h);
+    if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
+        h->grant_auto = atoi(e) < 0;
+        if (!h->grant_auto) h->grant_mode = atoi(e) ? 1 : 0;
+    }
     DA(h->d_st, 1);
     DA(h->d_run, 4);
     DA(h->d_pace, 4);

@@ -1162,29 +1162,32 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                         blk = blk && uc >= 2 && B >= RS_BLOCK_MIN;
                         bmode = more && blk;
                         const bool cont = bmode && m > 0.0;
+                        // Both passes step FOUR pairs per iteration: th_j = pf_a th_(j-1) + share(bits_j), and the
+                        // bits after j more pairs are known in advance (bits + j per_it until the queue runs dry), so
+                        // the four shares are independent chains and only the four mul-adds depend on each other.
+                        // Same operations on the same operands as the one-pair-at-a-time loop, same doubles.
+                        const int kl = cont ? (int)((double)(q + per_it - 1) / (double)per_it) : 0;  // pairs that empty my queue (exact, see above)
                         // ---- pass 1: my key after B - 1 more pairs (largest th seen <=> smallest metric)
                         double e = m;
                         {
-                            int q1 = q, b1 = bits;
+                            const bool run1 = cont && kl > B - 1;  // still holding data after B - 1 more pairs (else: key 0)
                             double t1 = thl, tmax1 = thl;
-                            bool alive = cont, dead = false;
-                            for (int j = 1;; ++j) {
-                                alive = alive && j < B;
-                                if (!wave_any(alive)) break;
-                                if (alive) {
-                                    const int tx = per_it < q1 ? per_it : q1;
-                                    q1 -= tx;
-                                    b1 += tx;
-                                    if (q1 > 0) {
-                                        t1 = pf_a * t1 + pf_share(b1);
-                                        tmax1 = max_finite(tmax1, t1);
-                                    } else {
-                                        dead = true;  // drained: every later head is 0
-                                        alive = false;
-                                    }
-                                }
+                            int b1 = bits;
+                            for (int j = 1; wave_any(run1 && j < B); j += 4) {
+                                const double s1 = pf_share(b1 + per_it), s2 = pf_share(b1 + 2 * per_it);
+                                const double s3 = pf_share(b1 + 3 * per_it), s4 = pf_share(b1 + 4 * per_it);
+                                const double a1 = pf_a * t1 + s1;
+                                const double a2 = pf_a * a1 + s2;
+                                const double a3 = pf_a * a2 + s3;
+                                const double a4 = pf_a * a3 + s4;
+                                const double x1 = max_finite(tmax1, a1), x2 = max_finite(x1, a2);
+                                const double x3 = max_finite(x2, a3), x4 = max_finite(x3, a4);
+                                const int left = run1 ? B - j : 0;  // steps still to do, this one included
+                                t1 = left >= 4 ? a4 : (left == 3 ? a3 : (left == 2 ? a2 : (left == 1 ? a1 : t1)));
+                                tmax1 = left >= 4 ? x4 : (left == 3 ? x3 : (left == 2 ? x2 : (left == 1 ? x1 : tmax1)));
+                                b1 += 4 * per_it;
                             }
-                            if (cont) e = dead ? 0.0 : rate_d / tmax1;
+                            if (cont) e = run1 ? rate_d / tmax1 : 0.0;
                         }
                         SEC_MARK(11)
                         const double Lk = group_max<G>(e);
@@ -1199,32 +1202,47 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_st
                             // double after L, rate below the lower one under the double before it, and rounding is
                             // monotone.  Anything closer (ties between equal UEs included) takes the divide.
                             const double L_hi = Lk * 0x1.0000000001p+0, L_lo = Lk * 0x1.fffffffffep-1;
+                            auto above = [&](double tm) -> bool {
+                                bool pass = rate_d > L_hi * tm;
+                                if (!pass && !(rate_d < L_lo * tm)) {
+                                    const double kk = rate_d / tm;
+                                    pass = kk > Lk || (kk == Lk && low);
+                                }
+                                return pass;
+                            };
                             double tmax = thl;
+                            int kl2 = kl;  // pairs until my queue is empty
                             bool open_ = cont && (target || m > Lk || (m == Lk && low));
                             for (;;) {
                                 if (!wave_any(open_)) break;
+                                const int lim = B - cnt;  // pairs I may still take in this round
+                                const int c1 = per_it < q ? per_it : q, c2 = 2 * per_it < q ? 2 * per_it : q;
+                                const int c3 = 3 * per_it < q ? 3 * per_it : q, c4 = 4 * per_it < q ? 4 * per_it : q;
+                                const double s1 = pf_share(bits + c1), s2 = pf_share(bits + c2);
+                                const double s3 = pf_share(bits + c3), s4 = pf_share(bits + c4);
+                                const double a1 = pf_a * thl + s1;
+                                const double a2 = pf_a * a1 + s2;
+                                const double a3 = pf_a * a2 + s3;
+                                const double a4 = pf_a * a3 + s4;
+                                const double x1 = max_finite(tmax, a1), x2 = max_finite(x1, a2);
+                                const double x3 = max_finite(x2, a3), x4 = max_finite(x3, a4);
+                                // p_i: with i pairs of this iteration in hand, the next one is mine too
+                                const bool p1 = open_ && kl2 > 1 && 1 < lim && (target || above(x1));
+                                const bool p2 = p1 && kl2 > 2 && 2 < lim && (target || above(x2));
+                                const bool p3 = p2 && kl2 > 3 && 3 < lim && (target || above(x3));
+                                const bool p4 = p3 && kl2 > 4 && 4 < lim && (target || above(x4));
                                 if (open_) {
-                                    const int tx = per_it < q ? per_it : q;
-                                    q -= tx;
-                                    bits += tx;
-                                    rbs += gran;
-                                    cnt += 1;
-                                    if (q > 0) {
-                                        thl = pf_a * thl + pf_share(bits);
-                                        tmax = max_finite(tmax, thl);
-                                        bool pass = target;
-                                        if (!target) {
-                                            pass = rate_d > L_hi * tmax;
-                                            if (!pass && !(rate_d < L_lo * tmax)) {
-                                                const double kk = rate_d / tmax;
-                                                pass = kk > Lk || (kk == Lk && low);
-                                            }
-                                        }
-                                        open_ = pass && cnt < B;
-                                    } else {
-                                        open_ = false;  // drained: the next head is 0
-                                    }
+                                    const int n = 1 + (p1 ? 1 : 0) + (p2 ? 1 : 0) + (p3 ? 1 : 0);
+                                    const int cn = p3 ? c4 : (p2 ? c3 : (p1 ? c2 : c1));
+                                    q -= cn;
+                                    bits += cn;
+                                    rbs += n * gran;
+                                    cnt += n;
+                                    kl2 -= n;
+                                    thl = p3 ? a4 : (p2 ? a3 : (p1 ? a2 : a1));  // (after the pair that empties the queue: unused)
+                                    tmax = p3 ? x4 : (p2 ? x3 : (p1 ? x2 : x1));
                                 }
+                                open_ = p4;
                             }
                         }
                         SEC_MARK(12)

@@ -16,9 +16,7 @@ KBRL = '--kbrl' in sys.argv  # drive the env with one KBRL agent per replica ins
 env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
 env.reset()
 if KBRL:
-    # profile the plain instance: the instrumented build of the GRANT instance (304 B of spills per lane) faults
-    # on slices wider than the LDS row, which the un-instrumented one does not (tests: schedule_hint, soak)
-    env.set_schedule_hint(0)
+    env.set_schedule_hint(1)  # what kb_step_resident selects: the BLOCK instance
     import numpy as np
     from ranslice.kbrl_dev import VecKBRL
     agent = VecKBRL(N, [10] * 5, 200, capacity=512)
