@@ -150,7 +150,7 @@ def kbrl_record(n_envs, device, steps, warmup):
     cfg = make_config(SCENARIO, n_envs=n_envs)
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=[synth_fading(t, FADING_COLS) for t in range(3)], device=device)
     agent, capacity = None, None
-    for cap in (1024, 512, 256):
+    for cap in ([int(os.environ['KBRL_CAPACITY'])] if os.environ.get('KBRL_CAPACITY') else [1024, 512, 256]):  # (developer knob)
         try:
             agent = VecKBRL(n_envs, [10] * cfg.n_embb, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=cap,
                             device=device)

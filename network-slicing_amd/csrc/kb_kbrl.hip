@@ -57,6 +57,7 @@ struct KbState {
     double* acc;       // [n_envs][S][n_prbs]
     int32_t* err;      // [n_envs]
     uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
+    double* work;      // [blocks][2][cap rounded up to 16] per-block columns of an update in progress (kf, d*)
 };
 
 __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int s) {
@@ -67,18 +68,17 @@ __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int
     return v;
 }
 
-// Shared-memory working set of one learner
-// Per-block LDS working set, carved out of dynamic shared memory so a block only occupies what its
-// dictionary capacity needs (7 columns of cap rounded up to a 16-landmark tile): at capacity 256 that is
-// 17 KB instead of 60 KB, i.e. 8 resident blocks per CU instead of 2.
+// Working set of one learner.  Three columns live in LDS (carved out of dynamic shared memory by capacity: 27 KB at
+// capacity 1024, so five blocks stay resident per CU; the MFMA operands D0 + lam^2 and -2 lam are formed from them on
+// the fly).  The two columns of an update in progress (kernel column, d* = Kinv k_f) are touched by the one learner
+// in ten that updates in a step: they sit in a per-block row of global memory (KbState.work) behind the same
+// pointers.
 struct Lds {
-    double* bq;   // D0_j + lam_j^2
-    double* bl;   // -2 lam_j
     double* lam;  // lam_j (last coordinate of the landmark)
     double* d0;   // D0_j
     double* co;   // coeff_j
-    double* kf;   // kernel column of the candidate being updated
-    double* ds;   // d* = Kinv k_f
+    double* kf;   // kernel column of the candidate being updated   (global, per block)
+    double* ds;   // d* = Kinv k_f                                   (global, per block)
     double* f;    // [KB_CAND_MAX]
     double* x;    // [KB_DMAX]
     double* red;  // [16]
@@ -88,25 +88,23 @@ struct Lds {
 
 __host__ __device__ inline int kb_capr(int cap) { return (cap + 15) & ~15; }
 __host__ __device__ inline size_t kb_lds_bytes(int cap) {
-    return ((size_t)7 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 16) * sizeof(double) + 8 * sizeof(int);
+    return ((size_t)3 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 16) * sizeof(double) + 8 * sizeof(int);
 }
 
-__device__ __forceinline__ Lds carve_lds(int cap) {
+__device__ __forceinline__ Lds carve_lds(int cap, double* work) {
     extern __shared__ double kb_dyn_lds[];
     Lds sm;
     const int c = kb_capr(cap);
     double* p = kb_dyn_lds;
-    sm.bq = p; p += c;
-    sm.bl = p; p += c;
     sm.lam = p; p += c;
     sm.d0 = p; p += c;
     sm.co = p; p += c;
-    sm.kf = p; p += c;
-    sm.ds = p; p += c;
     sm.f = p; p += KB_CAND_MAX;
     sm.x = p; p += KB_DMAX;
     sm.red = p; p += 16;
     sm.ired = (int*)p;
+    sm.kf = work + (size_t)blockIdx.x * 2 * c;
+    sm.ds = sm.kf + c;
     sm.capr = c;
     return sm;
 }
@@ -141,8 +139,6 @@ __device__ void prepare_operands(const KbDev& D, const KbState& K, int dict, int
         }
         sm.d0[j] = d0;
         sm.lam[j] = lam;
-        sm.bq[j] = d0 + lam * lam;
-        sm.bl[j] = -2.0 * lam;
         sm.co[j] = co;
     }
     __syncthreads();
@@ -181,7 +177,8 @@ __device__ void score_range(const KbDev& D, int m, int c_lo, int c_hi, Lds& sm) 
         for (int jt = 0; jt < mt; ++jt) {
             const int j = jt * 16 + li;
             // A[landmark][k]: (D0 + lam^2, -2 lam, 1, 0)
-            const double aval = kq == 0 ? sm.bq[j] : (kq == 1 ? sm.bl[j] : (kq == 2 ? 1.0 : 0.0));
+            const double lam_j = sm.lam[j];
+            const double aval = kq == 0 ? sm.d0[j] + lam_j * lam_j : (kq == 1 ? -2.0 * lam_j : (kq == 2 ? 1.0 : 0.0));
             kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
             // lane holds dist[landmark = kq + 4 r][cand = li]
@@ -269,7 +266,7 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < sm.capr) {
         // the landmark after this one opens a new 16-landmark tile: make it read as empty
         const int j = m + 1 + threadIdx.x;
-        sm.d0[j] = 0.0; sm.lam[j] = 0.0; sm.bq[j] = 0.0; sm.bl[j] = 0.0; sm.co[j] = 0.0;
+        sm.d0[j] = 0.0; sm.lam[j] = 0.0; sm.co[j] = 0.0;
     }
     if (threadIdx.x == 0) {
         for (int q = 0; q < d - 1; ++q) L[(size_t)q * cap + m] = sm.x[q];
@@ -278,8 +275,6 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         sm.co[m] = (double)y;
         sm.d0[m] = 0.0;  // the new landmark shares the current state
         sm.lam[m] = t;
-        sm.bq[m] = t * t;
-        sm.bl[m] = -2.0 * t;
         sm.ds[m] = -1.0;
     }
     __syncthreads();
@@ -309,8 +304,8 @@ struct CtlArgs {
 // KBRL_Control.update_control for one learner (kbrl_control.py:83-112)
 __global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
     const KbDev& D = A.D;
-    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
+    Lds sm = carve_lds(D.cap, K.work);
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
@@ -448,8 +443,8 @@ struct SelArgs {
 // batches of one 16-candidate strip per wave, in order, until a batch contains the answer.
 __global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
     const KbDev& D = A.D;
-    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
+    Lds sm = carve_lds(D.cap, K.work);
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
@@ -597,8 +592,8 @@ struct ScanArgs {
 
 __global__ __launch_bounds__(256) void shared_scan_kernel(ScanArgs A) {
     const KbDev& D = A.D;
-    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
+    Lds sm = carve_lds(D.cap, K.work);
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
@@ -797,7 +792,7 @@ __global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_
 // apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
 __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                          int budget, uint64_t* gstats) {
-    Lds sm = carve_lds(D.cap);
+    Lds sm = carve_lds(D.cap, K.work);
     const int s = blockIdx.x;
     const int d = D.dims[s] + 1;
     int m = K.m[s];
@@ -848,8 +843,8 @@ struct OneArgs {
 
 __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
-    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
+    Lds sm = carve_lds(D.cap, K.work);
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
     const int d = D.dims[s] + 1, cap = D.cap;
@@ -889,8 +884,8 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
 
 __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
-    Lds sm = carve_lds(D.cap);
     const KbState& K = A.K;
+    Lds sm = carve_lds(D.cap, K.work);
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
     const int d = D.dims[s] + 1, cap = D.cap;

@@ -21,3 +21,21 @@ for C in FETCH_SIZE WRITE_SIZE; do
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB --last 20 | grep -E "embb_step_kernel<16.*$C" >> $OUT/${TAG}_pmc_hbm.txt
 done
 cat $OUT/${TAG}_pmc_hbm.txt
+# SQ issue / wait counters of the same short run (one group per pass)
+echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch of the step kernel (last 20 launches)" > $OUT/${TAG}_pmc_sq.txt
+i=0
+for GRP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_MISC"; do
+  i=$((i+1))
+  ( cd /tmp && timeout 300 rocprofv3 --pmc $GRP -d /tmp/sq_${TAG}_$i -o p -- bash -c "cd $GRAFT_REPO_ROOT && $PCMD" > /tmp/sq_$i.log 2>&1; echo "group $i rc=$?" )
+  DB=$(find /tmp/sq_${TAG}_$i -name '*.db' | head -1)
+  [ -n "$DB" ] && python tools/rocpd_summary.py $DB --last 20 | grep -E "embb_step_kernel<16" | grep "last 20" >> $OUT/${TAG}_pmc_sq.txt
+done
+cat $OUT/${TAG}_pmc_sq.txt
+# config 3 (agents in the loop): kernel trace of the bench's kbrl leg
+KCMD="python bench.py --steps 50 --warmup 5 --burn-in 300 --no-cpu-baseline --kbrl-steps 200"
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kprof_$TAG -o t -- bash -c "cd $GRAFT_REPO_ROOT && $KCMD > /tmp/kprof_$TAG.json" > /tmp/kprof_$TAG.log 2>&1 )
+DB=$(find /tmp/kprof_$TAG -name '*.db' | head -1)
+{ echo "# rocprofv3 --kernel-trace --stats of: $KCMD  (random-script leg first, then the kbrl leg: BLOCK instance <16,false,true> + kb_* kernels)"
+  python -c "import json; l = json.loads(open('/tmp/kprof_$TAG.json').read().strip().splitlines()[-1]); k = l['kbrl']; print('# kbrl record of the same run: %.0f env-steps/s, ms_per_step %.3f, embb_kernel_ms %.3f, kb kernels %.3f ms each' % (k['value'], k['ms_per_step'], k['embb_kernel_ms'], k['kb_kernel_ms_mean_of_update_and_select']))"
+  python tools/rocpd_summary.py $DB; } > $OUT/${TAG}_kbrl_kernel_trace_stats.txt
+head -24 $OUT/${TAG}_kbrl_kernel_trace_stats.txt
