@@ -63,6 +63,9 @@ namespace rs {
 #ifndef RS_OCC
 #define RS_OCC 5
 #endif
+#ifndef RS_OCC_OTHER
+#define RS_OCC_OTHER 3  // waves per SIMD the tracing / 8- and 32-lane instances are compiled for (5: tools/spill_repro.sh)
+#endif
 #ifndef RS_DYN_PRIO
 #define RS_DYN_PRIO 1
 #endif
@@ -556,7 +559,7 @@ __device__ __noinline__ double wide_response(const RsDev* D, const double* fad, 
 // BLOCK: the contested PF allocation may hand out RB pairs in block rounds (wide slices); without it the instance
 // carries only the trip loop (fewer live registers: the whole point at 5 waves per SIMD).
 template <int G, bool TRACE, bool BLOCK>
-__global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : 3) void embb_step_kernel(StepArgs A) {
+__global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) void embb_step_kernel(StepArgs A) {
     static_assert(G == 8 || G == 16 || G == 32, "lanes per task");
     constexpr int TPB = 256 / G;                     // tasks per block
     constexpr int TPW = 64 / G;                      // tasks per wave
