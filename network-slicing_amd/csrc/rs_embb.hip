@@ -310,9 +310,14 @@ __device__ __forceinline__ double lane_block(int off, int n, bool on, F ld) {
     double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));  // n < 8: 0.0, as numpy starts
     const int rem = n - lim;
     if (wave_any(on && rem > 0)) {
+        // the (up to seven) remainder elements are added one after the other, but fetched together: one memory round
+        // trip instead of one per element
+        double v[7];
+#pragma unroll
+        for (int j = 0; j < 7; ++j) v[j] = ld(off + lim + (j < rem ? j : 0));
 #pragma unroll
         for (int j = 0; j < 7; ++j)
-            if (on && j < rem) res += ld(off + lim + j);
+            if (on && j < rem) res += v[j];
     }
     return res;
 }
