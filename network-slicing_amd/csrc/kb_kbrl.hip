@@ -35,6 +35,7 @@ struct KbDev {
     double alfa, lo, hi, gamma, eta;
     int32_t shared;   // 1: one dictionary per slice shared by all replicas (build-defined extension)
     int32_t first_env; // global id of local replica 0 (shared mode proposals carry global ids)
+    int32_t serial_apply; // shared mode: apply a full dictionary's proposals one by one as well (KBRL_SERIAL_APPLY, tests)
 };
 
 // dictionary a learner (task = env * S + s) reads and writes
@@ -58,6 +59,7 @@ struct KbState {
     int32_t* err;      // [n_envs]
     uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
     double* work;      // [blocks][2][cap rounded up to 16] per-block columns of an update in progress (kf, d*)
+    double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 16] kernel columns and d* of a proposal list
 };
 
 __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int s) {
@@ -209,6 +211,9 @@ __device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
 
 // Projectron.update (projectron.py:39-60) for x = (sm.x[0..d-2], t_last), given its kernel column in sm.kf.
 // Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.
+// R: rows of Kinv per pass of the mat-vec (their loads stay in flight together; the 1024-thread shared apply uses 8,
+// the per-replica kernels 1 -- more would cost them registers they need for residency)
+template <int R = 1>
 __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, double t_last, int y,
                             Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
     const int cap = D.cap;
@@ -224,11 +229,28 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     } else {
         // d* = Kinv k_f: one row per wave-strided lane group (rows are contiguous -> coalesced)
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        for (int i = wave; i < m; i += nw) {
-            double a = 0.0;
-            for (int j = lane; j < m; j += 64) a += Kinv[(size_t)i * cap + j] * sm.kf[j];
-            for (int dd = 32; dd >= 1; dd >>= 1) a += __shfl_xor(a, dd);
-            if (lane == 0) sm.ds[i] = a;
+        // (eight rows per pass: their loads are independent and stay in flight together; each row's sum is formed
+        // exactly as before -- lane-strided partial sums in increasing j, then the xor butterfly)
+        for (int i0 = wave; i0 < m; i0 += nw * R) {
+            double a[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) a[r] = 0.0;
+            for (int j = lane; j < m; j += 64) {
+                const double kfj = sm.kf[j];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = i0 + r * nw;
+                    const double kv = Kinv[(size_t)(i < m ? i : i0) * cap + j];
+                    if (i < m) a[r] += kv * kfj;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                double v = a[r];
+                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_xor(v, dd);
+                const int i = i0 + r * nw;
+                if (lane == 0 && i < m) sm.ds[i] = v;
+            }
         }
         __syncthreads();
         // 256 strided partial sums whatever the block size (the shared-dictionary kernel runs 1024 threads and must
@@ -682,47 +704,66 @@ __global__ __launch_bounds__(256) void shared_scan_kernel(ScanArgs A) {
 }
 
 // first `budget` proposers of each slice in replica order -> props[s][i][KB_PROP_W], counts[s] = all proposers
-__global__ void shared_collect_kernel(KbDev D, const float* state, const int32_t* labels, const int32_t* cstar,
-                                      int budget, double* props, int32_t* counts) {
-    const int s = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int cnt = 0;
-    const int d = D.dims[s] + 1;
-    for (int env = 0; env < D.n_envs; ++env) {
-        const int c = cstar[env * D.S + s];
-        if (c < 0) continue;
-        if (cnt < budget) {
-            double* p = props + ((size_t)s * budget + cnt) * KB_PROP_W;
-            p[0] = (double)(D.first_env + env);
-            p[1] = (double)(c * 4 + (labels[env * D.S + s] == 1 ? 1 : 0));
-            for (int q = 0; q < d - 1; ++q) p[2 + q] = (double)state[(size_t)env * D.nv + D.off[s] + q];
-        }
-        cnt += 1;
+// Rank of every local proposer of slice s (replicas with cstar >= 0) in replica order, by all threads of the block:
+// thread t owns a contiguous run of replicas, counts its proposers, the block scans the counts.  Calls
+// emit(env, rank) for every proposer and returns the total.  (Launch with KB_RANK_THREADS threads.)
+#define KB_RANK_THREADS 1024
+template <class F>
+__device__ __forceinline__ int ranked_proposers(const KbDev& D, const int32_t* cstar, int s, F emit) {
+    __shared__ int sc[KB_RANK_THREADS];
+    const int T = (int)blockDim.x, t = (int)threadIdx.x;
+    const int per = (D.n_envs + T - 1) / T;
+    const int e0 = t * per, e1 = e0 + per < D.n_envs ? e0 + per : D.n_envs;
+    int c = 0;
+    for (int env = e0; env < e1; ++env) c += cstar[env * D.S + s] >= 0 ? 1 : 0;
+    sc[t] = c;
+    __syncthreads();
+    int incl = c;
+    for (int d = 1; d < T; d <<= 1) {  // Hillis-Steele inclusive scan
+        const int o = t >= d ? sc[t - d] : 0;
+        __syncthreads();
+        incl += o;
+        sc[t] = incl;
+        __syncthreads();
     }
-    counts[s] = cnt;
+    const int total = sc[T - 1];
+    int pos = incl - c;
+    for (int env = e0; env < e1; ++env)
+        if (cstar[env * D.S + s] >= 0) emit(env, pos++);
+    return total;
+}
+
+__device__ __forceinline__ void write_proposal(const KbDev& D, const float* state, const int32_t* labels, int s, int env,
+                                               int c, double* p) {
+    const int d = D.dims[s] + 1;
+    p[0] = (double)(D.first_env + env);
+    p[1] = (double)(c * 4 + (labels[env * D.S + s] == 1 ? 1 : 0));
+    for (int q = 0; q < d - 1; ++q) p[2 + q] = (double)state[(size_t)env * D.nv + D.off[s] + q];
+}
+
+__global__ __launch_bounds__(KB_RANK_THREADS) void shared_collect_kernel(KbDev D, const float* state, const int32_t* labels,
+                                                                         const int32_t* cstar, int budget, double* props,
+                                                                         int32_t* counts) {
+    const int s = blockIdx.x;
+    const int total = ranked_proposers(D, cstar, s, [&](int env, int rank) {
+        if (rank < budget)
+            write_proposal(D, state, labels, s, env, cstar[env * D.S + s], props + ((size_t)s * budget + rank) * KB_PROP_W);
+    });
+    if (threadIdx.x == 0) counts[s] = total;
 }
 
 // ---- device-resident exchange (kb_shared_step): the proposal block a rank contributes to the all-gather is
 //   block = [S doubles: proposers per slice] [S][budget][KB_PROP_W] proposals
-__global__ void shared_collect_block_kernel(KbDev D, const float* state, const int32_t* labels, const int32_t* cstar,
-                                            int budget, double* block) {
+__global__ __launch_bounds__(KB_RANK_THREADS) void shared_collect_block_kernel(KbDev D, const float* state,
+                                                                               const int32_t* labels, const int32_t* cstar,
+                                                                               int budget, double* block) {
     const int s = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int cnt = 0;
-    const int d = D.dims[s] + 1;
     double* props = block + D.S;
-    for (int env = 0; env < D.n_envs; ++env) {
-        const int c = cstar[env * D.S + s];
-        if (c < 0) continue;
-        if (cnt < budget) {
-            double* p = props + ((size_t)s * budget + cnt) * KB_PROP_W;
-            p[0] = (double)(D.first_env + env);
-            p[1] = (double)(c * 4 + (labels[env * D.S + s] == 1 ? 1 : 0));
-            for (int q = 0; q < d - 1; ++q) p[2 + q] = (double)state[(size_t)env * D.nv + D.off[s] + q];
-        }
-        cnt += 1;
-    }
-    block[s] = (double)cnt;
+    const int total = ranked_proposers(D, cstar, s, [&](int env, int rank) {
+        if (rank < budget)
+            write_proposal(D, state, labels, s, env, cstar[env * D.S + s], props + ((size_t)s * budget + rank) * KB_PROP_W);
+    });
+    if (threadIdx.x == 0) block[s] = (double)total;
 }
 
 // Merge the gathered blocks of all W ranks for slice s = blockIdx.x: ascending global replica id, the first `budget`
@@ -777,16 +818,109 @@ __global__ __launch_bounds__(256) void shared_merge_kernel(KbDev D, const double
 }
 
 // the first n_accept[s] local proposers of slice s (replica order) had their sample applied: move on
-__global__ void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_t* n_accept, int32_t* cursor) {
+__global__ __launch_bounds__(KB_RANK_THREADS) void shared_commit_kernel(KbDev D, const int32_t* cstar, const int32_t* n_accept,
+                                                                        int32_t* cursor) {
     const int s = blockIdx.x;
-    if (threadIdx.x != 0) return;
-    int left = n_accept[s];
-    for (int env = 0; env < D.n_envs && left > 0; ++env) {
-        const int c = cstar[env * D.S + s];
-        if (c < 0) continue;
-        cursor[env * D.S + s] = c + 1;
-        left -= 1;
+    const int left = n_accept[s];
+    ranked_proposers(D, cstar, s, [&](int env, int rank) {
+        if (rank < left) cursor[env * D.S + s] = cstar[env * D.S + s] + 1;
+    });
+}
+
+// sum of the 256 strided partial products Σ_{j = t, t + 256, ...} a[j] b[j] (t < 256) exactly as block_sum forms it in the
+// 256-thread kernels -- per 64-lane wave the xor butterfly (lane 0's value), then the four wave totals in order -- but
+// by ONE wave, without block barriers.  All lanes return the value.
+__device__ __forceinline__ double wave_dot256(const double* a, const double* b, int m) {
+    const int lane = threadIdx.x & 63;
+    double t = 0.0;
+    for (int v = 0; v < 4; ++v) {
+        double part = 0.0;
+        for (int j = 64 * v + lane; j < m; j += 256) part += a[j] * b[j];
+        for (int dd = 32; dd >= 1; dd >>= 1) part += __shfl_xor(part, dd);
+        t += __shfl(part, 0);
     }
+    return t;  // (the 1024-thread kernels add exact zeros for their waves 4..15)
+}
+
+// shared_apply_kernel for a dictionary at capacity (projection only).  Returns the number of mistakes.
+__device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, int d, const double* pr, int np,
+                                     int budget, Lds& sm) {
+    const int cap = D.cap, capr = sm.capr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const double* L = K.L + (size_t)s * KB_DMAX * cap;
+    const double* Kinv = K.Kinv + (size_t)s * cap * cap;
+    double* coeffg = K.coeff + (size_t)s * cap;
+    double* KF = K.workb + (size_t)s * 2 * budget * capr;  // [np][capr] kernel columns
+    double* DS = KF + (size_t)budget * capr;               // [np][capr] d* = Kinv k_f
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        sm.lam[j] = L[(size_t)(d - 1) * cap + j];
+        sm.co[j] = coeffg[j];
+    }
+    __syncthreads();
+    // ---- kernel columns of all proposals (prepare_operands' D0 and kernel_column's arithmetic)
+    for (int e = threadIdx.x; e < np * m; e += blockDim.x) {
+        const int p = e / m, j = e - p * m;
+        const double* x = pr + (size_t)p * KB_PROP_W + 2;
+        double d0 = 0.0;
+        for (int q = 0; q < d - 1; ++q) {
+            const double t = L[(size_t)q * cap + j] - x[q];
+            d0 += t * t;
+        }
+        const int c = ((int)pr[(size_t)p * KB_PROP_W + 1]) >> 2;
+        const double dl = sm.lam[j] - (double)c / (double)D.n_prbs;
+        KF[(size_t)p * capr + j] = rs_exp(-D.gamma * (d0 + dl * dl));
+    }
+    __syncthreads();
+    // ---- d* = Kinv k_f for all proposals: a wave keeps a row of Kinv hot and walks the proposals (each row sum as in
+    // apply_update: lane-strided partial sums in increasing j, then the xor butterfly, lane 0's value)
+    for (int i = wave; i < m; i += nw) {
+        const double* row = Kinv + (size_t)i * cap;
+        for (int p0 = 0; p0 < np; p0 += 4) {
+            double a[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int j = lane; j < m; j += 64) {
+                const double kv = row[j];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double kf = KF[(size_t)(p0 + r < np ? p0 + r : p0) * capr + j];
+                    a[r] += kv * kf;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double v = a[r];
+                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_xor(v, dd);
+                if (lane == 0 && p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = v;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- delta = 1 - k_f . d* per proposal (only the "saturated" flag depends on it here)
+    for (int p = wave; p < np; p += nw) {
+        const double dot = wave_dot256(DS + (size_t)p * capr, KF + (size_t)p * capr, m);
+        double delta = 1.0 - dot;
+        delta = delta > 0.0 ? delta : 0.0;
+        if (lane == 0) sm.f[p] = delta > D.eta ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // ---- the proposals in order: predict against the evolving coefficients, project if still a mistake
+    uint64_t n_mist = 0;
+    if (wave == 0) {
+        bool sat = false;
+        for (int p = 0; p < np; ++p) {
+            const int y = (((int)pr[(size_t)p * KB_PROP_W + 1]) & 1) ? 1 : -1;
+            const double f = wave_dot256(KF + (size_t)p * capr, sm.co, m);
+            if (f * (double)y <= 0.0) {
+                n_mist += 1;
+                sat = sat || sm.f[p] != 0.0;
+                const double* ds = DS + (size_t)p * capr;
+                for (int j = lane; j < m; j += 64) sm.co[j] = sm.co[j] + (double)y * ds[j];
+            }
+        }
+        if (sat && lane == 0) atomicOr(&K.err[0], 8);  // a full dictionary met a sample it would have grown for
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += blockDim.x) coeffg[j] = sm.co[j];
+    return n_mist;
 }
 
 // apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
@@ -798,6 +932,14 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     int m = K.m[s];
     const int np = counts[s] < budget ? counts[s] : budget;
     uint64_t n_mist = 0, n_grow = 0;
+    if (np > 0 && m >= D.cap && m >= 2 && !D.serial_apply) {
+        // A dictionary at capacity only projects: landmarks and Kinv are fixed for the whole list, so everything that
+        // does not involve the coefficients is computed for ALL proposals at once, and only f = k . coeff and the
+        // coefficient update run one proposal after the other (by one wave, without block barriers).
+        n_mist = apply_full_batch(D, K, s, m, d, props + (size_t)s * budget * KB_PROP_W, np, budget, sm);
+        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
+        return;
+    }
     for (int i = 0; i < np; ++i) {
         const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
         const int packed = (int)p[1];
@@ -817,7 +959,7 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
         if (f * (double)y <= 0.0) {  // still a mistake against the evolving dictionary
             int branch;
             double delta;
-            const int m_new = apply_update(D, K, s, 0, m, d, (double)c / (double)D.n_prbs, y, sm, &branch, &delta);
+            const int m_new = apply_update<8>(D, K, s, 0, m, d, (double)c / (double)D.n_prbs, y, sm, &branch, &delta);
             n_mist += 1;
             if (branch == 2 && m_new > m) n_grow += 1;
             m = m_new;

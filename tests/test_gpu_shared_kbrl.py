@@ -169,6 +169,59 @@ def test_shared_loop_run_to_run_determinism():
         R['agent'].close()
 
 
+def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch):
+    """A shared dictionary at capacity only projects, so the apply kernel computes the kernel columns and d* = Kinv k_f
+    of a whole proposal list at once and runs only predict + coefficient update in order (one wave, no block
+    barriers).  With a capacity small enough to fill within a few steps (16 landmarks), that path against the
+    one-proposal-at-a-time path (KBRL_SERIAL_APPLY): same hits, sizes, coefficients (bits) and actions at every step."""
+    from ranslice.config import EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import SharedVecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps = 512, 30
+    cfg = make_config(2, n_envs=N)
+    fading = [synth_fading(t, 4000) for t in range(3)]
+    dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
+
+    def make(serial):
+        if serial:
+            monkeypatch.setenv('KBRL_SERIAL_APPLY', '1')
+        else:
+            monkeypatch.delenv('KBRL_SERIAL_APPLY', raising=False)
+        env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading)
+        agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=16)
+        monkeypatch.delenv('KBRL_SERIAL_APPLY', raising=False)
+        rng = np.random.default_rng(77)
+        ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
+                             rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+        sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)),
+                             rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+        state = env.reset()
+        agent.reset(ia, sf)
+        return dict(env=env, agent=agent, state=state, action=ia.copy())
+    A, B = make(False), make(True)
+    full_seen = False
+    for i in range(steps):
+        res = []
+        for R in (A, B):
+            obs, rew, _, info = R['env'].step(R['action'])
+            hits = R['agent'].update_control(R['state'], R['action'], info['SLA_labels'])
+            learners = [R['agent'].learner(0, s) for s in range(len(dims))]
+            action, adj = R['agent'].select_action(obs)
+            R['state'], R['action'] = obs, action
+            res.append((hits, [l['m'] for l in learners], [l['coeff'].tobytes() for l in learners], action))
+        a, b = res
+        assert (a[0] == b[0]).all(), ('hits', i)
+        assert a[1] == b[1], ('sizes', i, a[1], b[1])
+        assert a[2] == b[2], ('coeff', i)
+        assert (a[3] == b[3]).all(), ('action', i)
+        full_seen = full_seen or max(a[1]) >= 16
+    assert full_seen, 'no dictionary reached its capacity: the batched path was not exercised'
+    for R in (A, B):
+        R['env'].close()
+        R['agent'].close()
+
+
 def _run_ranks(world, n_per_rank, steps, tmp_path, extra_env=None):
     import subprocess
     import sys
