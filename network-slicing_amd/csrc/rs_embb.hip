@@ -63,6 +63,9 @@ namespace rs {
 #ifndef RS_OCC
 #define RS_OCC 5
 #endif
+#ifndef RS_LOADS
+#define RS_LOADS 4  // column sums: fading samples a lane has in flight (4 or 8)
+#endif
 #ifndef RS_OCC_OTHER
 #define RS_OCC_OTHER 3  // waves per SIMD the tracing / 8- and 32-lane instances are compiled for (5: tools/spill_repro.sh)
 #endif
@@ -298,12 +301,12 @@ __device__ __forceinline__ double lane_block(int off, int n, bool on, F ld) {
     for (int i = 8; wave_any(on && i < lim); i += 8) {
         if (on && i < lim) {
 #pragma unroll
-            for (int h = 0; h < 8; h += 4) {  // four loads in flight at a time (register budget)
-                double v[4];
+            for (int h = 0; h < 8; h += RS_LOADS) {  // RS_LOADS loads in flight at a time (register budget)
+                double v[RS_LOADS];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ld(off + i + h + j);
+                for (int j = 0; j < RS_LOADS; ++j) v[j] = ld(off + i + h + j);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[h + j] += v[j];
+                for (int j = 0; j < RS_LOADS; ++j) r[h + j] += v[j];
             }
         }
     }
