@@ -157,10 +157,13 @@ int rs_set_kernel_timing(rs_handle* h, int enable);
  * more UE lanes are replayed by the 32-lane instance; results are identical for every setting. */
 int rs_set_group_size(rs_handle* h, int lanes);
 
-/* Scheduling hint.  mode 1: allocations come from a learning agent (the carrier is concentrated on few slices);
- * the step launches the kernel instance tuned for long contested PF loops.  mode 0: the plain instance.
- * mode < 0 (default): automatic -- by batch size, and kb_step_resident switches it on for the environment it
- * drives.  Results do not depend on it. */
+/* Scheduling hint.  mode 1: allocations come from a learning agent (the carrier is concentrated on few, wide slices);
+ * the 16-lane step uses its BLOCK instance, which hands out the RB pairs of wide contested slices in block rounds
+ * (every backlogged UE steps ahead in parallel) instead of one leader run at a time.  mode 0: the plain instance
+ * (trip loop only; faster on the 30-50-RB slices of an even split).  mode < 0 (default): automatic -- rs_step looks at
+ * the allocations it is handed, kb_step_resident asks for the BLOCK instance for the environment it drives, the
+ * on-device random script goes by its average slice width.  Results do not depend on it (both are exact against the
+ * reference loop, tests/test_gpu_parity.py::test_block_round_allocations). */
 int rs_set_schedule_hint(rs_handle* h, int mode);
 
 /* Developer aid: cycle sums per code section of the eMBB step kernel (zeros in normal builds). */

@@ -92,8 +92,8 @@ struct rs_handle {
     int order_par = 0;           // which half of d_ohist the next step counts into
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
     int order_pair = 256;        // modes 4..: share (/256) of the waves led by one heavy task (RANSLICE_PAIR)
-    int grant_mode = 0;          // 1: wide contested slices are expected, the 16-lane step uses its BLOCK instance (rs_set_schedule_hint)
-    bool grant_auto = true;      // grant_mode follows the scenario / the driving agent until the caller sets it
+    int block_hint = 0;          // 1: wide contested slices are expected, the 16-lane step uses its BLOCK instance (rs_set_schedule_hint)
+    bool hint_auto = true;      // block_hint follows the scenario / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
@@ -493,10 +493,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         const int g = atoi(e);
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
-    h->grant_mode = auto_hint(h);
+    h->block_hint = auto_hint(h);
     if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
-        h->grant_auto = atoi(e) < 0;
-        if (!h->grant_auto) h->grant_mode = atoi(e) ? 1 : 0;
+        h->hint_auto = atoi(e) < 0;
+        if (!h->hint_auto) h->block_hint = atoi(e) ? 1 : 0;
     }
     DA(h->d_st, 1);
     DA(h->d_run, 4);
@@ -751,7 +751,7 @@ static int launch_step(rs_handle* h) {
                 else hipLaunchKernelGGL((embb_step_kernel<8, false, true>), grid, block, 0, h->stream, a);
             } else if (g == 16) {
                 if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, true>), grid, block, 0, h->stream, a);
-                else if (h->grant_mode) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
+                else if (h->block_hint) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
                 else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
             } else {
                 if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, true>), grid, block, 0, h->stream, a);
@@ -847,10 +847,10 @@ extern "C" int rs_step(rs_handle* h, const int32_t* actions, float* obs, double*
             return RS_EINVAL;
         }
     }
-    if (h->grant_auto) {  // these allocations are in plain sight: pick the instance for them (a hint, same results)
+    if (h->hint_auto) {  // these allocations are in plain sight: pick the instance for them (a hint, same results)
         const int want = wide * 16 >= N ? 1 : 0;
-        if (want != h->grant_mode) {
-            h->grant_mode = want;
+        if (want != h->block_hint) {
+            h->block_hint = want;
             drop_graph(h);
         }
     }
@@ -995,15 +995,14 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
     return RS_OK;
 }
 
-// Lanes per task of the primary eMBB launch (16 or 32).  Results do not depend on it.
-// mode 1: allocations come from a learning agent, which concentrates the carrier on few slices (long contested PF
-// loops in a few tasks): the step uses the instance whose heaviest waves schedule one RB pair per trip.  mode 0:
-// the plain instance.  mode < 0: automatic (by batch size; kb_step_resident switches it on for the environment it
-// drives).  A scheduling hint only: results are identical.
+// mode 1: allocations come from a learning agent, which concentrates the carrier on few wide slices: the 16-lane step
+// uses its BLOCK instance (block rounds of the contested PF allocation, rs_embb.hip).  mode 0: the plain instance
+// (trip loop only).  mode < 0: automatic (auto_hint; rs_step goes by the allocations it is handed, kb_step_resident
+// switches BLOCK on for the environment it drives).  A scheduling hint only: results are identical.
 extern "C" int rs_set_schedule_hint(rs_handle* h, int mode) {
     if (!h) return RS_EINVAL;
-    h->grant_auto = mode < 0;
-    h->grant_mode = mode < 0 ? auto_hint(h) : (mode ? 1 : 0);
+    h->hint_auto = mode < 0;
+    h->block_hint = mode < 0 ? auto_hint(h) : (mode ? 1 : 0);
     drop_graph(h);
     return RS_OK;
 }
