@@ -15,6 +15,7 @@
 #include "rs_mmtc.hip"
 #include "rs_order.hip"
 #include "rs_mux.hip"
+#include "rs_lane.hip"
 
 using namespace rs;
 
@@ -99,6 +100,8 @@ struct rs_handle {
     int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
     int n_ran = 0;                                // RAN slices (info rows): n_embb + n_mmtc
     bool mux = false;                             // rs_config.l1_multiplex
+    bool lane_engine = false;                     // eMBB step in lane-per-task form (rs_lane.hip): own per-UE layout
+    rs::LaneWork lane_w = {};
     int64_t* d_run = nullptr;    // device-side run state read by the step kernels: [0] slots since reset,
                                  // [1] step index and [2] seed of the on-device action script (rs_run_random)
     hipGraph_t graph = nullptr;  // two captured steps (one per parity of the order counters) of rs_run_random
@@ -447,7 +450,11 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     for (int i = 0; i < 3; ++i) d.norm_mmtc[i] = cfg->norm_mmtc[i];
 
     int rc;
-    const size_t T = (size_t)h->n_tasks, U = T * RS_GROUP, N = (size_t)cfg->n_envs;
+    // Lane-per-task engine (rs_lane.hip) from 8192 replicas' worth of eMBB tasks on; RANSLICE_LANE=1/0 forces it on/off
+    h->lane_engine = !h->mux && h->n_tasks >= 8192 * 4;
+    if (const char* e = getenv("RANSLICE_LANE")) h->lane_engine = !h->mux && h->n_tasks > 0 && atoi(e) != 0;
+    const size_t T = (size_t)h->n_tasks, N = (size_t)cfg->n_envs;
+    const size_t U = (h->lane_engine ? (T + 63) / 64 * 64 : T) * RS_GROUP;  // the lane-major layout fills whole waves
     RsState& s = h->st;
 #define DA(p, n)                                   \
     if ((rc = dalloc(h, &(p), (n))) != RS_OK) return rc
@@ -457,6 +464,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(s.u_hold_at, U); DA(s.u_e_snr, U); DA(s.u_findex, U); DA(s.u_bits, U); DA(s.u_prbs, U);
     DA(s.u_vbr_at, U); DA(s.u_ctr, U); DA(s.u_serial, U); DA(s.u_flags, U);
     DA(s.u_burst, U * RS_BURSTS);
+    if (h->lane_engine) {
+        DA(h->lane_w.evt, U); DA(h->lane_w.nact, U); DA(h->lane_w.q, U); DA(h->lane_w.rate, U);
+        DA(h->lane_w.thl, U); DA(h->lane_w.m, U);
+    }
     DA(s.seeds, N); DA(s.err, N);
     DA(h->d_actions, N * h->n_slices);
     DA(h->d_obs, N * h->n_vars);
@@ -758,6 +769,18 @@ static int launch_step(rs_handle* h) {
                 else hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
             }
         };
+        if (h->lane_engine) {
+            if (h->trace_on) {
+                h->err = "the allocation trace needs the group engine (RANSLICE_LANE=0)";
+                return RS_ESTATE;
+            }
+            rs::LaneArgs la;
+            la.a = a;
+            la.w = h->lane_w;
+            if (h->timing) HIPCHK(h, hipEventRecord(e0, h->stream));
+            hipLaunchKernelGGL(embb_lane_step_kernel, dim3((unsigned)((h->n_tasks + 255) / 256)), dim3(256), 0, h->stream, la);
+            if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
+        } else {
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
         // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)
         if (h->order_mode > 0) {
@@ -779,6 +802,7 @@ static int launch_step(rs_handle* h) {
         if (h->group < 32) {
             a.replay = 1;
             launch(32);
+        }
         }
     }
     if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
