@@ -450,8 +450,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     for (int i = 0; i < 3; ++i) d.norm_mmtc[i] = cfg->norm_mmtc[i];
 
     int rc;
-    // Lane-per-task engine (rs_lane.hip) from 8192 replicas' worth of eMBB tasks on; RANSLICE_LANE=1/0 forces it on/off
-    h->lane_engine = !h->mux && h->n_tasks >= 8192 * 4;
+    // Lane-per-task engine (rs_lane.hip): exact, but measured 4-12x slower than the group kernels at every batch size
+    // (its per-UE state sits in HBM behind dependent loads and every lane walks its own fading column), so nothing
+    // selects it; RANSLICE_LANE=1 turns it on (tests, tools/lane_check.sh).
+    h->lane_engine = false;
     if (const char* e = getenv("RANSLICE_LANE")) h->lane_engine = !h->mux && h->n_tasks > 0 && atoi(e) != 0;
     const size_t T = (size_t)h->n_tasks, N = (size_t)cfg->n_envs;
     const size_t U = (h->lane_engine ? (T + 63) / 64 * 64 : T) * RS_GROUP;  // the lane-major layout fills whole waves

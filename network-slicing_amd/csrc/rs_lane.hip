@@ -1,17 +1,24 @@
-// eMBB step, LANE-PER-TASK form (batches of >= 8192 replicas per GPU: BASELINE config 5).
+// eMBB step, LANE-PER-TASK form (VERDICT r1 #3 asked for it for batches of >= 8192 replicas per GPU).
 //
 // embb_step_kernel (rs_embb.hip) gives a (replica, slice) task 16 lanes, of which three or four hold a UE: its
-// instruction stream is issued for 64 lanes and used by a fifth of them, and what it buys is latency -- fine while a
-// batch only just fills the chip.  Here ONE LANE owns a task for the whole step and walks its UEs one after the other,
-// the way the reference's Python does: 64 tasks per wavefront, no cross-lane traffic at all, every loop runs for the
-// longest of the 64 tasks.  A wave's step takes about as long as in the group kernel, but it carries 16 times the
-// tasks, so once a batch has more tasks than lanes on the chip this form wins (tools/size_sweep.sh).
+// instruction stream is issued for 64 lanes and used by a fifth of them.  Here ONE LANE owns a task for the whole step
+// and walks its UEs one after the other, the way the reference's Python does: 64 tasks per wavefront, no cross-lane
+// traffic at all, every loop runs for the longest of the 64 tasks; an eighth of the instructions per task.
 //
-// Same state fields, same Philox streams, same arithmetic in the same order as the group kernel (both are
-// bit-exact against the oracle); only the HBM layout of the per-UE arrays differs -- lane-major,
-// [task / 64][UE][task % 64], so that the 64 lanes of a wave touch one 256/512-byte segment per field -- which is why a
-// handle keeps the engine it was created with.  Per-UE scratch of the scheduler (queue in bits, rate, local
-// throughput average, metric) lives in the same layout in global memory.
+// Same state fields, same Philox streams, same arithmetic in the same order as the group kernel, and bit-exact
+// against the oracle at full size (tests/test_gpu_parity.py::test_lane_engine_matches_oracle; the whole of
+// tests/test_gpu_fullsize.py passes with RANSLICE_LANE=1).  Only the HBM layout of the per-UE arrays differs --
+// lane-major, [task / 64][UE][task % 64], one 256/512-byte segment per field and wave -- which is why a handle keeps
+// the engine it was created with.
+//
+// MEASURED (tools/lane_check.sh, MI355X, scenario_0, stationary population): 14.1 ms per step at 4096 replicas
+// (group kernel 1.13), 15.5 at 8192 (2.08), 17.2 at 16384 (3.83), 47.6 at 65536 (13.8).  The instruction count is
+// not what bounds it: a lane's UE records sit in HBM/L2 behind loads that depend on each other (~1 us each, some
+// 200 per slot), every lane walks its own fading column (64 cache lines per load instruction, nine batches of four per
+// UE and slot), and at 235 VGPRs two waves per SIMD cannot hide any of that.  Moving the records into LDS (~84 B per
+// UE, eight UEs per lane: three waves per CU) would cut the chain to an estimated 1.5 ms per round of waves -- a
+// third better than the group kernel at >= 8192 replicas at best, and worse below.  So nothing selects this engine; it
+// stays as the exact, measured answer to "would one lane per task pay on this chip?" (DESIGN.md section 8).
 #pragma once
 #include "rs_embb.hip"
 
