@@ -832,33 +832,45 @@ __global__ __launch_bounds__(KB_RANK_THREADS) void shared_commit_kernel(KbDev D,
 // by ONE wave, without block barriers.  All lanes return the value.
 __device__ __forceinline__ double wave_dot256(const double* a, const double* b, int m) {
     const int lane = threadIdx.x & 63;
-    double t = 0.0;
+    double part[4];
+#pragma unroll
     for (int v = 0; v < 4; ++v) {
-        double part = 0.0;
-        for (int j = 64 * v + lane; j < m; j += 256) part += a[j] * b[j];
-        for (int dd = 32; dd >= 1; dd >>= 1) part += __shfl_xor(part, dd);
-        t += __shfl(part, 0);
+        part[v] = 0.0;
+        for (int j = 64 * v + lane; j < m; j += 256) part[v] += a[j] * b[j];
     }
+    for (int dd = 32; dd >= 1; dd >>= 1) {  // four independent butterflies, stepped together
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t += __shfl(part[v], 0);
     return t;  // (the 1024-thread kernels add exact zeros for their waves 4..15)
 }
 
-// shared_apply_kernel for a dictionary at capacity (projection only).  Returns the number of mistakes.
-__device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, int d, const double* pr, int np,
-                                     int budget, Lds& sm) {
-    const int cap = D.cap, capr = sm.capr;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+// ---- A dictionary at capacity only projects: landmarks and Kinv are fixed for a whole proposal list, so everything
+// that does not involve the coefficients is computed for ALL proposals at once by kernels as wide as the chip
+// (shared_cols_kernel, shared_matvec_kernel: one workgroup per slice would leave 250 CUs idle and walk 256 dependent L2
+// round trips per wave), and only f = k . coeff and the coefficient update run one proposal after the other
+// (shared_apply_kernel, one wave, no block barriers).  Work area per slice: KF [budget][capr] kernel columns,
+// DS [budget][capr] d* = Kinv k_f.
+__device__ __forceinline__ bool batch_applies(const KbDev& D, int m) { return m >= D.cap && m >= 2 && !D.serial_apply; }
+
+#define KB_COLS_BLOCKS 16
+#define KB_MATVEC_BLOCKS 32
+
+// kernel columns of all proposals of the full dictionaries (prepare_operands' D0 and kernel_column's arithmetic)
+__global__ __launch_bounds__(256) void shared_cols_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
+                                                          int budget) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!batch_applies(D, m)) return;
+    const int np = counts[s] < budget ? counts[s] : budget;
+    const int d = D.dims[s] + 1, cap = D.cap, capr = kb_capr(cap);
+    const double* pr = props + (size_t)s * budget * KB_PROP_W;
     const double* L = K.L + (size_t)s * KB_DMAX * cap;
-    const double* Kinv = K.Kinv + (size_t)s * cap * cap;
-    double* coeffg = K.coeff + (size_t)s * cap;
-    double* KF = K.workb + (size_t)s * 2 * budget * capr;  // [np][capr] kernel columns
-    double* DS = KF + (size_t)budget * capr;               // [np][capr] d* = Kinv k_f
-    for (int j = threadIdx.x; j < m; j += blockDim.x) {
-        sm.lam[j] = L[(size_t)(d - 1) * cap + j];
-        sm.co[j] = coeffg[j];
-    }
-    __syncthreads();
-    // ---- kernel columns of all proposals (prepare_operands' D0 and kernel_column's arithmetic)
-    for (int e = threadIdx.x; e < np * m; e += blockDim.x) {
+    double* KF = K.workb + (size_t)s * 2 * budget * capr;
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < np * m; e += gridDim.y * blockDim.x) {
         const int p = e / m, j = e - p * m;
         const double* x = pr + (size_t)p * KB_PROP_W + 2;
         double d0 = 0.0;
@@ -867,12 +879,24 @@ __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, in
             d0 += t * t;
         }
         const int c = ((int)pr[(size_t)p * KB_PROP_W + 1]) >> 2;
-        const double dl = sm.lam[j] - (double)c / (double)D.n_prbs;
+        const double dl = L[(size_t)(d - 1) * cap + j] - (double)c / (double)D.n_prbs;
         KF[(size_t)p * capr + j] = rs_exp(-D.gamma * (d0 + dl * dl));
     }
-    __syncthreads();
-    // ---- d* = Kinv k_f for all proposals: a wave keeps a row of Kinv hot and walks the proposals (each row sum as in
-    // apply_update: lane-strided partial sums in increasing j, then the xor butterfly, lane 0's value)
+}
+
+// d* = Kinv k_f for all proposals of the full dictionaries: a wave takes rows of Kinv and walks the proposals four at a
+// time (each row sum as in apply_update: lane-strided partial sums in increasing j, then the xor butterfly, lane 0)
+__global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!batch_applies(D, m)) return;
+    const int np = counts[s] < budget ? counts[s] : budget;
+    const int cap = D.cap, capr = kb_capr(cap);
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    const double* Kinv = K.Kinv + (size_t)s * cap * cap;
+    const double* KF = K.workb + (size_t)s * 2 * budget * capr;
+    double* DS = K.workb + (size_t)s * 2 * budget * capr + (size_t)budget * capr;
     for (int i = wave; i < m; i += nw) {
         const double* row = Kinv + (size_t)i * cap;
         for (int p0 = 0; p0 < np; p0 += 4) {
@@ -885,15 +909,29 @@ __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, in
                     a[r] += kv * kf;
                 }
             }
+            for (int dd = 32; dd >= 1; dd >>= 1) {  // the four butterflies step together
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double v = a[r];
-                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_xor(v, dd);
-                if (lane == 0 && p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = v;
+                for (int r = 0; r < 4; ++r) a[r] += __shfl_xor(a[r], dd);
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = a[r];
             }
         }
     }
-    __syncthreads();
+}
+
+// the ordered part, by the slice's own workgroup (shared_apply_kernel): delta per proposal, then predict + projection in
+// list order.  Returns the number of mistakes.
+__device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, const double* pr, int np, int budget,
+                                     Lds& sm) {
+    const int cap = D.cap, capr = sm.capr;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    double* coeffg = K.coeff + (size_t)s * cap;
+    const double* KF = K.workb + (size_t)s * 2 * budget * capr;
+    const double* DS = KF + (size_t)budget * capr;
+    for (int j = threadIdx.x; j < m; j += blockDim.x) sm.co[j] = coeffg[j];
     // ---- delta = 1 - k_f . d* per proposal (only the "saturated" flag depends on it here)
     for (int p = wave; p < np; p += nw) {
         const double dot = wave_dot256(DS + (size_t)p * capr, KF + (size_t)p * capr, m);
@@ -932,11 +970,9 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     int m = K.m[s];
     const int np = counts[s] < budget ? counts[s] : budget;
     uint64_t n_mist = 0, n_grow = 0;
-    if (np > 0 && m >= D.cap && m >= 2 && !D.serial_apply) {
-        // A dictionary at capacity only projects: landmarks and Kinv are fixed for the whole list, so everything that
-        // does not involve the coefficients is computed for ALL proposals at once, and only f = k . coeff and the
-        // coefficient update run one proposal after the other (by one wave, without block barriers).
-        n_mist = apply_full_batch(D, K, s, m, d, props + (size_t)s * budget * KB_PROP_W, np, budget, sm);
+    if (np > 0 && batch_applies(D, m)) {
+        // kernel columns and d* of the whole list are in the work area (shared_cols_kernel, shared_matvec_kernel)
+        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, sm);
         if (threadIdx.x == 0) atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
         return;
     }
