@@ -58,11 +58,13 @@ def _wide_actions(rng, n_envs, n_slices, n_prbs, step):
 
 
 def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None, group=None, hint=None,
-             actions=None):
+             actions=None, tweak=None):
     from ranslice.vec_env import VecRanSlice
     cfg = make_config(scenario, n_envs=n_envs)
     if churn:
         _churn(cfg)
+    if tweak:
+        tweak(cfg)
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, seed=seed0)
     if group is not None:
         env.set_group_size(group)
@@ -76,6 +78,8 @@ def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sa
     ocfg = make_config(scenario, n_envs=1)
     if churn:
         _churn(ocfg)
+    if tweak:
+        tweak(ocfg)
     oracles = []
     for r in reps:
         o = po.OracleEnv(ocfg, fading)
@@ -294,3 +298,19 @@ def test_lane_engine_matches_oracle(golden_dir, scenario, monkeypatch):
              check_trace=False)
     _compare(scenario, n_envs=70, steps=12, fading=_small_fading(golden_dir), churn=True, seed0=5200 + scenario,
              check_trace=False, actions=_wide_actions)
+
+
+@pytest.mark.parametrize('gran,window', [(1, 50), (3, 50), (4, 7), (2, 3)])
+def test_pf_granularity_and_window_variants(golden_dir, gran, window):
+    """The PF allocation's shortcuts (closed forms, the run test without the divide, block rounds with their "full
+    pairs" bookkeeping and the verified reciprocal form of the throughput update) do not lean on the reference's
+    defaults: RB granularities 1, 3 and 4 (odd slices leave a short last "pair"), averaging windows 50, 7 and 3, narrow
+    and wide contested slices -- per-slot allocations of the tracing BLOCK instance and step outputs of the plain one
+    against the oracle's reference loop."""
+    def tweak(cfg):
+        cfg.pf_granularity, cfg.pf_window = gran, window
+    for acts in (None, _wide_actions):
+        _compare(0, n_envs=32, steps=10, fading=_small_fading(golden_dir), churn=True, seed0=6000 + 10 * gran + window,
+                 group=16, hint=1, actions=acts, tweak=tweak)
+        _compare(0, n_envs=32, steps=10, fading=_small_fading(golden_dir), churn=True, seed0=6100 + 10 * gran + window,
+                 group=16, hint=0, actions=acts, tweak=tweak, check_trace=False)
