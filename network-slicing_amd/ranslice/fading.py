@@ -40,6 +40,54 @@ def synth_fading(trace_id, n_cols, seed=20240, n_rows=100, nan_cols=()):
     return np.ascontiguousarray(db)
 
 
+# ---- second profile: tapped-delay-line traces in the style of the ns-3 LTE fading traces the reference was run on
+# (fading_trace_{EPA,ETU,EVA}: 100 RBs x 10,000 samples of 1 ms, produced by ns-3's fading-trace-generator from the
+# 3GPP TS 36.104 Annex B.2 delay profiles).  Each tap is an independent Rayleigh process with a Jakes Doppler spectrum
+# (sum of sinusoids), the RB gain is |sum_l sqrt(P_l) g_l(t) exp(-j 2 pi f_RB tau_l)|^2 with unit mean power.  The
+# first profile (synth_fading) is kept as it is: the golden fixtures depend on it.
+_TDL = {
+    0: ((0, 30, 70, 90, 110, 190, 410), (0.0, -1.0, -2.0, -3.0, -8.0, -17.2, -20.8), 3.0),            # EPA, 3 km/h
+    1: ((0, 50, 120, 200, 230, 500, 1600, 2300, 5000), (-1.0, -1.0, -1.0, 0.0, 0.0, 0.0, -3.0, -5.0, -7.0), 3.0),  # ETU
+    2: ((0, 30, 150, 310, 370, 710, 1090, 1730, 2510), (0.0, -1.5, -1.4, -3.6, -0.6, -9.1, -7.0, -12.0, -16.9), 60.0),  # EVA
+}
+
+
+def synth_fading_tdl(trace_id, n_cols, seed=20240, n_rows=100, carrier_ghz=2.0, n_osc=24, nan_cols=()):
+    """Frequency-selective Rayleigh fading gains in dB, [rows = RB (180 kHz apart)][cols = 1-ms samples], quantised to
+    1e-4 dB like the CSV exports.  Doppler f_d = v f_c / c (5.6 Hz at 3 km/h, 111 Hz at 60 km/h)."""
+    delays_ns, powers_db, kmph = _TDL[trace_id]
+    rng = np.random.default_rng([int(seed), 7, int(trace_id)])
+    fd = kmph / 3.6 * carrier_ghz * 1e9 / 299792458.0
+    t = np.arange(n_cols, dtype=np.float64) * 1e-3
+    f = (np.arange(n_rows, dtype=np.float64) - (n_rows - 1) / 2.0) * 180e3
+    p = 10.0 ** (np.asarray(powers_db) / 10.0)
+    p = p / p.sum()
+    h = np.zeros((n_rows, n_cols), dtype=np.complex128)
+    for tau, pw in zip(delays_ns, p):
+        # Jakes spectrum: n_osc arrivals with uniform angles, random phases (Zheng-Xiao style sum of sinusoids)
+        alpha = (2.0 * np.pi * np.arange(1, n_osc + 1) - np.pi + rng.uniform(-np.pi, np.pi)) / (4.0 * n_osc)
+        ph_i = rng.uniform(-np.pi, np.pi, n_osc)
+        ph_q = rng.uniform(-np.pi, np.pi, n_osc)
+        w = 2.0 * np.pi * fd * t[None, :]
+        gi = np.cos(w * np.cos(alpha)[:, None] + ph_i[:, None]).sum(axis=0)
+        gq = np.cos(w * np.sin(alpha)[:, None] + ph_q[:, None]).sum(axis=0)
+        g = (gi + 1j * gq) / np.sqrt(n_osc)          # E|g|^2 = 1
+        h += np.sqrt(pw) * np.exp(-2j * np.pi * f[:, None] * (tau * 1e-9)) * g[None, :]
+    power = h.real ** 2 + h.imag ** 2
+    db = np.round(10.0 * np.log10(np.maximum(power, 1e-12)), 4)
+    for c in nan_cols:
+        db[int(rng.integers(n_rows)), int(c)] = np.nan
+    return np.ascontiguousarray(db)
+
+
+PROFILES = {'sos': synth_fading, 'tdl': synth_fading_tdl}
+
+
+def synth_traces(n_cols, profile='sos', seed=20240):
+    """the three traces of SINRSelectiveFading from one of the seeded generators"""
+    return [PROFILES[profile](t, n_cols, seed=seed) for t in range(3)]
+
+
 def extend_rows(table, n_prbs):
     """Row extension used when the cell has more than 100 PRBs: wrap the first rows
     (reference channel_models.py:144-148)."""

@@ -119,3 +119,71 @@ def test_g11_results_schema(golden_dir):
     assert sorted(k[4:] for k in g.files) == sorted(want)
     for k, (dt, nd) in want.items():
         assert str(g['key_' + k].dtype) == dt and g['key_' + k].ndim == nd
+
+
+def check_kinv_digest(kinv, g, rtol):
+    """compare a Kinv with what the long fixtures keep of the reference's (every 16th row, the diagonal, Kinv @ four
+    probe vectors: tools/gen_golden_kbrl.py:_kinv_digest)"""
+    scale = np.abs(g['kinv_rows']).max()
+    np.testing.assert_allclose(kinv[::16], g['kinv_rows'], rtol=rtol, atol=rtol * scale)
+    np.testing.assert_allclose(np.diag(kinv), g['kinv_diag'], rtol=rtol, atol=rtol * scale)
+    kp = kinv @ g['kinv_probes']
+    np.testing.assert_allclose(kp, g['kinv_kp'], rtol=rtol, atol=rtol * np.abs(g['kinv_kp']).max())
+
+
+def test_g14_projectron_long(golden_dir):
+    """Projectron far past G9's sizes: 7,000 recorded samples that take the reference's dictionary to 790 landmarks,
+    with projections still happening above 600.  Tolerances as G9; the conditioning of Kinv degrades
+    with 1/delta, hence 1e-6 on its entries."""
+    g = _load(golden_dir, 'g14_projectron_long')
+    ag = po.OracleKBRL([10], 200, [10], [3], capacity=1024)
+    ag.set_tape(g['ties'])
+    xs, ys = g['x'], g['y']
+    worst_f = 0.0
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, xs[i])
+        fr = g['f'][i]
+        assert f == pytest.approx(fr, rel=1e-8, abs=TOL), i
+        worst_f = max(worst_f, abs(f - fr))
+        if abs(fr) > TOL:
+            assert yp == g['ypred'][i], i
+        br, dl = ag.update(0, xs[i], int(ys[i]))
+        assert br == g['branch'][i], i
+        if br:
+            assert dl == pytest.approx(g['delta'][i], rel=1e-7, abs=1e-9), i
+            assert abs(g['delta'][i] - ETA) > 1e-6
+        assert ag.m(0) == g['m'][i], i
+    m = ag.m(0)
+    assert m == len(g['landmarks']) and m > 600
+    assert ((g['branch'] == 1) & (g['m'] > 600)).sum() >= 20   # projections against a large dictionary are exercised
+    np.testing.assert_array_equal(ag.landmarks(0), g['landmarks'])
+    np.testing.assert_allclose(ag.coeff(0), g['coeff'], rtol=1e-7, atol=1e-8)
+    check_kinv_digest(ag.kinv(0), g, 1e-6)
+    assert ag.error() == 0
+
+
+def test_g15_kbrl_control_long(golden_dir):
+    """KBRL_Control teacher-forced over 2,200 recorded steps of scenario_0 (dictionaries of several hundred
+    landmarks): every hit, action, adjusted flag, margin, security factor and dictionary size of the reference"""
+    g = _load(golden_dir, 'g15_kbrl_long_s0')
+    dims, n_prbs = _dims(0)
+    ag = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']), capacity=2048)
+    ag.set_tape(g['ties'])
+    steps = len(g['state'])
+    assert steps >= 2000
+    for i in range(steps):
+        hits = ag.update_control(g['state'][i], g['action_in'][i], g['labels'][i])
+        assert (hits == g['hits'][i]).all(), i
+        nxt = g['state'][i + 1] if i + 1 < steps else g['final_state']
+        act, adj = ag.select_action(nxt)
+        ag.adjusted = adj
+        assert (act == g['action_out'][i]).all(), i
+        assert adj == g['adjusted'][i]
+        assert (ag.margins == g['margins'][i]).all() and (ag.security_factors == g['security'][i]).all(), i
+        sizes = [ag.set_size(s) if ag.m(s) else 0 for s in range(len(dims))]
+        assert sizes == list(g['set_size'][i]), i
+    np.testing.assert_allclose(ag.accuracies, g['acc'][-1], rtol=1e-12, atol=0)
+    for s in range(len(dims)):
+        np.testing.assert_array_equal(ag.landmarks(s), g['landmarks%d' % s])
+        np.testing.assert_allclose(ag.coeff(s), g['coeff%d' % s], rtol=1e-6, atol=1e-8)
+    assert max(ag.m(s) for s in range(len(dims))) >= 200 and ag.error() == 0

@@ -109,7 +109,88 @@ def _g11(rh, tape, save):
     save('g11_results_schema', **out)
 
 
+def _kinv_digest(kinv, seed=14):
+    """what the fixtures keep of a large Kinv: every 16th row, the diagonal and Kinv @ four fixed probe vectors (a
+    700 x 700 float64 matrix would be 4 MB per fixture)"""
+    kinv = np.atleast_2d(np.asarray(kinv, dtype=np.float64))
+    m = kinv.shape[0]
+    probes = np.random.default_rng(seed).standard_normal((m, 4))
+    return dict(rows=kinv[::16].copy(), diag=np.diag(kinv).copy(), probes=probes, kp=kinv @ probes)
+
+
+def _g14(rh, tape, save):
+    """G14: Projectron teacher-forced far past the sizes of G9 (m ~ 800): half of the samples revisit an earlier
+    state (exactly, or with a small perturbation) with a new action, as KBRL's sample augmentation does, so that
+    projections keep happening against a dictionary of several hundred landmarks"""
+    from algorithms.kernel import GaussianKernel
+    from algorithms.projectron import SVvariable, Projectron
+    spread, noise, n, d = 1.3, 0.12, 7000, 11
+    rng = np.random.default_rng(140)
+    np.random.seed(14)
+    tape.clear()
+    alg = Projectron(GaussianKernel(SVvariable(), 1))
+    xs, ys, fs, ypred, branch, delta, ms, states = [], [], [], [], [], [], [], []
+    for i in range(n):
+        if states and rng.random() < 0.5:
+            s = states[rng.integers(len(states))]
+            if rng.random() < 0.5:
+                s = (s + rng.normal(0, 0.02, d - 1)).astype(np.float32)
+        else:
+            s = (rng.random(d - 1) * spread).astype(np.float32)
+        states.append(s)
+        x = np.append(s, rng.integers(0, 201) / 200)
+        score = x[:-1].mean() * 0.8 / spread + 0.35 - x[-1]
+        y = -1 if score + rng.normal(0, noise) > 0 else 1
+        yp = alg.predict(x)
+        f = float(alg.f)
+        m0 = alg.counter
+        dl = np.nan
+        if alg.f * y <= 0:  # projectron.py:41-44 on the reference's arrays
+            d_star = alg.Kinv @ alg.K_f
+            if np.ndim(d_star) == 0:
+                d_star = np.array([d_star], dtype=np.float32)
+            dl = float(max(alg.kernel.k_eval(x, x) - d_star @ alg.K_f, 0))
+        alg.update(x, y)
+        br = 0 if not (f * y <= 0) else (2 if alg.counter > m0 else 1)
+        xs.append(x); ys.append(y); fs.append(f); ypred.append(int(yp)); branch.append(br)
+        delta.append(dl); ms.append(alg.counter)
+    kind, val = tape.arrays()
+    dg = _kinv_digest(alg.Kinv)
+    save('g14_projectron_long', x=np.asarray(xs), y=np.asarray(ys, dtype=np.int8), f=np.asarray(fs),
+         ypred=np.asarray(ypred, dtype=np.int8), branch=np.asarray(branch, dtype=np.int8), delta=np.asarray(delta),
+         m=np.asarray(ms, dtype=np.int32), ties=val, landmarks=np.atleast_2d(alg.sv.landmarks),
+         coeff=np.asarray(alg.sv.coeff, dtype=np.float64), kinv_rows=dg['rows'], kinv_diag=dg['diag'],
+         kinv_probes=dg['probes'], kinv_kp=dg['kp'])
+
+
+def _g15(rh, tape, save):
+    """G15: KBRL_Control teacher-forced over 2,200 steps of scenario_0 on 10,000-column tapped-delay-line traces
+    (ranslice.fading.synth_fading_tdl), the length at which dictionaries hold several hundred landmarks"""
+    import tempfile
+    from ranslice.fading import synth_traces
+    rh.setup(tempfile.mkdtemp(prefix='refwork_g15_'), synth_traces(10000, 'tdl'))
+    out = _run_agent(rh, tape, 0, seed=5, steps=2200, a_range=[0.99, 0.999])
+    for k in ('tape_kind', 'tape_val'):
+        pass
+    # only the tie-break draws of the agent are needed by the teacher-forced replay (the simulator is not replayed)
+    ties = out['tape_val'][out['tape_kind'] == 6]
+    drop = ('tape_kind', 'tape_val', 'reward')
+    out = {k: v for k, v in out.items() if k not in drop}
+    out['ties'] = ties
+    out['acc'] = out['acc'][-1:]          # the accuracy tables of the last step only
+    for k in ('action_in', 'labels', 'hits', 'action_out', 'margins', 'security', 'set_size', 'violation', 'adjusted'):
+        out[k] = out[k].astype(np.int16)
+    save('g15_kbrl_long_s0', **out)
+
+
 def generate(rh, tape, save):
     _g9(rh, tape, save)
     _g10(rh, tape, save)
     _g11(rh, tape, save)
+
+
+def generate_long(rh, tape, save, which):
+    if 'G14' in which:
+        _g14(rh, tape, save)
+    if 'G15' in which:
+        _g15(rh, tape, save)
