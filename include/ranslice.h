@@ -186,12 +186,14 @@ void rs_destroy(rs_handle* h);
  * algorithms/projectron.py:23-64, algorithms/kernel.py:3-34), one independent agent per replica.
  * ------------------------------------------------------------------------------------------ */
 #define KB_MAX_SLICES 8
+#define KB_CAPACITY_MAX 65536
 
 typedef struct kb_config {
     int32_t n_envs;               /* agents (one per env replica) */
     int32_t n_slices;             /* learners per agent */
     int32_t n_prbs;
-    int32_t capacity;             /* landmarks per learner (<= 1024) */
+    int32_t capacity;             /* most landmarks a dictionary may hold (<= KB_CAPACITY_MAX); storage is taken from the
+                                     pool 64 landmarks at a time as dictionaries grow, so this is a limit, not a reservation */
     int32_t dims[KB_MAX_SLICES];  /* state variables of learner s: 10 eMBB / 3 mMTC (scenario_creator.py:209-235) */
     double alfa;                  /* scenario_creator.py:187 */
     double acc_lo, acc_hi;        /* accuracy_range */
@@ -199,6 +201,10 @@ typedef struct kb_config {
     int32_t shared_dictionary;    /* 0: one agent per replica (the reference); 1: one dictionary per slice shared by all
                                      replicas (build-defined extension) */
     int32_t first_env;            /* shared mode: global id of this handle's replica 0 (rank * n_envs) */
+    int64_t pool_bytes;           /* device memory all dictionaries of the handle grow in (landmarks, coefficients, Kinv:
+                                     SVvariable / Projectron.Kinv, projectron.py:3-30, which the reference grows without
+                                     bound).  0: every dictionary at its capacity, or half of the free device memory,
+                                     whichever is smaller */
 } kb_config;
 
 typedef struct kb_handle kb_handle;
@@ -270,10 +276,13 @@ int kb_history_fetch(kb_handle* k, double* reward, int16_t* resources, int16_t* 
 int kb_get_stats(kb_handle* k, uint64_t stats[4]);
 /* landmarks in every dictionary: i32 [n_envs][S] (one agent per replica) or [S] (shared dictionaries) */
 int kb_get_sizes(kb_handle* k, int32_t* m);
+/* the dictionary pool: bytes in use / in total, replicas with a dictionary at its capacity, replicas that found the pool
+ * exhausted (both keep learning by projection -- build-defined, the reference's SVvariable is unbounded; any may be NULL) */
+int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_bytes, int32_t* n_saturated, int32_t* n_pool_full);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
 int kb_set_kernel_timing(kb_handle* k, int enable);
-/* waits for the agent's stream; returns RS_EOVERFLOW if any dictionary hit its capacity since kb_reset (the
- * device-resident loop kb_step_resident does not check on its own) */
+/* waits for the agent's stream and reports an internal error flag raised by any kernel since kb_reset (the
+ * device-resident loop kb_step_resident does not check on its own); dictionaries at capacity are not errors (kb_get_pool) */
 int kb_synchronize(kb_handle* k);
 
 #ifdef __cplusplus

@@ -29,7 +29,7 @@ class SVvariable:
 
 
 class Projectron:
-    def __init__(self, kernel, eta=0.1, capacity=1024):
+    def __init__(self, kernel, eta=0.1, capacity=4096):
         self.kernel = kernel
         self.sv = kernel.sv
         self.eta = eta

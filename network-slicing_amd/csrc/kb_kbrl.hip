@@ -1,20 +1,34 @@
-// kb_kbrl.hip -- the KBRL agent's kernel machinery on gfx950, batched over env replicas.
+// kb_kbrl.hip -- the KBRL agent's kernel machinery on gfx950, batched over env replicas (third version: round 3).
 //
 // What it computes (reference call tree):
 //   GaussianKernel.k / predict       algorithms/kernel.py:8-28
 //   Projectron.predict / update      algorithms/projectron.py:32-60
 //   KBRL_Control.select_action / adjust_action / update_control   kbrl_control.py:41-114
 //
-// One workgroup (4 waves) owns one learner = (replica, slice).  Both hot loops of the agent --
-// the augmentation loop of update_control and the linear scan of select_action -- evaluate the
-// classifier on candidates x_c = (state, c / n_prbs) that differ only in the last coordinate.
-// For landmark l_j:  ||l_j - x_c||^2 = D0_j + (lam_j - t_c)^2 = [D0_j + lam_j^2, -2 lam_j, 1] . [1, t_c, t_c^2]
-// so the [landmarks x candidates] distance block is a K=4 dense contraction: exactly one
-// v_mfma_f64_16x16x4_f64 per 16x16 tile.  exp() of the tile and the contraction with the
-// coefficient vector follow on the VALU (4 exps per lane per tile: this, not the MFMA, bounds
-// the kernel; DESIGN.md gives the flop model).  The reference's sequentially dependent loop
-// (predict, update, predict, ...) is reproduced exactly in order: score the whole remaining
-// range, find the first mistake, apply that one Projectron update, rescore what follows (H4).
+// Storage.  A dictionary (landmarks, coefficients, Kinv: SVvariable + Projectron.Kinv, projectron.py:3-30) lives in
+// a POOL shared by all dictionaries of the handle and grows 64 landmarks at a time, like the reference's np.vstack /
+// np.append / np.column_stack do one landmark at a time (projectron.py:17-21,52-57): when landmark 64 b arrives the
+// learner's own workgroup takes "shell" b from a bump allocator --
+//     [ vector page: 22 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
+//     [ 2 b + 1 tiles of 64 x 64 doubles  ]  Kinv tiles (b,0) .. (b,b), then (0,b) .. (b-1,b)
+// and records its pool offset in the dictionary's shell table.  Nothing is ever moved or freed before kb_reset, so
+// the capacity is bounded by the pool (device memory), not by a per-learner reservation: a handle of 4096 x 5
+// learners costs what its dictionaries hold (43 KB each while below 64 landmarks; round 2 reserved 8 MB each).
+//
+// Scoring.  Both hot loops of the agent -- the augmentation loop of update_control and the scan of select_action --
+// evaluate the classifier on candidates x_c = (state, c / n_prbs) that differ only in the last coordinate, and the
+// last coordinate of every landmark they ever inserted is itself a / n_prbs for an integer a.  So
+//     k(l_j, x_c) = exp(-g |l_j[:d-1] - state|^2) * exp(-g ((a_j - c) / n)^2) = E_j * G[|a_j - c|]
+// with ONE exp per landmark (E_j) and a 256-entry table G that depends on (gamma, n_prbs) only:
+//     f(c) = sum_j (coeff_j E_j) G[|a_j - c|]
+// One wavefront owns one learner; lane = candidate (c = 64 g + lane), landmarks stream through in 64-chunks
+// (coalesced rows of the vector pages), their (w_j, a_j) are broadcast with v_readlane and every lane walks the G
+// table in LDS at consecutive addresses (conflict-free).  Per (landmark, 64 candidates): one LDS read and one FMA
+// instead of 64 exps -- the round-2 form (one v_mfma_f64_16x16x4 distance tile + 256 exps) issued 6x more
+// instructions and could not leave the exp bound.  Landmarks with an off-grid last coordinate (inserted through the
+// N=1 Projectron.update entry point with an arbitrary x) take the direct exp, per landmark.
+// The reference's sequentially dependent loop (predict, update, predict, ...) is reproduced exactly in order: score
+// the whole remaining range, find the first mistake, apply that one Projectron update, rescore what follows (H4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -23,32 +37,48 @@
 
 namespace kb {
 
-#define KB_DMAX 16      // max len(x)
-#define KB_CAND_MAX 272 // n_prbs + 1 rounded up to 16 (n_prbs <= 256)
+#define KB_DMAX 16        // max len(x)
+#define KB_NPRB_MAX 255   // candidates 0..n_prbs fit four 64-lane groups
+#define KB_GTAB 264       // G[k], k = 0..255 (+ padding)
+#define KB_CH 64          // landmarks per chunk
+#define KB_TILE 4096      // doubles per Kinv tile
+#define KB_ROW_CO 16      // rows of a vector page (64 doubles each): 0..15 coordinates, then
+#define KB_ROW_D0 17      //   |l_j[:d-1] - state|^2 of the state being processed
+#define KB_ROW_E 18       //   exp(-gamma D0)
+#define KB_ROW_KF 19      //   kernel column K_f of the sample being learned (also Projectron's cached K_f, projectron.py:34)
+#define KB_ROW_DS 20      //   d* = Kinv K_f
+#define KB_ROW_IDX 21     //   64 x int32 grid index a_j of the last coordinate (-1: off the grid), 64 x int32 chain link
+#define KB_VEC_ROWS 22
+#define KB_VEC (KB_VEC_ROWS * KB_CH)
+#define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 
 typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
 
 struct KbDev {
     int32_t n_envs, S, n_prbs, cap, nv;
+    int32_t max_shells;  // shell-table entries per dictionary = ceil(cap / 64)
     int32_t dims[8];  // state variables per learner (len(x) = dims+1)
     int32_t off[8];   // first state variable of learner s
     double alfa, lo, hi, gamma, eta;
     int32_t shared;   // 1: one dictionary per slice shared by all replicas (build-defined extension)
     int32_t first_env; // global id of local replica 0 (shared mode proposals carry global ids)
     int32_t serial_apply; // shared mode: apply a full dictionary's proposals one by one as well (KBRL_SERIAL_APPLY, tests)
+    uint64_t pool_doubles;
 };
 
 // dictionary a learner (task = env * S + s) reads and writes
 __device__ __forceinline__ int dict_of(const KbDev& D, int task) { return D.shared ? task % D.S : task; }
 
 struct KbState {
-    int32_t* m;        // [T] landmarks per learner (T = n_envs * S)
-    double* L;         // [T][KB_DMAX][cap] landmarks, coordinate-major
-    double* coeff;     // [T][cap]
-    double* Kinv;      // [T][cap][cap]
-    double* kf;        // [T][cap]  K_f cached by the last predict (projectron.py:34)
+    int32_t* m;        // [ND] landmarks per dictionary
+    uint64_t* shell;   // [ND][max_shells] pool offset (in doubles) of shell b; 0 = not allocated yet
+    int32_t* head;     // [ND][KB_HEAD] newest landmark with grid index a (-1 none)
+    double* pool;      // the pool
+    unsigned long long* pool_top;  // [1] next free double
+    double* gtab;      // [KB_GTAB] G[k] = exp(-gamma (k / n_prbs)^2)
     double* f_last;    // [T]
-    int32_t* m_last;   // [T] dictionary size the cached (f_last, kf) was computed against (Q12 guard)
+    int32_t* m_last;   // [T] dictionary size the cached (f_last, K_f row) was computed against (Q12 guard)
+    int32_t* kf_owner; // [ND] task whose predict filled the dictionary's K_f row
     uint32_t* tie_ctr; // [T] Philox counter of the tie-break stream (kernel.py:26-27)
     uint64_t* seeds;   // [n_envs]
     int32_t* action;   // [n_envs][S]
@@ -56,11 +86,38 @@ struct KbState {
     int32_t* margins;  // [n_envs][S]
     int32_t* adjusted; // [n_envs]
     double* acc;       // [n_envs][S][n_prbs]
-    int32_t* err;      // [n_envs]
+    int32_t* err;      // [n_envs]  bit 8: a dictionary is at its capacity, bit 16: the pool is exhausted
     uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
-    double* work;      // [blocks][2][cap rounded up to 16] per-block columns of an update in progress (kf, d*)
-    double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 16] kernel columns and d* of a proposal list
+    double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
 };
+
+__host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
+__host__ __device__ inline uint64_t kb_shell_doubles(int b) { return (uint64_t)KB_VEC + (uint64_t)(2 * b + 1) * KB_TILE; }
+
+__device__ __forceinline__ const uint64_t* shells_of(const KbDev& D, const KbState& K, int dict) {
+    return K.shell + (size_t)dict * D.max_shells;
+}
+__device__ __forceinline__ double* vec_page(const KbState& K, const uint64_t* sh, int b) { return K.pool + sh[b]; }
+// tile holding Kinv[i][j] for i in row block bi, j in column block bj (row-major 64 x 64)
+__device__ __forceinline__ double* kinv_tile(const KbState& K, const uint64_t* sh, int bi, int bj) {
+    return bj <= bi ? K.pool + sh[bi] + KB_VEC + (size_t)bj * KB_TILE
+                    : K.pool + sh[bj] + KB_VEC + (size_t)(bj + 1 + bi) * KB_TILE;
+}
+// element j of row `row` of the dictionary's vector pages
+__device__ __forceinline__ double* vec_at(const KbState& K, const uint64_t* sh, int row, int j) {
+    return vec_page(K, sh, j >> 6) + row * KB_CH + (j & 63);
+}
+__device__ __forceinline__ int32_t* idx_at(const KbState& K, const uint64_t* sh, int j) {
+    return (int32_t*)(vec_page(K, sh, j >> 6) + KB_ROW_IDX * KB_CH) + (j & 63);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
 
 __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int s) {
     uint64_t seed = K.seeds[env];
@@ -70,47 +127,27 @@ __device__ __forceinline__ int tie_draw(const KbState& K, int task, int env, int
     return v;
 }
 
-// Working set of one learner.  Three columns live in LDS (carved out of dynamic shared memory by capacity: 27 KB at
-// capacity 1024, so five blocks stay resident per CU; the MFMA operands D0 + lam^2 and -2 lam are formed from them on
-// the fly).  The two columns of an update in progress (kernel column, d* = Kinv k_f) are touched by the one learner
-// in ten that updates in a step: they sit in a per-block row of global memory (KbState.work) behind the same
-// pointers.
+// grid index of a last coordinate t: a with (double)a / n == t exactly, else -1
+__device__ __forceinline__ int grid_index(double t, int n) {
+    const double r = __builtin_rint(t * (double)n);
+    if (!(r >= 0.0 && r <= (double)n)) return -1;
+    const int a = (int)r;
+    return (double)a / (double)n == t ? a : -1;
+}
+
+// small per-block staging area (static LDS; nothing in these kernels scales with the capacity)
 struct Lds {
-    double* lam;  // lam_j (last coordinate of the landmark)
-    double* d0;   // D0_j
-    double* co;   // coeff_j
-    double* kf;   // kernel column of the candidate being updated   (global, per block)
-    double* ds;   // d* = Kinv k_f                                   (global, per block)
-    double* f;    // [KB_CAND_MAX]
-    double* x;    // [KB_DMAX]
-    double* red;  // [16]
-    int* ired;    // [8]
-    int capr;     // column length (capacity rounded up to 16)
+    double G[KB_GTAB];
+    double x[KB_DMAX];
+    double red[16];
+    int ired[8];
 };
 
-__host__ __device__ inline int kb_capr(int cap) { return (cap + 15) & ~15; }
-__host__ __device__ inline size_t kb_lds_bytes(int cap) {
-    return ((size_t)3 * kb_capr(cap) + KB_CAND_MAX + KB_DMAX + 16) * sizeof(double) + 8 * sizeof(int);
+__device__ __forceinline__ void load_gtab(const KbState& K, Lds& sm) {
+    for (int k = threadIdx.x; k < KB_GTAB; k += blockDim.x) sm.G[k] = K.gtab[k];
 }
 
-__device__ __forceinline__ Lds carve_lds(int cap, double* work) {
-    extern __shared__ double kb_dyn_lds[];
-    Lds sm;
-    const int c = kb_capr(cap);
-    double* p = kb_dyn_lds;
-    sm.lam = p; p += c;
-    sm.d0 = p; p += c;
-    sm.co = p; p += c;
-    sm.f = p; p += KB_CAND_MAX;
-    sm.x = p; p += KB_DMAX;
-    sm.red = p; p += 16;
-    sm.ired = (int*)p;
-    sm.kf = work + (size_t)blockIdx.x * 2 * c;
-    sm.ds = sm.kf + c;
-    sm.capr = c;
-    return sm;
-}
-
+// sum over the block, any block size that is a multiple of 64: butterfly per wave, wave totals in order
 __device__ __forceinline__ double block_sum(double v, Lds& sm) {
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     __syncthreads();
@@ -118,196 +155,395 @@ __device__ __forceinline__ double block_sum(double v, Lds& sm) {
     __syncthreads();
     double t = 0.0;
     for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm.red[w];
+    __syncthreads();
     return t;
 }
 
-// D0_j, lam_j and the MFMA operands for the current state (first d-1 coordinates in sm.x)
-__device__ void prepare_operands(const KbDev& D, const KbState& K, int dict, int m, int d, Lds& sm) {
-    const int cap = D.cap;
-    const double* L = K.L + (size_t)dict * KB_DMAX * cap;
-    // entries beyond the dictionary must read as zero coefficients up to the end of the last 16-landmark tile
-    // (apply_update clears a new tile when the dictionary grows into it)
-    int lim = (m + 16) & ~15;
-    lim = lim < sm.capr ? lim : sm.capr;
-    for (int j = threadIdx.x; j < lim; j += blockDim.x) {
-        double d0 = 0.0, lam = 0.0, co = 0.0;
-        if (j < m) {
-            for (int q = 0; q < d - 1; ++q) {
-                double t = L[(size_t)q * cap + j] - sm.x[q];
-                d0 += t * t;
-            }
-            lam = L[(size_t)(d - 1) * cap + j];
-            co = K.coeff[(size_t)dict * cap + j];
-        }
-        sm.d0[j] = d0;
-        sm.lam[j] = lam;
-        sm.co[j] = co;
-    }
-    __syncthreads();
-}
-
-// f(c) for c in [c_lo, c_hi] -> sm.f[c]; one wave per 16-candidate strip, MFMA distance tiles
-__device__ void score_range(const KbDev& D, int m, int c_lo, int c_hi, Lds& sm) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const double inv_n = 1.0;  // t_c = c / n_prbs computed below with a true division
-    (void)inv_n;
-    if (m == 0) {
-        for (int c = c_lo + (int)threadIdx.x; c <= c_hi; c += blockDim.x) sm.f[c] = 0.0;
-        __syncthreads();
-        return;
-    }
-    if (m == 1) {
-        // single landmark: numpy keeps k and coeff in float32 (kernel.py:16, projectron.py:9)
-        for (int c = c_lo + (int)threadIdx.x; c <= c_hi; c += blockDim.x) {
-            double t = (double)c / (double)D.n_prbs;
-            double dl = sm.lam[0] - t;
-            double k = rs_exp(-D.gamma * (sm.d0[0] + dl * dl));
-            sm.f[c] = (double)(float)((float)k * (float)sm.co[0]);
-        }
-        __syncthreads();
-        return;
-    }
-    const int n_strips = (c_hi - c_lo) / 16 + 1;
-    const int mt = (m + 15) / 16;
-    const int kq = lane >> 4, li = lane & 15;
-    for (int strip = wave; strip < n_strips; strip += nw) {
-        const int c = c_lo + strip * 16 + li;
-        const double t = (double)c / (double)D.n_prbs;
-        // B[k][cand]: (1, t, t^2, 0)
-        const double bval = kq == 0 ? 1.0 : (kq == 1 ? t : (kq == 2 ? t * t : 0.0));
-        double part = 0.0;
-        for (int jt = 0; jt < mt; ++jt) {
-            const int j = jt * 16 + li;
-            // A[landmark][k]: (D0 + lam^2, -2 lam, 1, 0)
-            const double lam_j = sm.lam[j];
-            const double aval = kq == 0 ? sm.d0[j] + lam_j * lam_j : (kq == 1 ? -2.0 * lam_j : (kq == 2 ? 1.0 : 0.0));
-            kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aval, bval, acc, 0, 0, 0);
-            // lane holds dist[landmark = kq + 4 r][cand = li]
+// Sum_j a[j] b[j] over two rows of the vector pages, formed as 256 strided partial sums (j = t, t + 256, ...), the xor
+// butterfly within each group of 64, and the four group totals in order -- by ONE wave, whatever the block size, so that
+// every kernel (64-thread per-replica learners, 256-thread entry points, 1024-thread shared apply) gets the same bits.
+// All lanes of the calling wave return the value.
+__device__ __forceinline__ double wave_dot256_rows(const KbState& K, const uint64_t* sh, int row_a, int row_b, int m) {
+    const int lane = threadIdx.x & 63;
+    double part[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int jj = jt * 16 + kq + 4 * r;
-                double dist = acc[r] > 0.0 ? acc[r] : 0.0;
-                part += rs_exp_nonpos(-D.gamma * dist) * sm.co[jj];  // dist >= 0: branch-free, the 4 chains interleave
+    for (int v = 0; v < 4; ++v) {
+        part[v] = 0.0;
+        for (int j = 64 * v + lane; j < m; j += 256) {
+            const double* P = vec_page(K, sh, j >> 6);
+            part[v] += P[row_a * KB_CH + lane] * P[row_b * KB_CH + lane];
+        }
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) {  // four independent butterflies, stepped together
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t += __shfl(part[v], 0);
+    return t;
+}
+// the same sum over two plain arrays
+__device__ __forceinline__ double wave_dot256(const double* a, const double* b, int m) {
+    const int lane = threadIdx.x & 63;
+    double part[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        part[v] = 0.0;
+        for (int j = 64 * v + lane; j < m; j += 256) part[v] += a[j] * b[j];
+    }
+    for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
+    }
+    double t = 0.0;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t += __shfl(part[v], 0);
+    return t;
+}
+
+// |l_j[:d-1] - x|^2 for the landmark this lane holds in page P, summed in coordinate order
+__device__ __forceinline__ double dist0(const double* P, int lane, int d, const double* x) {
+    double d0 = 0.0;
+    if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82): all ten loads in flight
+        double v[10];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) v[q] = P[q * KB_CH + lane];
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+            const double t = v[q] - x[q];
+            d0 += t * t;
+        }
+    } else {
+        for (int q = 0; q < d - 1; ++q) {
+            const double t = P[q * KB_CH + lane] - x[q];
+            d0 += t * t;
+        }
+    }
+    return d0;
+}
+
+// ---------------------------------------------------------------------------------------------- streaming scoring
+// f[g] = f(c) for c = 64 (g0 + g) + lane, g < NG, against the m landmarks of the dictionary, by ONE wave.
+// MODE 0: compute D0 / E for the state in sm.x and keep them in the dictionary's rows (the learner owns its dictionary)
+// MODE 1: reuse the E row (same state, coefficients may have changed)
+// MODE 2: compute E, store nothing (shared dictionaries: many learners read the same pages)
+template <int NG, int MODE>
+__device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm,
+                                           int g0, double (&f)[NG]) {
+    const int lane = threadIdx.x & 63;
+    int cb[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        cb[g] = (64 * (g0 + g) + lane) * 8;
+        f[g] = 0.0;
+    }
+    const int nch = (m + 63) >> 6;
+    const char* Gb = (const char*)sm.G;
+    for (int b = 0; b < nch; ++b) {
+        double* P = vec_page(K, sh, b);
+        const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
+        double E;
+        if (MODE == 1) {
+            E = P[KB_ROW_E * KB_CH + lane];
+        } else {
+            const double d0 = dist0(P, lane, d, sm.x);
+            E = rs_exp_nonpos(-D.gamma * d0);
+            if (MODE == 0) {
+                P[KB_ROW_D0 * KB_CH + lane] = d0;
+                P[KB_ROW_E * KB_CH + lane] = E;
             }
         }
-        part += __shfl_xor(part, 16);
-        part += __shfl_xor(part, 32);
-        if (kq == 0 && c <= c_hi) sm.f[c] = part;
+        const double co = P[KB_ROW_CO * KB_CH + lane];
+        const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
+        const double lam = P[(d - 1) * KB_CH + lane];
+        const double w = lane < cnt ? co * E : 0.0;
+        const int a8 = lane < cnt ? a * 8 : 0;
+        // lanes past the end of the dictionary carry w = 0 on the grid: the loop may run to the next multiple of four
+        for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int jj = jj0 + u;
+                const double ws = readlane_f64(w, jj);
+                const int as8 = __builtin_amdgcn_readlane(a8, jj);
+                if (as8 >= 0) {
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        int o = as8 - cb[g];
+                        o = o < 0 ? -o : o;
+                        f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
+                    }
+                } else {  // off-grid last coordinate: the exp itself
+                    const double ls = readlane_f64(lam, jj);
+#pragma unroll
+                    for (int g = 0; g < NG; ++g) {
+                        const double dl = ls - (double)(cb[g] >> 3) / (double)D.n_prbs;
+                        f[g] = __builtin_fma(ws, rs_exp_nonpos(-D.gamma * (dl * dl)), f[g]);
+                    }
+                }
+            }
+        }
     }
-    __syncthreads();
 }
 
-// kernel column of candidate c against the dictionary -> sm.kf (exact (lam - t)^2 form)
-__device__ void kernel_column(const KbDev& D, int m, int c, Lds& sm) {
-    const double t = (double)c / (double)D.n_prbs;
+// the single-landmark dictionary: numpy keeps k and coeff in float32 (kernel.py:16, projectron.py:9)
+template <int NG, int MODE>
+__device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, const uint64_t* sh, int d, const Lds& sm, int g0,
+                                             double (&f)[NG]) {
+    const int lane = threadIdx.x & 63;
+    double* P = vec_page(K, sh, 0);
+    double d0 = 0.0;
+    for (int q = 0; q < d - 1; ++q) {
+        const double t = P[q * KB_CH] - sm.x[q];
+        d0 += t * t;
+    }
+    if (MODE == 0 && lane == 0) {
+        P[KB_ROW_D0 * KB_CH] = d0;
+        P[KB_ROW_E * KB_CH] = rs_exp_nonpos(-D.gamma * d0);
+    }
+    const double lam = P[(d - 1) * KB_CH], co = P[KB_ROW_CO * KB_CH];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double t = (double)(64 * (g0 + g) + lane) / (double)D.n_prbs;
+        const double dl = lam - t;
+        const double k = rs_exp(-D.gamma * (d0 + dl * dl));
+        f[g] = (double)(float)((float)k * (float)co);
+    }
+}
+
+template <int NG, int MODE>
+__device__ __forceinline__ void score(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm, int g0,
+                                      double (&f)[NG]) {
+    if (m == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) f[g] = 0.0;
+    } else if (m == 1) {
+        score_single<NG, MODE>(D, K, sh, d, sm, g0, f);
+    } else {
+        score_pass<NG, MODE>(D, K, sh, m, d, sm, g0, f);
+    }
+}
+
+// f of candidate c out of the four group registers (c's lane holds it): broadcast to the wave
+__device__ __forceinline__ double f_of(const double (&f)[4], int c) {
+    const int g = c >> 6, l = c & 63;
+    double v = g == 0 ? f[0] : (g == 1 ? f[1] : (g == 2 ? f[2] : f[3]));
+    return readlane_f64(v, l);
+}
+
+// first candidate c in [c_from, c_to] (in order) with f(c) * y <= 0, or -1; *zeros = candidates with f == 0 among
+// [c_from, min(c_to, found)]
+__device__ __forceinline__ int first_mistake(const double (&f)[4], int y, int c_from, int c_to, int* zeros) {
+    const int lane = threadIdx.x & 63;
+    int found = -1, nz = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int c = 64 * g + lane;
+        const bool in = c >= c_from && c <= c_to;
+        const unsigned long long bad = __ballot(in && f[g] * (double)y <= 0.0);
+        const unsigned long long zer = __ballot(in && f[g] == 0.0);
+        if (found < 0) {
+            if (bad) {
+                const int l = __builtin_ctzll(bad);
+                found = 64 * g + l;
+                nz += __builtin_popcountll(zer & ((l == 63) ? ~0ull : ((2ull << l) - 1ull)));
+            } else {
+                nz += __builtin_popcountll(zer);
+            }
+        }
+    }
+    *zeros = nz;
+    return found;
+}
+
+// ------------------------------------------------------------------------------------------ Projectron.update pieces
+// kernel column of x = (state the D0 row was computed for, t) against the dictionary -> K_f row, in the exact form
+// exp(-gamma (D0 + (lam - t)^2)) (kernel.py:18-19)
+__device__ __forceinline__ void kernel_column_from_d0(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, double t) {
     for (int j = threadIdx.x; j < m; j += blockDim.x) {
-        double dl = sm.lam[j] - t;
-        double k = rs_exp(-D.gamma * (sm.d0[j] + dl * dl));
-        sm.kf[j] = m == 1 ? (double)(float)k : k;
+        double* P = vec_page(K, sh, j >> 6);
+        const int l = j & 63;
+        const double dl = P[(d - 1) * KB_CH + l] - t;
+        const double k = rs_exp(-D.gamma * (P[KB_ROW_D0 * KB_CH + l] + dl * dl));
+        P[KB_ROW_KF * KB_CH + l] = m == 1 ? (double)(float)k : k;
+    }
+    __syncthreads();
+}
+// the same for an arbitrary x (all d coordinates given): D0 is formed in the same coordinate order
+__device__ __forceinline__ void kernel_column_full(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d,
+                                                   const double* x, double t) {
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        double* P = vec_page(K, sh, j >> 6);
+        const int l = j & 63;
+        double d0 = 0.0;
+        for (int q = 0; q < d - 1; ++q) {
+            const double u = P[q * KB_CH + l] - x[q];
+            d0 += u * u;
+        }
+        const double dl = P[(d - 1) * KB_CH + l] - t;
+        const double k = rs_exp(-D.gamma * (d0 + dl * dl));
+        P[KB_ROW_KF * KB_CH + l] = m == 1 ? (double)(float)k : k;
     }
     __syncthreads();
 }
 
-// Projectron.update (projectron.py:39-60) for x = (sm.x[0..d-2], t_last), given its kernel column in sm.kf.
-// Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.
-// R: rows of Kinv per pass of the mat-vec (their loads stay in flight together; the 1024-thread shared apply uses 8,
-// the per-replica kernels 1 -- more would cost them registers they need for residency)
-template <int R = 1>
-__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, double t_last, int y,
-                            Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
-    const int cap = D.cap;
-    double* Kinv = K.Kinv + (size_t)dict * cap * cap;
-    double* coeffg = K.coeff + (size_t)dict * cap;
+// d* = Kinv K_f -> DS row.  Kinv is symmetric bit for bit (it only ever receives (d_i d_j) / delta), so the thread that
+// owns output i walks COLUMN i: rows j = 0, 1, ... of the tiles (b_j, b_i), coalesced across the threads of a wave, one
+// sequential sum per output and no cross-lane reduction.  The order does not depend on the block size.
+__device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* sh, int m) {
+    const int nb = (m + 63) >> 6, nt = blockDim.x, lane = threadIdx.x & 63;
+    for (int i0 = threadIdx.x; i0 < nb * 64; i0 += nt * 4) {
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        int bi[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bi[k] = (i0 + k * nt) >> 6;  // wave-uniform
+        for (int bj = 0; bj < nb; ++bj) {
+            const int rows = m - 64 * bj < 64 ? m - 64 * bj : 64;
+            const double kfv = vec_page(K, sh, bj)[KB_ROW_KF * KB_CH + lane];
+            const double* tp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tp[k] = kinv_tile(K, sh, bj, bi[k] < nb ? bi[k] : 0) + lane;
+            for (int r0 = 0; r0 < rows; r0 += 4) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + u;
+                    if (r < rows) {
+                        const double kfr = readlane_f64(kfv, r);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (bi[k] < nb) acc[k] = __builtin_fma(tp[k][r * 64], kfr, acc[k]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * nt;
+            if (i < m) *vec_at(K, sh, KB_ROW_DS, i) = acc[k];
+        }
+    }
+    __syncthreads();
+}
+
+// take shell b for the dictionary (thread 0; everybody learns the outcome).  false: capacity or pool exhausted.
+__device__ __forceinline__ bool take_shell(const KbDev& D, const KbState& K, int dict, int b, Lds& sm) {
+    if (threadIdx.x == 0) {
+        int ok = 0;
+        if (b < D.max_shells) {
+            const unsigned long long need = kb_shell_doubles(b);
+            const unsigned long long at = atomicAdd(K.pool_top, need);
+            if (at + need <= D.pool_doubles) {
+                K.shell[(size_t)dict * D.max_shells + b] = at;
+                ok = 1;
+            }
+        }
+        sm.ired[6] = ok;
+    }
+    __syncthreads();
+    const bool ok = sm.ired[6] != 0;
+    __syncthreads();
+    return ok;
+}
+
+// Projectron.update (projectron.py:39-60) for x = (x[0..d-2], t_last) whose kernel column is in the K_f row.
+// Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.  Runs on the whole block (64,
+// 256 or 1024 threads); every sum is formed in an order that does not depend on the block size.
+__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, const double* x, double t_last,
+                            int a_last, int y, Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
+    const uint64_t* sh = shells_of(D, K, dict);
     double dot;
     if (m <= 1) {
         float kinv = m == 0 ? 0.0f : 1.0f;
-        float ds = kinv * (float)(m == 0 ? 0.0 : sm.kf[0]);
-        if (threadIdx.x == 0) sm.ds[0] = (double)ds;
-        dot = (double)(float)(ds * (float)(m == 0 ? 0.0 : sm.kf[0]));
+        const float kf0 = m == 0 ? 0.0f : (float)*vec_at(K, sh, KB_ROW_KF, 0);
+        float ds = kinv * kf0;
+        __syncthreads();
+        if (threadIdx.x == 0 && m == 1) *vec_at(K, sh, KB_ROW_DS, 0) = (double)ds;
+        dot = (double)(float)(ds * kf0);
         __syncthreads();
     } else {
-        // d* = Kinv k_f: one row per wave-strided lane group (rows are contiguous -> coalesced)
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        // (eight rows per pass: their loads are independent and stay in flight together; each row's sum is formed
-        // exactly as before -- lane-strided partial sums in increasing j, then the xor butterfly)
-        for (int i0 = wave; i0 < m; i0 += nw * R) {
-            double a[R];
-#pragma unroll
-            for (int r = 0; r < R; ++r) a[r] = 0.0;
-            for (int j = lane; j < m; j += 64) {
-                const double kfj = sm.kf[j];
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = i0 + r * nw;
-                    const double kv = Kinv[(size_t)(i < m ? i : i0) * cap + j];
-                    if (i < m) a[r] += kv * kfj;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
-                double v = a[r];
-                for (int dd = 32; dd >= 1; dd >>= 1) v += __shfl_xor(v, dd);
-                const int i = i0 + r * nw;
-                if (lane == 0 && i < m) sm.ds[i] = v;
-            }
+        matvec_colsum(K, sh, m);
+        if (threadIdx.x < 64) {
+            const double v = wave_dot256_rows(K, sh, KB_ROW_DS, KB_ROW_KF, m);
+            if (threadIdx.x == 0) sm.red[15] = v;
         }
         __syncthreads();
-        // 256 strided partial sums whatever the block size (the shared-dictionary kernel runs 1024 threads and must
-        // produce the bits of the 256-thread per-replica kernels); waves beyond the fourth add exact zeros
-        double p = 0.0;
-        if (threadIdx.x < 256)
-            for (int j = threadIdx.x; j < m; j += 256) p += sm.ds[j] * sm.kf[j];
-        dot = block_sum(p, sm);
+        dot = sm.red[15];
+        __syncthreads();
     }
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
     delta = delta > 0.0 ? delta : 0.0;
     *delta_out = delta;
-    // A dictionary that has reached its capacity projects every further sample onto its span (the fixed-budget
-    // reading of Projectron) instead of growing as the reference's unbounded SVvariable would: learning goes on,
-    // nothing is dropped, and the replica is flagged (err bit 8, "saturated": reported by kb_get_sizes == capacity
-    // and by the host classes as a warning, not as an error).
-    const bool full = m >= cap;
+    // A dictionary that cannot grow (capacity reached, or the pool has no shell left) projects every further sample
+    // onto its span -- the fixed-budget reading of Projectron -- instead of growing as the reference's unbounded
+    // SVvariable would: learning goes on, nothing is dropped, and the replica is flagged (err bit 8 "saturated", bit 16
+    // "pool exhausted": reported by kb_get_sizes / kb_get_pool and by the host classes as a warning).
+    bool full = m >= D.cap;
+    if (delta > D.eta && !full && (m & 63) == 0) {
+        if (!take_shell(D, K, dict, m >> 6, sm)) {
+            full = true;
+            if (threadIdx.x == 0) atomicOr(&K.err[err_env], 16);
+        }
+    }
     if (delta > D.eta && full && threadIdx.x == 0) atomicOr(&K.err[err_env], 8);
     if (saturated) *saturated = delta > D.eta && full;
     if (delta <= D.eta || full) {
         *branch = 1;
         for (int j = threadIdx.x; j < m; j += blockDim.x) {
-            double nc = sm.co[j] + (double)y * sm.ds[j];
+            double* P = vec_page(K, sh, j >> 6);
+            const int l = j & 63;
+            double nc = P[KB_ROW_CO * KB_CH + l] + (double)y * P[KB_ROW_DS * KB_CH + l];
             if (m == 1) nc = (double)(float)nc;
-            sm.co[j] = nc;
-            coeffg[j] = nc;
+            P[KB_ROW_CO * KB_CH + l] = nc;
         }
         __syncthreads();
         return m;
     }
     *branch = 2;
     // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
-    double* L = K.L + (size_t)dict * KB_DMAX * cap;
-    const double t = t_last;
-    if ((m & 15) == 15 && threadIdx.x < 16 && m + 1 + (int)threadIdx.x < sm.capr) {
-        // the landmark after this one opens a new 16-landmark tile: make it read as empty
-        const int j = m + 1 + threadIdx.x;
-        sm.d0[j] = 0.0; sm.lam[j] = 0.0; sm.co[j] = 0.0;
-    }
-    if (threadIdx.x == 0) {
-        for (int q = 0; q < d - 1; ++q) L[(size_t)q * cap + m] = sm.x[q];
-        L[(size_t)(d - 1) * cap + m] = t;
-        coeffg[m] = (double)y;
-        sm.co[m] = (double)y;
-        sm.d0[m] = 0.0;  // the new landmark shares the current state
-        sm.lam[m] = t;
-        sm.ds[m] = -1.0;
+    {
+        double* P = vec_page(K, sh, m >> 6);
+        const int l = m & 63;
+        if ((int)threadIdx.x < d - 1) P[threadIdx.x * KB_CH + l] = x[threadIdx.x];
+        if (threadIdx.x == 0) {
+            P[(d - 1) * KB_CH + l] = t_last;
+            P[KB_ROW_CO * KB_CH + l] = (double)y;
+            P[KB_ROW_D0 * KB_CH + l] = 0.0;  // the new landmark shares the state being processed
+            P[KB_ROW_E * KB_CH + l] = 1.0;
+            P[KB_ROW_DS * KB_CH + l] = -1.0;
+            int32_t* ix = (int32_t*)(P + KB_ROW_IDX * KB_CH);
+            ix[l] = a_last;
+            if (a_last >= 0) {  // chain of the landmarks with this grid index, newest first
+                int32_t* hd = K.head + (size_t)dict * KB_HEAD;
+                ix[64 + l] = hd[a_last];
+                hd[a_last] = m;
+            } else {
+                ix[64 + l] = -1;
+            }
+        }
     }
     __syncthreads();
     if (m == 0) {
-        if (threadIdx.x == 0) Kinv[0] = 1.0;
+        if (threadIdx.x == 0) kinv_tile(K, sh, 0, 0)[0] = 1.0;
     } else {
-        const int m1 = m + 1;
-        for (int e = threadIdx.x; e < m1 * m1; e += blockDim.x) {
-            const int i = e / m1, j = e - i * m1;
-            double old = (i < m && j < m) ? Kinv[(size_t)i * cap + j] : 0.0;
-            Kinv[(size_t)i * cap + j] = old + (sm.ds[i] * sm.ds[j]) / delta;
+        const int m1 = m + 1, nb = (m1 + 63) >> 6;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+        const double inv = 1.0 / delta;
+        // one tile row per wave per step: d_i broadcast from the row block's lanes, d_j in this lane
+        for (int tb = 0; tb < nb * nb; ++tb) {
+            const int bi = tb / nb, bj = tb - bi * nb;
+            double* T = kinv_tile(K, sh, bi, bj);
+            const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
+            const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
+            const int j = 64 * bj + lane;
+            const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
+            for (int r = wave; r < rows; r += nw) {
+                const int i = 64 * bi + r;
+                const double dsi = readlane_f64(dsi_v, r);
+                if (j < m1) {
+                    const double old = (i < m && j < m) ? T[r * 64 + lane] : 0.0;
+                    T[r * 64 + lane] = old + (dsi * dsj) * inv;
+                }
+            }
         }
     }
     __syncthreads();
@@ -323,129 +559,126 @@ struct CtlArgs {
     int32_t* hits;          // [n_envs][S]
 };
 
-// KBRL_Control.update_control for one learner (kbrl_control.py:83-112)
-__global__ __launch_bounds__(256, 5) void update_control_kernel(CtlArgs A) {
+// y_pred of update_control's first predict, the accuracy table and the security factor (kbrl_control.py:88-101)
+__device__ __forceinline__ int control_bookkeeping(const KbDev& D, const KbState& K, int task, int env, int s, int m, double f0, int y,
+                                                   int32_t* hits, Lds& sm) {
+    const int n = D.n_prbs;
+    int y_pred = 0;
+    if (m > 0) {
+        y_pred = f0 > 0.0 ? 1 : (f0 < 0.0 ? -1 : 0);
+        if (y_pred == 0) {
+            if (threadIdx.x == 0) sm.ired[0] = tie_draw(K, task, env, s);
+            __syncthreads();
+            y_pred = sm.ired[0];
+            __syncthreads();
+        }
+    }
+    const int hit = y == y_pred;
+    int margin = K.margins[env * D.S + s];
+    margin = margin > 0 ? margin : 0;
+    double* acc = K.acc + ((size_t)env * D.S + s) * n;
+    if (y_pred == 1) {
+        for (int c = threadIdx.x; c < n; c += blockDim.x) {
+            if (!hit) {
+                if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
+            } else {
+                if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
+            }
+        }
+    }
+    __syncthreads();
+    if (!K.adjusted[env]) {
+        if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
+        __syncthreads();
+        int first = 0x7fffffff;
+        for (int c = threadIdx.x; c < n; c += blockDim.x)
+            if (acc[c] > D.lo) { first = c; break; }
+        if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
+        __syncthreads();
+        if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
+    }
+    if (threadIdx.x == 0) hits[env * D.S + s] = hit;
+    return hit;
+}
+
+__device__ __forceinline__ void stage_state(const KbDev& D, const float* state, int env, int s, int d, Lds& sm) {
+    if ((int)threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+}
+
+// KBRL_Control.update_control for one learner (kbrl_control.py:83-112): one wave
+__global__ __launch_bounds__(64) void update_control_kernel(CtlArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    Lds sm = carve_lds(D.cap, K.work);
+    __shared__ Lds sm;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
+    const uint64_t* sh = shells_of(D, K, dict);
     int m = K.m[dict];
-    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    load_gtab(K, sm);
+    stage_state(D, A.state, env, s, d, sm);
     __syncthreads();
-    prepare_operands(D, K, dict, m, d, sm);
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
     uint64_t n_pred = 0, n_mist = 0, n_grow = 0, n_eval = 0;
 
-    // ---- y_pred = predict((state, a_i / n)) (kbrl_control.py:88-89)
-    score_range(D, m, a_i, a_i, sm);
+    // ---- the classifier on every candidate of this state (the augmentation range contains a_i)
+    double f[4];
+    score<4, 0>(D, K, sh, m, d, sm, 0, f);
     n_pred += 1;
     n_eval += (uint64_t)m;
-    int y_pred = 0;
-    {
-        double f0 = sm.f[a_i];
-        if (m > 0) {
-            y_pred = f0 > 0.0 ? 1 : (f0 < 0.0 ? -1 : 0);
-            if (y_pred == 0) {
-                if (threadIdx.x == 0) sm.ired[0] = tie_draw(K, task, env, s);
-                __syncthreads();
-                y_pred = sm.ired[0];
-                __syncthreads();
-            }
-        }
-    }
-    const int hit = y == y_pred;
-    // ---- accuracy table and security factor (kbrl_control.py:92-99)
-    {
-        int margin = K.margins[env * D.S + s];
-        margin = margin > 0 ? margin : 0;
-        double* acc = K.acc + ((size_t)env * D.S + s) * n;
-        if (y_pred == 1) {
-            for (int c = threadIdx.x; c < n; c += blockDim.x) {
-                if (!hit) {
-                    if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
-                } else {
-                    if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
-                }
-            }
-        }
-        __syncthreads();
-        if (!K.adjusted[env]) {
-            if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
-            __syncthreads();
-            int first = 0x7fffffff;
-            for (int c = threadIdx.x; c < n; c += blockDim.x)
-                if (acc[c] > D.lo) { first = c; break; }
-            if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
-            __syncthreads();
-            if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
-        }
-        if (threadIdx.x == 0) A.hits[env * D.S + s] = hit;
-    }
+    control_bookkeeping(D, K, task, env, s, m, f_of(f, a_i), y, A.hits, sm);
+
     // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
     int c_from = y == 1 ? a_i : 0;
     const int c_to = y == 1 ? n : a_i;
-    bool rescore = true;
+    n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
     while (c_from <= c_to) {
-        if (rescore) {
-            score_range(D, m, c_from, c_to, sm);
-            n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
-        }
-        // first candidate (in order) with f * y <= 0
-        if (threadIdx.x == 0) sm.ired[2] = 0x7fffffff;
-        __syncthreads();
-        int firstc = 0x7fffffff;
-        for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x)
-            if (sm.f[c] * (double)y <= 0.0) { firstc = c; break; }
-        if (firstc != 0x7fffffff) atomicMin(&sm.ired[2], firstc);
-        __syncthreads();
-        const int cstar = sm.ired[2];
-        __syncthreads();
-        const int last = cstar == 0x7fffffff ? c_to : cstar;
+        int zeros;
+        const int cstar = first_mistake(f, y, c_from, c_to, &zeros);
+        const int last = cstar < 0 ? c_to : cstar;
         n_pred += (uint64_t)(last - c_from + 1);
         // the predictions made on the way each consume a tie-break draw when f == 0 (Q11)
-        if (m > 0) {
-            int zeros = 0;
-            for (int c = c_from + (int)threadIdx.x; c <= last; c += blockDim.x) zeros += sm.f[c] == 0.0 ? 1 : 0;
-            int tz = (int)block_sum((double)zeros, sm);
-            if (threadIdx.x == 0 && tz > 0) K.tie_ctr[task] += (uint32_t)tz;
-        }
-        if (cstar == 0x7fffffff) break;
+        if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
+        if (cstar < 0) break;
         n_mist += 1;
-        kernel_column(D, m, cstar, sm);
+        kernel_column_from_d0(D, K, sh, m, d, (double)cstar / (double)n);
         int branch;
         double delta;
         bool saturated;
-        const int m_new = apply_update(D, K, dict, env, m, d, (double)cstar / (double)n, y, sm, &branch, &delta, &saturated);
+        const int m_new = apply_update(D, K, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta, &saturated);
         // A FULL dictionary that met a sample it would have added cannot represent this region: the remaining
         // candidates would meet the same wall one O(m^2) projection at a time, so the augmentation of this learner
         // stops for this step (build-defined; the reference's dictionary is unbounded; the oracle does the same)
         if (saturated) break;
         c_from = cstar + 1;
-        rescore = true;
         if (branch == 2 && m_new > m) {
             n_grow += 1;
-            // The dictionary grew by the landmark (state, c*/n) with coefficient y and nothing else changed, so
-            // the scores of the remaining candidates move by one kernel value each (same state: only the last
-            // coordinate differs) -- instead of a full rescoring.  The float32 regime of a
+            // The dictionary grew by the landmark (state, c*/n) with coefficient y and nothing else changed: in the
+            // order the scores are summed it is one more term, E = 1 (same state).  The float32 regime of a
             // single-landmark dictionary (kernel.py:16) keeps the full pass.
             if (m >= 2) {
-                const double ts = (double)cstar / (double)n;
-                for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x) {
-                    const double dl = ts - (double)c / (double)n;
-                    sm.f[c] += (double)y * rs_exp(-D.gamma * (dl * dl));
+                const int lane = threadIdx.x & 63;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    int o = cstar - (64 * g + lane);
+                    o = o < 0 ? -o : o;
+                    f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
                 }
                 n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0);
-                __syncthreads();
-                rescore = false;
+            } else {
+                score<4, 1>(D, K, sh, m_new, d, sm, 0, f);
+                n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0) * (uint64_t)m_new;
             }
+        } else {  // projection: every coefficient moved
+            score<4, 1>(D, K, sh, m_new, d, sm, 0, f);
+            n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0) * (uint64_t)m_new;
         }
         m = m_new;
     }
     if (threadIdx.x == 0) {
         K.m[dict] = m;
+        if (n_mist) K.kf_owner[dict] = -1;  // the K_f row no longer holds a Projectron.predict's cache (Q12 guard)
         uint64_t* st = K.stats + (size_t)task * 4;
         st[0] += n_pred;
         st[1] += n_mist;
@@ -462,48 +695,56 @@ struct SelArgs {
 
 // per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63): the smallest candidate the classifier
 // accepts.  The reference scans c = 0, 1, 2, ... and stops at the first +1 (about 15 candidates in); so does this:
-// batches of one 16-candidate strip per wave, in order, until a batch contains the answer.
-__global__ __launch_bounds__(256) void select_kernel(SelArgs A) {
+// 64 candidates per pass of the landmarks, in order, until a pass contains the answer.
+template <int MODE>
+__device__ __forceinline__ int select_scan(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, int task, int env,
+                                           int s, const Lds& sm, uint64_t* n_scored) {
+    const int n = D.n_prbs, lane = threadIdx.x & 63;
+    int found = -1;
+    for (int g = 0; 64 * g <= n && found < 0; ++g) {
+        double f[1];
+        if (g == 0)
+            score<1, MODE>(D, K, sh, m, d, sm, g, f);
+        else
+            score<1, MODE == 0 ? 1 : MODE>(D, K, sh, m, d, sm, g, f);
+        const int c = 64 * g + lane;
+        const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
+        *n_scored += (uint64_t)(c1 - 64 * g + 1);
+        unsigned long long cand = __ballot(c <= n && f[0] >= 0.0);  // positive, or a tie to be drawn
+        // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
+        while (cand) {
+            const int l = __builtin_ctzll(cand);
+            const double fl = readlane_f64(f[0], l);
+            if (fl > 0.0) { found = 64 * g + l; break; }
+            int dr = 0;
+            if (threadIdx.x == 0) dr = tie_draw(K, task, env, s);
+            dr = __builtin_amdgcn_readfirstlane(dr);
+            if (dr == 1) { found = 64 * g + l; break; }
+            cand &= cand - 1;
+        }
+    }
+    return found;
+}
+
+__global__ __launch_bounds__(64) void select_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    Lds sm = carve_lds(D.cap, K.work);
+    __shared__ Lds sm;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
+    const uint64_t* sh = shells_of(D, K, dict);
     const int m = K.m[dict];
-    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    load_gtab(K, sm);
+    stage_state(D, A.state, env, s, d, sm);
     __syncthreads();
     int found = -1;
     uint64_t n_scored = 0;
     if (m > 0) {
-        prepare_operands(D, K, dict, m, d, sm);
-        const int batch = 16 * (int)(blockDim.x >> 6);
-        for (int c0 = 0; c0 <= n && found < 0; c0 += batch) {
-            const int c1 = c0 + batch - 1 < n ? c0 + batch - 1 : n;
-            score_range(D, m, c0, c1, sm);
-            n_scored += (uint64_t)(c1 - c0 + 1);
-            if (threadIdx.x == 0) sm.ired[0] = 0x7fffffff;
-            __syncthreads();
-            const int c = c0 + (int)threadIdx.x;
-            if (c <= c1 && sm.f[c] >= 0.0) atomicMin(&sm.ired[0], c);  // positive, or a tie to be drawn
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                // walk the (rare) exact ties of this batch in order; each consumes one draw (kernel.py:26-27)
-                int cc = sm.ired[0], hit = -1;
-                while (cc <= c1) {
-                    if (sm.f[cc] > 0.0) { hit = cc; break; }
-                    if (sm.f[cc] == 0.0 && tie_draw(K, task, env, s) == 1) { hit = cc; break; }
-                    int nx = 0x7fffffff;
-                    for (int q = cc + 1; q <= c1; ++q)
-                        if (sm.f[q] >= 0.0) { nx = q; break; }
-                    cc = nx;
-                }
-                sm.ired[1] = hit;
-            }
-            __syncthreads();
-            found = sm.ired[1];
-            __syncthreads();
-        }
+        if (D.shared)
+            found = select_scan<2>(D, K, sh, m, d, task, env, s, sm, &n_scored);
+        else
+            found = select_scan<0>(D, K, sh, m, d, task, env, s, sm, &n_scored);
     }
     if (threadIdx.x == 0) {
         const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
@@ -612,87 +853,46 @@ struct ScanArgs {
     int32_t round;
 };
 
-__global__ __launch_bounds__(256) void shared_scan_kernel(ScanArgs A) {
+__global__ __launch_bounds__(64) void shared_scan_kernel(ScanArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    Lds sm = carve_lds(D.cap, K.work);
+    __shared__ Lds sm;
     const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
+    const uint64_t* sh = shells_of(D, K, dict);
     const int m = K.m[dict];
-    if (threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
-    __syncthreads();
-    prepare_operands(D, K, dict, m, d, sm);
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
     uint64_t n_pred = 0, n_eval = 0;
-    int c_from;
+    int c_from = A.round == 0 ? (y == 1 ? a_i : 0) : A.cursor[task];
+    const int c_to = y == 1 ? n : a_i;
+    if (A.round > 0 && !(c_from >= 0 && c_from <= c_to)) {  // nothing left to examine
+        if (threadIdx.x == 0) {
+            A.cstar[task] = -1;
+            A.cursor[task] = -1;
+        }
+        return;
+    }
+    load_gtab(K, sm);
+    stage_state(D, A.state, env, s, d, sm);
+    __syncthreads();
+    double f[4];
+    score<4, 2>(D, K, sh, m, d, sm, 0, f);
     if (A.round == 0) {
         // y_pred, accuracy table, security factor: kbrl_control.py:88-101 (as update_control_kernel)
-        score_range(D, m, a_i, a_i, sm);
         n_pred += 1;
         n_eval += (uint64_t)m;
-        int y_pred = 0;
-        double f0 = sm.f[a_i];
-        if (m > 0) {
-            y_pred = f0 > 0.0 ? 1 : (f0 < 0.0 ? -1 : 0);
-            if (y_pred == 0) {
-                if (threadIdx.x == 0) sm.ired[0] = tie_draw(K, task, env, s);
-                __syncthreads();
-                y_pred = sm.ired[0];
-                __syncthreads();
-            }
-        }
-        const int hit = y == y_pred;
-        int margin = K.margins[env * D.S + s];
-        margin = margin > 0 ? margin : 0;
-        double* acc = K.acc + ((size_t)env * D.S + s) * n;
-        if (y_pred == 1) {
-            for (int c = threadIdx.x; c < n; c += blockDim.x) {
-                if (!hit) {
-                    if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
-                } else {
-                    if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
-                }
-            }
-        }
-        __syncthreads();
-        if (!K.adjusted[env]) {
-            if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
-            __syncthreads();
-            int first = 0x7fffffff;
-            for (int c = threadIdx.x; c < n; c += blockDim.x)
-                if (acc[c] > D.lo) { first = c; break; }
-            if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
-            __syncthreads();
-            if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
-        }
-        if (threadIdx.x == 0) A.hits[env * D.S + s] = hit;
-        c_from = y == 1 ? a_i : 0;
-    } else {
-        c_from = A.cursor[task];
+        control_bookkeeping(D, K, task, env, s, m, f_of(f, a_i), y, A.hits, sm);
     }
-    const int c_to = y == 1 ? n : a_i;
     int cstar = -1;
     if (c_from >= 0 && c_from <= c_to) {
-        score_range(D, m, c_from, c_to, sm);
         n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
-        if (threadIdx.x == 0) sm.ired[2] = 0x7fffffff;
-        __syncthreads();
-        int firstc = 0x7fffffff;
-        for (int c = c_from + (int)threadIdx.x; c <= c_to; c += blockDim.x)
-            if (sm.f[c] * (double)y <= 0.0) { firstc = c; break; }
-        if (firstc != 0x7fffffff) atomicMin(&sm.ired[2], firstc);
-        __syncthreads();
-        if (sm.ired[2] != 0x7fffffff) cstar = sm.ired[2];
+        int zeros;
+        cstar = first_mistake(f, y, c_from, c_to, &zeros);
         const int last = cstar >= 0 ? cstar : c_to;
         n_pred += (uint64_t)(last - c_from + 1);
-        if (m > 0) {  // predictions with f == 0 consume a tie-break draw each (Q11)
-            int zeros = 0;
-            for (int c = c_from + (int)threadIdx.x; c <= last; c += blockDim.x) zeros += sm.f[c] == 0.0 ? 1 : 0;
-            int tz = (int)block_sum((double)zeros, sm);
-            if (threadIdx.x == 0 && tz > 0) K.tie_ctr[task] += (uint32_t)tz;
-        }
+        if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;  // Q11
     }
     if (threadIdx.x == 0) {
         A.cstar[task] = cstar;
@@ -827,117 +1027,104 @@ __global__ __launch_bounds__(KB_RANK_THREADS) void shared_commit_kernel(KbDev D,
     });
 }
 
-// sum of the 256 strided partial products Σ_{j = t, t + 256, ...} a[j] b[j] (t < 256) exactly as block_sum forms it in the
-// 256-thread kernels -- per 64-lane wave the xor butterfly (lane 0's value), then the four wave totals in order -- but
-// by ONE wave, without block barriers.  All lanes return the value.
-__device__ __forceinline__ double wave_dot256(const double* a, const double* b, int m) {
-    const int lane = threadIdx.x & 63;
-    double part[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        part[v] = 0.0;
-        for (int j = 64 * v + lane; j < m; j += 256) part[v] += a[j] * b[j];
-    }
-    for (int dd = 32; dd >= 1; dd >>= 1) {  // four independent butterflies, stepped together
-#pragma unroll
-        for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
-    }
-    double t = 0.0;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) t += __shfl(part[v], 0);
-    return t;  // (the 1024-thread kernels add exact zeros for their waves 4..15)
-}
-
 // ---- A dictionary at capacity only projects: landmarks and Kinv are fixed for a whole proposal list, so everything
 // that does not involve the coefficients is computed for ALL proposals at once by kernels as wide as the chip
-// (shared_cols_kernel, shared_matvec_kernel: one workgroup per slice would leave 250 CUs idle and walk 256 dependent L2
-// round trips per wave), and only f = k . coeff and the coefficient update run one proposal after the other
-// (shared_apply_kernel, one wave, no block barriers).  Work area per slice: KF [budget][capr] kernel columns,
-// DS [budget][capr] d* = Kinv k_f.
+// (shared_cols_kernel, shared_matvec_kernel: one workgroup per slice would leave 250 CUs idle), and only f = k . coeff
+// and the coefficient update run one proposal after the other (shared_apply_kernel, one wave, no block barriers).
+// Work area per slice: KF [budget][capr] kernel columns, DS [budget][capr] d* = Kinv k_f.
 __device__ __forceinline__ bool batch_applies(const KbDev& D, int m) { return m >= D.cap && m >= 2 && !D.serial_apply; }
 
 #define KB_COLS_BLOCKS 16
 #define KB_MATVEC_BLOCKS 32
 
-// kernel columns of all proposals of the full dictionaries (prepare_operands' D0 and kernel_column's arithmetic)
+// kernel columns of all proposals of the full dictionaries (kernel_column_full's arithmetic)
 __global__ __launch_bounds__(256) void shared_cols_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                           int budget) {
     const int s = blockIdx.x;
     const int m = K.m[s];
     if (!batch_applies(D, m)) return;
     const int np = counts[s] < budget ? counts[s] : budget;
-    const int d = D.dims[s] + 1, cap = D.cap, capr = kb_capr(cap);
+    const int d = D.dims[s] + 1, capr = kb_capr(D.cap);
+    const uint64_t* sh = shells_of(D, K, s);
     const double* pr = props + (size_t)s * budget * KB_PROP_W;
-    const double* L = K.L + (size_t)s * KB_DMAX * cap;
     double* KF = K.workb + (size_t)s * 2 * budget * capr;
     for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < np * m; e += gridDim.y * blockDim.x) {
         const int p = e / m, j = e - p * m;
         const double* x = pr + (size_t)p * KB_PROP_W + 2;
+        const double* P = vec_page(K, sh, j >> 6);
+        const int l = j & 63;
         double d0 = 0.0;
         for (int q = 0; q < d - 1; ++q) {
-            const double t = L[(size_t)q * cap + j] - x[q];
+            const double t = P[q * KB_CH + l] - x[q];
             d0 += t * t;
         }
         const int c = ((int)pr[(size_t)p * KB_PROP_W + 1]) >> 2;
-        const double dl = L[(size_t)(d - 1) * cap + j] - (double)c / (double)D.n_prbs;
+        const double dl = P[(d - 1) * KB_CH + l] - (double)c / (double)D.n_prbs;
         KF[(size_t)p * capr + j] = rs_exp(-D.gamma * (d0 + dl * dl));
     }
 }
 
-// d* = Kinv k_f for all proposals of the full dictionaries: a wave takes rows of Kinv and walks the proposals four at a
-// time (each row sum as in apply_update: lane-strided partial sums in increasing j, then the xor butterfly, lane 0)
+// d* = Kinv k_f for all proposals of the full dictionaries, each output summed as matvec_colsum does (column walk,
+// rows in increasing order, fused multiply-add): a thread owns output i and walks the proposals four at a time
 __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
     const int s = blockIdx.x;
     const int m = K.m[s];
     if (!batch_applies(D, m)) return;
     const int np = counts[s] < budget ? counts[s] : budget;
-    const int cap = D.cap, capr = kb_capr(cap);
+    const int capr = kb_capr(D.cap);
+    const uint64_t* sh = shells_of(D, K, s);
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
-    const double* Kinv = K.Kinv + (size_t)s * cap * cap;
+    const int nb = (m + 63) >> 6;
     const double* KF = K.workb + (size_t)s * 2 * budget * capr;
     double* DS = K.workb + (size_t)s * 2 * budget * capr + (size_t)budget * capr;
-    for (int i = wave; i < m; i += nw) {
-        const double* row = Kinv + (size_t)i * cap;
-        for (int p0 = 0; p0 < np; p0 += 4) {
-            double a[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int j = lane; j < m; j += 64) {
-                const double kv = row[j];
+    const int nwork = nb * ((np + 3) >> 2);  // (column block, group of four proposals) per wave
+    const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    for (int wk = wave; wk < nwork; wk += nw) {
+        const int bi = wk % nb, p0 = (wk / nb) * 4;
+        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int bj = 0; bj < nb; ++bj) {
+            const int rows = m - 64 * bj < 64 ? m - 64 * bj : 64;
+            const double* tp = kinv_tile(K, sh, bj, bi) + lane;
+            double kfv[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const double kf = KF[(size_t)(p0 + r < np ? p0 + r : p0) * capr + j];
-                    a[r] += kv * kf;
+            for (int r = 0; r < 4; ++r) kfv[r] = KF[(size_t)(p0 + r < np ? p0 + r : p0) * capr + 64 * bj + lane];
+            for (int r0 = 0; r0 < rows; r0 += 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int rr = r0 + u;
+                    if (rr < rows) {
+                        const double kv = tp[rr * 64];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) a[r] = __builtin_fma(kv, readlane_f64(kfv[r], rr), a[r]);
+                    }
                 }
             }
-            for (int dd = 32; dd >= 1; dd >>= 1) {  // the four butterflies step together
+        }
+        const int i = 64 * bi + lane;
+        if (i < m) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) a[r] += __shfl_xor(a[r], dd);
-            }
-            if (lane == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = a[r];
-            }
+            for (int r = 0; r < 4; ++r)
+                if (p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = a[r];
         }
     }
 }
 
 // the ordered part, by the slice's own workgroup (shared_apply_kernel): delta per proposal, then predict + projection in
-// list order.  Returns the number of mistakes.
+// list order.  co: the coefficient column in (dynamic) LDS.  Returns the number of mistakes.
 __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, const double* pr, int np, int budget,
-                                     Lds& sm) {
-    const int cap = D.cap, capr = sm.capr;
+                                     double* co, double* flag) {
+    const int capr = kb_capr(D.cap);
+    const uint64_t* sh = shells_of(D, K, s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    double* coeffg = K.coeff + (size_t)s * cap;
     const double* KF = K.workb + (size_t)s * 2 * budget * capr;
     const double* DS = KF + (size_t)budget * capr;
-    for (int j = threadIdx.x; j < m; j += blockDim.x) sm.co[j] = coeffg[j];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) co[j] = *vec_at(K, sh, KB_ROW_CO, j);
     // ---- delta = 1 - k_f . d* per proposal (only the "saturated" flag depends on it here)
     for (int p = wave; p < np; p += nw) {
         const double dot = wave_dot256(DS + (size_t)p * capr, KF + (size_t)p * capr, m);
         double delta = 1.0 - dot;
         delta = delta > 0.0 ? delta : 0.0;
-        if (lane == 0) sm.f[p] = delta > D.eta ? 1.0 : 0.0;
+        if (lane == 0) flag[p] = delta > D.eta ? 1.0 : 0.0;
     }
     __syncthreads();
     // ---- the proposals in order: predict against the evolving coefficients, project if still a mistake
@@ -946,33 +1133,36 @@ __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, in
         bool sat = false;
         for (int p = 0; p < np; ++p) {
             const int y = (((int)pr[(size_t)p * KB_PROP_W + 1]) & 1) ? 1 : -1;
-            const double f = wave_dot256(KF + (size_t)p * capr, sm.co, m);
+            const double f = wave_dot256(KF + (size_t)p * capr, co, m);
             if (f * (double)y <= 0.0) {
                 n_mist += 1;
-                sat = sat || sm.f[p] != 0.0;
+                sat = sat || flag[p] != 0.0;
                 const double* ds = DS + (size_t)p * capr;
-                for (int j = lane; j < m; j += 64) sm.co[j] = sm.co[j] + (double)y * ds[j];
+                for (int j = lane; j < m; j += 64) co[j] = co[j] + (double)y * ds[j];
             }
         }
         if (sat && lane == 0) atomicOr(&K.err[0], 8);  // a full dictionary met a sample it would have grown for
     }
     __syncthreads();
-    for (int j = threadIdx.x; j < m; j += blockDim.x) coeffg[j] = sm.co[j];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) *vec_at(K, sh, KB_ROW_CO, j) = co[j];
     return n_mist;
 }
 
-// apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order
+// apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order.  Dynamic LDS: capr + budget doubles.
 __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                          int budget, uint64_t* gstats) {
-    Lds sm = carve_lds(D.cap, K.work);
+    extern __shared__ double kb_dyn_lds[];
+    __shared__ Lds sm;
     const int s = blockIdx.x;
     const int d = D.dims[s] + 1;
+    const uint64_t* sh = shells_of(D, K, s);
     int m = K.m[s];
     const int np = counts[s] < budget ? counts[s] : budget;
     uint64_t n_mist = 0, n_grow = 0;
     if (np > 0 && batch_applies(D, m)) {
         // kernel columns and d* of the whole list are in the work area (shared_cols_kernel, shared_matvec_kernel)
-        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, sm);
+        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, kb_dyn_lds,
+                                  kb_dyn_lds + kb_capr(D.cap));
         if (threadIdx.x == 0) atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
         return;
     }
@@ -981,21 +1171,27 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
         const int packed = (int)p[1];
         const int c = packed >> 2, y = (packed & 1) ? 1 : -1;
         __syncthreads();
-        if (threadIdx.x < d - 1) sm.x[threadIdx.x] = p[2 + threadIdx.x];
+        if ((int)threadIdx.x < d - 1) sm.x[threadIdx.x] = p[2 + threadIdx.x];
         __syncthreads();
-        prepare_operands(D, K, s, m, d, sm);
         // Projectron.predict on (state, c/n): f = k . coeff (float32 while a single landmark is held)
-        kernel_column(D, m, c, sm);
-        double part = 0.0;
-        if (threadIdx.x < 256)  // same 256 strided partial sums as the 256-thread kernels
-            for (int j = threadIdx.x; j < m; j += 256) part += sm.kf[j] * sm.co[j];
-        double f = block_sum(part, sm);
-        if (m == 1) f = (double)(float)((float)sm.kf[0] * (float)sm.co[0]);
-        if (m == 0) f = 0.0;
+        const double t = (double)c / (double)D.n_prbs;
+        kernel_column_full(D, K, sh, m, d, sm.x, t);
+        double f = 0.0;
+        if (m >= 2) {
+            if (threadIdx.x < 64) {
+                const double v = wave_dot256_rows(K, sh, KB_ROW_KF, KB_ROW_CO, m);
+                if (threadIdx.x == 0) sm.red[14] = v;
+            }
+            __syncthreads();
+            f = sm.red[14];
+            __syncthreads();
+        } else if (m == 1) {
+            f = (double)(float)((float)*vec_at(K, sh, KB_ROW_KF, 0) * (float)*vec_at(K, sh, KB_ROW_CO, 0));
+        }
         if (f * (double)y <= 0.0) {  // still a mistake against the evolving dictionary
             int branch;
             double delta;
-            const int m_new = apply_update<8>(D, K, s, 0, m, d, (double)c / (double)D.n_prbs, y, sm, &branch, &delta);
+            const int m_new = apply_update(D, K, s, 0, m, d, sm.x, t, c, y, sm, &branch, &delta);
             n_mist += 1;
             if (branch == 2 && m_new > m) n_grow += 1;
             m = m_new;
@@ -1003,6 +1199,7 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     }
     if (threadIdx.x == 0) {
         K.m[s] = m;
+        if (np > 0) K.kf_owner[s] = -1;
         atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
         atomicAdd((unsigned long long*)&gstats[2], (unsigned long long)n_grow);
     }
@@ -1022,27 +1219,28 @@ struct OneArgs {
 __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    Lds sm = carve_lds(D.cap, K.work);
+    __shared__ Lds sm;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
-    const int d = D.dims[s] + 1, cap = D.cap;
+    const uint64_t* sh = shells_of(D, K, dt);
+    const int d = D.dims[s] + 1;
     const int m = K.m[dt];
-    double* kfg = K.kf + (size_t)task * cap;
     double p = 0.0;
-    const double* L = K.L + (size_t)dt * KB_DMAX * cap;
     for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        double* P = vec_page(K, sh, j >> 6);
+        const int l = j & 63;
         double dist = 0.0;
         for (int q = 0; q < d; ++q) {
-            double t = L[(size_t)q * cap + j] - A.x[q];
+            double t = P[q * KB_CH + l] - A.x[q];
             dist += t * t;
         }
         double k = rs_exp(-D.gamma * dist);
         if (m == 1) k = (double)(float)k;
-        kfg[j] = k;
-        p += k * K.coeff[(size_t)dt * cap + j];
+        P[KB_ROW_KF * KB_CH + l] = k;
+        p += k * P[KB_ROW_CO * KB_CH + l];
     }
     double f = block_sum(p, sm);
-    if (m == 1) f = (double)(float)((float)kfg[0] * (float)K.coeff[(size_t)dt * cap]);
+    if (m == 1) f = (double)(float)((float)*vec_at(K, sh, KB_ROW_KF, 0) * (float)*vec_at(K, sh, KB_ROW_CO, 0));
     if (threadIdx.x == 0) {
         int y = 0;
         if (m > 0) {
@@ -1050,10 +1248,10 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
             if (y == 0) y = tie_draw(K, task, env, s);
         } else {
             f = 0.0;
-            kfg[0] = 0.0;
         }
         K.f_last[task] = f;
         K.m_last[task] = m;
+        K.kf_owner[dt] = task;
         A.out[0] = (double)y;
         A.out[1] = f;
         K.stats[(size_t)task * 4 + 0] += 1;
@@ -1063,15 +1261,15 @@ __global__ __launch_bounds__(256) void predict_one_kernel(OneArgs A) {
 __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    Lds sm = carve_lds(D.cap, K.work);
+    __shared__ Lds sm;
     const int task = A.task, env = task / D.S, s = task - env * D.S;
     const int dt = dict_of(D, task);
-    const int d = D.dims[s] + 1, cap = D.cap;
+    const int d = D.dims[s] + 1;
     int m = K.m[dt];
     // Q12: Projectron.update uses the (f, K_f) cached by the predict that immediately preceded it.  Learners bound
-    // into a KBRL_Control share their dictionary with update_control / select_action, which may have grown it in
-    // between; the reference would then multiply arrays of different lengths (numpy raises).  Report it.
-    if (K.m_last[task] != m) {
+    // into a KBRL_Control share their dictionary with update_control / select_action, which may have grown it (or
+    // reused its K_f row) in between; the reference would then multiply arrays of different lengths (numpy raises).
+    if (K.m_last[task] != m || (m > 0 && K.kf_owner[dt] != task)) {
         if (threadIdx.x == 0) { A.out[2] = -1.0; A.out[3] = 0.0; }
         return;
     }
@@ -1080,18 +1278,14 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
         if (threadIdx.x == 0) { A.out[2] = 0.0; A.out[3] = 0.0; }
         return;
     }
-    // stage x, the coefficients and the cached kernel row for apply_update
     for (int q = threadIdx.x; q < d - 1; q += blockDim.x) sm.x[q] = A.x[q];
-    for (int j = threadIdx.x; j < sm.capr; j += blockDim.x) {
-        sm.co[j] = j < m ? K.coeff[(size_t)dt * cap + j] : 0.0;
-        sm.kf[j] = j < (m > 0 ? m : 1) ? K.kf[(size_t)task * cap + j] : 0.0;
-    }
     __syncthreads();
     int branch;
     double delta;
-    const int m_new = apply_update(D, K, dt, env, m, d, A.x[d - 1], A.y, sm, &branch, &delta);
+    const int m_new = apply_update(D, K, dt, env, m, d, sm.x, A.x[d - 1], grid_index(A.x[d - 1], D.n_prbs), A.y, sm, &branch, &delta);
     if (threadIdx.x == 0) {
         K.m[dt] = m_new;
+        K.kf_owner[dt] = -1;  // update_control reuses the row
         A.out[2] = (double)branch;
         A.out[3] = delta;
         K.stats[(size_t)task * 4 + 1] += 1;
@@ -1099,8 +1293,37 @@ __global__ __launch_bounds__(256) void update_one_kernel(OneArgs A) {
     }
 }
 
+// dense copies of one dictionary for the host (kb_get_learner, kb_get_kernel_row)
+__global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K, int dict, int d, int m, double* landmarks,
+                                                             double* coeff, double* kinv, double* kf_row) {
+    const uint64_t* sh = shells_of(D, K, dict);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
+    if (landmarks)
+        for (int e = tid; e < m * d; e += nt) {
+            const int j = e / d, q = e - j * d;
+            landmarks[e] = *vec_at(K, sh, q, j);
+        }
+    if (coeff)
+        for (int j = tid; j < m; j += nt) coeff[j] = *vec_at(K, sh, KB_ROW_CO, j);
+    if (kf_row)
+        for (int j = tid; j < m; j += nt) kf_row[j] = *vec_at(K, sh, KB_ROW_KF, j);
+    if (kinv)
+        for (size_t e = tid; e < (size_t)m * m; e += nt) {
+            const int i = (int)(e / m), j = (int)(e - (size_t)i * m);
+            kinv[e] = kinv_tile(K, sh, i >> 6, j >> 6)[(i & 63) * 64 + (j & 63)];
+        }
+}
+
+__global__ void kb_gtab_kernel(KbDev D, KbState K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < KB_GTAB) {
+        const double t = (double)k / (double)D.n_prbs;
+        K.gtab[k] = rs_exp_nonpos(-D.gamma * (t * t));
+    }
+}
+
 __global__ void kb_reset_kernel(KbDev D, KbState K, const int32_t* init_action, const int32_t* init_sec,
-                                const uint64_t* seeds) {
+                                const uint64_t* seeds, int n_dict) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int T = D.n_envs * D.S;
     if (i < T) {  // per-learner state; the dictionaries (K.m: one per learner, or one per slice when shared) are
@@ -1114,11 +1337,13 @@ __global__ void kb_reset_kernel(KbDev D, KbState K, const int32_t* init_action, 
         for (int k = 0; k < 4; ++k) K.stats[(size_t)i * 4 + k] = 0;
         for (int c = 0; c < D.n_prbs; ++c) K.acc[(size_t)i * D.n_prbs + c] = (D.lo + D.hi) / 2;
     }
+    if (i < n_dict) K.kf_owner[i] = -1;
     if (i < D.n_envs) {
         K.seeds[i] = seeds[i];
         K.adjusted[i] = 0;
         K.err[i] = 0;
     }
+    if (i == 0) K.pool_top[0] = 64;  // offset 0 means "no shell"
 }
 
 }  // namespace kb

@@ -53,7 +53,7 @@ class Evaluator():
 class BatchedEvaluator(Evaluator):
     """All runs of one (scenario, accuracy range) at once: run i = replica i."""
 
-    def evaluate_all(self, runs, device=0, capacity=1024, verbose=True):
+    def evaluate_all(self, runs, device=0, capacity=4096, verbose=True):
         import ctypes as C
         from ranslice import config as _c
         from ranslice.kbrl_dev import VecKBRL
@@ -98,11 +98,14 @@ class BatchedEvaluator(Evaluator):
         env.fetch()                           # surfaces simulator capacity errors
         assert hist['recorded'] == self.steps
         sizes = agent.dictionary_sizes()
-        if (sizes >= capacity).any():
+        pool = agent.pool()
+        self.last_run = dict(max_dictionary=int(sizes.max()), mean_dictionary=float(sizes.mean()), pool=pool)
+        if pool['saturated'] or pool['pool_full']:
             import warnings
-            warnings.warn('KBRL dictionaries of runs %s reached their capacity of %d landmarks and projected further '
-                          'samples instead of growing' % (sorted({runs[k] for k in np.nonzero(sizes >= capacity)[0]}),
-                                                          capacity))
+            warnings.warn('KBRL dictionaries of runs %s could not grow any further (capacity %d landmarks, pool %.1f of %.1f '
+                          'MB in use) and projected further samples instead of growing: raise capacity / pool_bytes'
+                          % (sorted({runs[k] for k in np.nonzero(sizes >= capacity)[0]}), capacity,
+                             pool['used_bytes'] / 2 ** 20, pool['total_bytes'] / 2 ** 20))
         files = []
         for k, i in enumerate(runs):
             results = {'reward': hist['reward'][k], 'resources': hist['resources'][k], 'hits': hist['hits'][k],

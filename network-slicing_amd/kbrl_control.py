@@ -22,7 +22,7 @@ class Learner:
 
 
 class KBRL_Control:
-    def __init__(self, learners, n_prbs, alfa=0.05, accuracy_range=[0.99, 0.999], capacity=1024, device=0, seed=0):
+    def __init__(self, learners, n_prbs, alfa=0.05, accuracy_range=[0.99, 0.999], capacity=4096, device=0, seed=0):
         self.learners = learners
         self.accuracy_range = accuracy_range
         self.n_slices = len(learners)
@@ -103,13 +103,15 @@ class KBRL_Control:
             resources_history[i] = action.sum()
             adjusted_actions[i] = self.adjusted
             hits_history[:, i] = hits
-        sizes = self._dev.dictionary_sizes()
-        if (sizes >= self._dev.capacity).any():
+        pool = self._dev.pool()
+        if pool['saturated'] or pool['pool_full']:
             import warnings
-            warnings.warn('KBRL dictionaries %s reached their capacity of %d landmarks: further samples were projected '
-                          'onto the span instead of growing the dictionary (the reference grows without bound); pass a '
-                          'larger capacity to KBRL_Control / create_kbrl_agent'
-                          % (np.nonzero(sizes[0] >= self._dev.capacity)[0].tolist(), self._dev.capacity))
+            sizes = self._dev.dictionary_sizes()
+            warnings.warn('KBRL dictionaries (sizes %s) could not grow any further -- capacity %d landmarks, dictionary pool '
+                          '%.1f of %.1f MB in use -- and projected the samples they would have added onto their span (the '
+                          "reference's SVvariable grows without bound): pass a larger capacity / pool_bytes to "
+                          'KBRL_Control / create_kbrl_agent (capacity up to 65536; the pool is bounded by device memory)'
+                          % (sizes[0].tolist(), self._dev.capacity, pool['used_bytes'] / 2 ** 20, pool['total_bytes'] / 2 ** 20))
         print('mean resources = {}'.format(resources_history.mean()))
         print('total violations = {}'.format(violation_history.sum()))
         print('mean adjusted = {}'.format(adjusted_actions.mean()))

@@ -96,7 +96,7 @@ class KbConfig(C.Structure):
     _fields_ = [('n_envs', C.c_int32), ('n_slices', C.c_int32), ('n_prbs', C.c_int32), ('capacity', C.c_int32),
                 ('dims', C.c_int32 * KB_MAX_SLICES), ('alfa', C.c_double), ('acc_lo', C.c_double),
                 ('acc_hi', C.c_double), ('gamma', C.c_double), ('eta', C.c_double),
-                ('shared_dictionary', C.c_int32), ('first_env', C.c_int32)]
+                ('shared_dictionary', C.c_int32), ('first_env', C.c_int32), ('pool_bytes', C.c_int64)]
 
 
 class RsAllocRec(C.Structure):

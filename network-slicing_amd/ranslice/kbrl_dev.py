@@ -20,7 +20,7 @@ _up = C.POINTER(C.c_uint64)
 
 class VecKBRL:
     def __init__(self, n_envs, dims, n_prbs, alfa=KBRL_ALFA, accuracy_range=(0.99, 0.999), gamma=KBRL_GAMMA,
-                 eta=KBRL_ETA, capacity=1024, device=0, shared=False, first_env=0):
+                 eta=KBRL_ETA, capacity=4096, device=0, shared=False, first_env=0, pool_bytes=0):
         self.L = _lib.load()
         cfg = KbConfig()
         cfg.n_envs, cfg.n_slices, cfg.n_prbs, cfg.capacity = n_envs, len(dims), n_prbs, capacity
@@ -29,6 +29,7 @@ class VecKBRL:
         cfg.alfa, cfg.acc_lo, cfg.acc_hi = alfa, accuracy_range[0], accuracy_range[1]
         cfg.gamma, cfg.eta = gamma, eta
         cfg.shared_dictionary, cfg.first_env = int(bool(shared)), int(first_env)
+        cfg.pool_bytes = int(pool_bytes)
         self.cfg = cfg
         self.n_envs, self.S, self.n_prbs, self.dims = n_envs, len(dims), n_prbs, list(dims)
         self.nv = int(sum(dims))
@@ -162,6 +163,14 @@ class VecKBRL:
         m = np.zeros(n, dtype=np.int32)
         self._check(self.L.kb_get_sizes(self.h, m.ctypes.data_as(_ip)))
         return m if self.cfg.shared_dictionary else m.reshape(self.n_envs, self.S)
+
+    def pool(self):
+        """the dictionary pool: dict(used_bytes, total_bytes, saturated = replicas with a dictionary at its capacity,
+        pool_full = replicas that found the pool exhausted)"""
+        u, t = C.c_uint64(), C.c_uint64()
+        ns, nf = C.c_int32(), C.c_int32()
+        self._check(self.L.kb_get_pool(self.h, C.byref(u), C.byref(t), C.byref(ns), C.byref(nf)))
+        return dict(used_bytes=u.value, total_bytes=t.value, saturated=ns.value, pool_full=nf.value)
 
     def set_kernel_timing(self, enable=True):
         self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))

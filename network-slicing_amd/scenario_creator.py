@@ -50,10 +50,11 @@ def create_env(rng, n, slots_per_step=50, propagation_type='macro_cell_urban_2GH
     return make('gym_ran_slice:RanSlice-v1', node_b=node, penalty=penalty)
 
 
-def create_kbrl_agent(rng, n, accuracy_range=[0.99, 0.999], device=0, capacity=1024):
+def create_kbrl_agent(rng, n, accuracy_range=[0.99, 0.999], device=0, capacity=4096):
     """scenario_creator.py:197-238: one Projectron learner per slice, random initial action/offset.
-    capacity: landmarks a learner's dictionary can hold (the authors' 50,400-step runs end at 45-305 on average,
-    1,025 at most); a full dictionary projects instead of growing and KBRL_Control.run warns."""
+    capacity: most landmarks a learner's dictionary may hold -- a limit, not a reservation: dictionaries take their
+    storage from a pool 64 landmarks at a time (the authors' 50,400-step runs end at 45-305 landmarks on average, 1,025 at
+    most).  A dictionary that reaches it projects instead of growing and KBRL_Control.run warns."""
     sc = scenarios[n]
     n_prbs, n_embb, n_mmtc = sc['n_prbs'], sc['n_embb'], sc['n_mmtc']
     embb_dim, mmtc_dim = len(state_variables_embb), len(state_variables_mmtc)

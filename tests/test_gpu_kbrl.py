@@ -388,3 +388,219 @@ def test_batched_evaluator_equals_run_by_run(golden_dir, tmp_path):
                 assert a[key].shape == b[key].shape, key
                 assert (a[key] == b[key]).all(), (scenario, i, key)
     sc.set_fading(None)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# round 3: dictionaries of real size -- reference-recorded long sequences, saturation at capacity 1024,
+# the pooled storage
+
+def _kinv_digest_check(kinv, g, rtol):
+    scale = np.abs(g['kinv_rows']).max()
+    np.testing.assert_allclose(kinv[::16], g['kinv_rows'], rtol=rtol, atol=rtol * scale)
+    np.testing.assert_allclose(np.diag(kinv), g['kinv_diag'], rtol=rtol, atol=rtol * scale)
+    np.testing.assert_allclose(kinv @ g['kinv_probes'], g['kinv_kp'], rtol=rtol, atol=rtol * np.abs(g['kinv_kp']).max())
+
+
+def test_projectron_long_golden_to_790_landmarks(golden_dir):
+    """G14: the reference's Projectron driven to 790 landmarks (7,000 samples, projections still happening above 600)
+    through kb_predict / kb_update: f within 1e-8 relative, every predicted sign, branch and dictionary size exact,
+    delta within 1e-7; final landmarks exact, coeff 1e-7, Kinv (every 16th row, diagonal, four probe products) 1e-6 --
+    its conditioning degrades with 1/delta, and the device sums d* = Kinv K_f column-wise with fused multiply-adds"""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g14_projectron_long')
+    ag = VecKBRL(1, [10], 200, capacity=4096)
+    ag.reset([[10]], [[3]])
+    xs, ys = g['x'], g['y']
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, 0, xs[i])
+        fr = g['f'][i]
+        assert f == pytest.approx(fr, rel=1e-8, abs=TOL), i
+        if abs(fr) > TOL:
+            assert yp == g['ypred'][i], i
+        br, dl = ag.update(0, 0, xs[i], int(ys[i]))
+        assert br == g['branch'][i], i
+        if br:
+            assert dl == pytest.approx(g['delta'][i], rel=1e-7, abs=1e-9), i
+        if i % 64 == 0 or i > len(xs) - 8:
+            assert ag.dictionary_sizes()[0, 0] == g['m'][i], i
+    L = ag.learner(0, 0, with_kinv=True)
+    assert L['m'] == len(g['landmarks']) == 790
+    np.testing.assert_array_equal(L['landmarks'], g['landmarks'])
+    np.testing.assert_allclose(L['coeff'], g['coeff'], rtol=1e-7, atol=1e-8)
+    _kinv_digest_check(L['kinv'], g, 1e-6)
+    assert np.array_equal(L['kinv'], L['kinv'].T)      # bit-symmetric: the column-walk mat-vec relies on it
+    p = ag.pool()
+    assert p['saturated'] == 0 and p['pool_full'] == 0 and 0 < p['used_bytes'] <= p['total_bytes']
+    ag.close()
+
+
+@pytest.mark.parametrize('name,min_m', [('g15_kbrl_long_s0', 200), ('g16_kbrl_long_tdl_s0', 0)])
+def test_kbrl_control_long_golden(golden_dir, name, min_m):
+    """G15 / G16: KBRL_Control teacher-forced over the reference's 2,200 recorded steps of scenario_0 (G15: dictionaries
+    of several hundred landmarks): every hit, selected action, adjusted flag, margin, security factor and dictionary
+    size; final landmarks exact, coefficients 1e-6"""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, name)
+    dims, n_prbs = _dims(0)
+    ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=4096)
+    ag.reset(g['init_action'][None].astype(np.int32), g['init_sec'][None].astype(np.int32))
+    steps = len(g['state'])
+    for i in range(steps):
+        hits = ag.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        assert (hits[0] == g['hits'][i]).all(), i
+        nxt = g['state'][i + 1] if i + 1 < steps else g['final_state']
+        act, adj = ag.select_action(nxt[None])
+        assert (act[0] == g['action_out'][i]).all(), i
+        assert adj[0] == g['adjusted'][i]
+        if i % 20 == 0 or i == steps - 1:
+            c = ag.control(with_accuracies=False)
+            assert (c['margins'][0] == g['margins'][i]).all() and (c['security_factors'][0] == g['security'][i]).all(), i
+            sizes = ag.dictionary_sizes()[0]
+            want = np.array([0 if z == 0 else z for z in g['set_size'][i]])
+            # get_set_size() of a single-landmark dictionary is len(x) (projectron.py:62-64), not 1
+            assert all(sz == w or (sz == 1 and w == dims[s] + 1) for s, (sz, w) in enumerate(zip(sizes, want))), i
+    np.testing.assert_allclose(ag.control()['accuracies'][0], g['acc'][-1], rtol=1e-12, atol=0)
+    for s in range(len(dims)):
+        L = ag.learner(0, s)
+        np.testing.assert_array_equal(L['landmarks'], np.atleast_2d(g['landmarks%d' % s]))
+        np.testing.assert_allclose(L['coeff'], g['coeff%d' % s], rtol=1e-6, atol=1e-8)
+    assert ag.dictionary_sizes().max() >= min_m
+    ag.close()
+
+
+def _fast_growing_samples(n, seed=141):
+    """a stream on which the dictionary grows by about one landmark every five samples (states spread over [0, 1.6]^10,
+    noisy labels); every second sample revisits an earlier state with a new action, as sample augmentation does"""
+    rng = np.random.default_rng(seed)
+    xs, ys, states = [], [], []
+    for i in range(n):
+        if states and rng.random() < 0.5:
+            s = states[rng.integers(len(states))]
+        else:
+            s = (rng.random(10) * 1.6).astype(np.float32)
+        states.append(s)
+        x = np.append(s, rng.integers(0, 201) / 200)
+        score = x[:-1].mean() * 0.5 + 0.35 - x[-1]
+        ys.append(-1 if score + rng.normal(0, 0.15) > 0 else 1)
+        xs.append(x)
+    return np.asarray(xs), np.asarray(ys)
+
+
+def test_projectron_through_saturation_at_capacity_1024():
+    """device vs oracle, Projectron.predict / update on one stream that fills a dictionary of capacity 1,024 and then
+    keeps projecting onto it (the fixed-budget behaviour both share; the reference's SVvariable would keep growing):
+    f within 1e-8, predicted sign / branch / size exact at every sample, delta 1e-6; final coefficients 1e-6"""
+    from ranslice.kbrl_dev import VecKBRL
+    xs, ys = _fast_growing_samples(9000)
+    cap = 1024
+    ag = VecKBRL(1, [10], 200, capacity=cap)
+    ag.reset([[10]], [[3]])
+    oa = po.OracleKBRL([10], 200, [10], [3], capacity=cap)
+    oa.set_seed(0)
+    n_sat = 0
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, 0, xs[i])
+        oyp, of = oa.predict(0, xs[i])
+        assert f == pytest.approx(of, rel=1e-8, abs=TOL), i
+        if abs(of) > 1e-7:
+            assert yp == oyp, i
+        br, dl = ag.update(0, 0, xs[i], int(ys[i]))
+        obr, odl = oa.update(0, xs[i], int(ys[i]))
+        assert br == obr, (i, br, obr, dl, odl)
+        if br:
+            assert dl == pytest.approx(odl, rel=1e-6, abs=1e-9), i
+            n_sat += int(oa.m(0) == cap and odl > 0.1)
+    assert oa.m(0) == cap and ag.dictionary_sizes()[0, 0] == cap
+    assert n_sat > 100, 'the stream should keep hitting the full dictionary'
+    np.testing.assert_allclose(ag.learner(0, 0)['coeff'], oa.coeff(0), rtol=1e-6, atol=1e-8)
+    p = ag.pool()
+    assert p['saturated'] == 1 and p['pool_full'] == 0
+    ag.synchronize()          # a dictionary at its capacity is reported, not an error
+    ag.close()
+
+
+def test_control_through_saturation_on_the_long_golden(golden_dir):
+    """KBRL_Control on G15's recorded sequence with dictionaries capped at 96 landmarks (the reference's reach 200+): device
+    and oracle agree on every hit, action and dictionary size while learners saturate and stop augmenting"""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g15_kbrl_long_s0')
+    dims, n_prbs = _dims(0)
+    cap, steps = 96, 700
+    ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=cap)
+    ag.reset(g['init_action'][None].astype(np.int32), g['init_sec'][None].astype(np.int32))
+    oa = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']), capacity=cap)
+    oa.set_seed(0)
+    for i in range(steps):
+        st, ac, lb = g['state'][i], g['action_in'][i].astype(np.int32), g['labels'][i].astype(np.int32)
+        hits = ag.update_control(st[None], ac[None], lb[None])
+        oh = oa.update_control(st, ac, lb)
+        assert (hits[0] == oh).all(), i
+        act, adj = ag.select_action(g['state'][i + 1][None])
+        oact, oadj = oa.select_action(g['state'][i + 1])
+        oa.adjusted = oadj
+        ag.set_adjusted([oadj])
+        assert (act[0] == oact).all() and adj[0] == oadj, i
+        if i % 25 == 0:
+            assert ag.dictionary_sizes()[0].tolist() == [oa.m(s) for s in range(len(dims))], i
+    assert ag.dictionary_sizes().max() == cap and ag.pool()['saturated'] == 1
+    ag.close()
+
+
+def test_off_grid_landmarks_mix_with_the_control_loop(golden_dir):
+    """landmarks inserted through Projectron.update with an arbitrary last coordinate (not a multiple of 1/n_prbs) are
+    scored by the direct exponential inside the streaming pass: a dictionary holding both kinds, then update_control /
+    select_action, device vs oracle"""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g10_kbrl_s0')
+    dims, n_prbs = _dims(0)
+    ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=256)
+    ag.reset(g['init_action'][None], g['init_sec'][None])
+    oa = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']), capacity=256)
+    oa.set_seed(0)
+    rng = np.random.default_rng(5)
+    for i in range(60):
+        for s in (0, 3):
+            x = np.append(g['state'][i][10 * s:10 * s + 10].astype(np.float64) + rng.normal(0, 0.05, 10), rng.random())
+            y = 1 if x[-1] > 0.2 else -1
+            yp, f = ag.predict(0, s, x)
+            oyp, of = oa.predict(s, x)
+            assert f == pytest.approx(of, rel=1e-8, abs=TOL)
+            assert ag.update(0, s, x, y)[0] == oa.update(s, x, y)[0]
+        hits = ag.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        oh = oa.update_control(g['state'][i], g['action_in'][i], g['labels'][i])
+        assert (hits[0] == oh).all(), i
+        act, adj = ag.select_action(g['state'][i + 1][None])
+        oact, oadj = oa.select_action(g['state'][i + 1])
+        oa.adjusted = oadj
+        ag.set_adjusted([oadj])
+        assert (act[0] == oact).all() and adj[0] == oadj, i
+    assert ag.dictionary_sizes()[0].tolist() == [oa.m(s) for s in range(len(dims))]
+    for s in range(len(dims)):
+        np.testing.assert_allclose(ag.learner(0, s)['coeff'], oa.coeff(s), rtol=1e-7, atol=1e-9)
+    ag.close()
+
+
+def test_pool_grows_on_demand_and_reports_exhaustion():
+    """the pool: kb_create accepts capacities far above round 2's 1,024 without reserving them (a 4096 x 5 handle at
+    capacity 4,096 would have been 2.7 TB of dense Kinv); usage follows the dictionaries; a pool too small to let a
+    dictionary take its next shell makes it project instead (flagged, not an error)"""
+    from ranslice import _lib
+    from ranslice.kbrl_dev import VecKBRL
+    xs, ys = _fast_growing_samples(1200)
+    big = VecKBRL(4096, [10] * 5, 200, capacity=4096, pool_bytes=4 << 30)
+    assert big.pool()['total_bytes'] <= 4 << 30
+    big.close()
+    shell0 = (22 * 64 + 4096) * 8
+    ag = VecKBRL(2, [10], 200, capacity=65536, pool_bytes=2 * shell0 + 3 * (22 * 64 + 3 * 4096) * 8 // 2 + 4096)
+    ag.reset([[10], [10]], [[3], [3]])
+    assert ag.pool()['used_bytes'] == 64 * 8
+    for i in range(len(xs)):
+        ag.predict(0, 0, xs[i])
+        ag.update(0, 0, xs[i], int(ys[i]))
+    p = ag.pool()
+    m = ag.dictionary_sizes()[0, 0]
+    assert m == 128 and p['pool_full'] == 1 and p['saturated'] == 1, (m, p)   # shells 0 and 1 fit, shell 2 does not
+    ag.synchronize()
+    with pytest.raises(_lib.RanSliceError):
+        VecKBRL(64, [10] * 5, 200, capacity=1024, pool_bytes=1 << 20)     # not even one shell per dictionary
+    ag.close()

@@ -163,24 +163,32 @@ def _g14(rh, tape, save):
          kinv_probes=dg['probes'], kinv_kp=dg['kp'])
 
 
-def _g15(rh, tape, save):
-    """G15: KBRL_Control teacher-forced over 2,200 steps of scenario_0 on 10,000-column tapped-delay-line traces
-    (ranslice.fading.synth_fading_tdl), the length at which dictionaries hold several hundred landmarks"""
+def _long_control(rh, tape, save, name, profile, seed):
     import tempfile
     from ranslice.fading import synth_traces
-    rh.setup(tempfile.mkdtemp(prefix='refwork_g15_'), synth_traces(10000, 'tdl'))
-    out = _run_agent(rh, tape, 0, seed=5, steps=2200, a_range=[0.99, 0.999])
-    for k in ('tape_kind', 'tape_val'):
-        pass
+    rh.setup(tempfile.mkdtemp(prefix='refwork_%s_' % name), synth_traces(10000, profile))
+    out = _run_agent(rh, tape, 0, seed=seed, steps=2200, a_range=[0.99, 0.999])
     # only the tie-break draws of the agent are needed by the teacher-forced replay (the simulator is not replayed)
     ties = out['tape_val'][out['tape_kind'] == 6]
-    drop = ('tape_kind', 'tape_val', 'reward')
-    out = {k: v for k, v in out.items() if k not in drop}
+    out = {k: v for k, v in out.items() if k not in ('tape_kind', 'tape_val', 'reward')}
     out['ties'] = ties
     out['acc'] = out['acc'][-1:]          # the accuracy tables of the last step only
     for k in ('action_in', 'labels', 'hits', 'action_out', 'margins', 'security', 'set_size', 'violation', 'adjusted'):
         out[k] = out[k].astype(np.int16)
-    save('g15_kbrl_long_s0', **out)
+    out['profile'] = np.array(profile)
+    save(name, **out)
+
+
+def _g15(rh, tape, save):
+    """G15: KBRL_Control teacher-forced over 2,200 steps of scenario_0 on the 10,000-column traces of the first
+    synthetic profile (deep, flat fades: the regime in which dictionaries grow to several hundred landmarks)"""
+    _long_control(rh, tape, save, 'g15_kbrl_long_s0', 'sos', 5)
+
+
+def _g16(rh, tape, save):
+    """G16: the same on the tapped-delay-line traces (ranslice.fading.synth_fading_tdl), the regime closer to the
+    paper's: few violations, small dictionaries"""
+    _long_control(rh, tape, save, 'g16_kbrl_long_tdl_s0', 'tdl', 5)
 
 
 def generate(rh, tape, save):
@@ -194,3 +202,5 @@ def generate_long(rh, tape, save, which):
         _g14(rh, tape, save)
     if 'G15' in which:
         _g15(rh, tape, save)
+    if 'G16' in which:
+        _g16(rh, tape, save)
