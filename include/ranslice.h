@@ -174,6 +174,8 @@ int rs_get_section_profile(rs_handle* h, uint64_t out[16]);
 int rs_get_task_profile(rs_handle* h, uint64_t* out);
 
 int rs_synchronize(rs_handle* h);
+/* HIP devices visible to this process, or RS_EHIP */
+int rs_device_count(void);
 int rs_n_vars(const rs_handle* h);
 int rs_n_slices(const rs_handle* h);
 const char* rs_last_error(const rs_handle* h);
@@ -263,6 +265,12 @@ int kb_comm_unique_id(void* id128);
 int kb_comm_init(kb_handle* k, const void* id128, int rank, int world);
 int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t budget,
                    int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
+/* The merge of kb_shared_step on a caller-supplied gathered buffer (what ncclAllGather delivers): `world` blocks of
+ * [S proposer counts][S][budget][KB_PROP_WIDTH] doubles -> merged proposals [S][budget][KB_PROP_WIDTH], their counts [S],
+ * how many of rank `me`'s made it [S], and the proposers of all ranks.  Lets a single process check the device merge
+ * for any world size against the host rule (ranslice.kbrl_dev.merge_proposals). */
+int kb_shared_merge(kb_handle* k, const double* gathered, int32_t world, int32_t me, int32_t budget, double* merged,
+                    int32_t* counts, int32_t* taken, int32_t* total);
 
 /* Histories of KBRL_Control.run (kbrl_control.py:119-124,135-141) kept on the device: after kb_history_begin(steps)
  * every kb_step_resident records one column per replica -- reward f64, resources (sum of the newly selected action),

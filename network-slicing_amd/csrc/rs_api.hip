@@ -542,6 +542,11 @@ extern "C" void rs_destroy(rs_handle* h) {
 extern "C" const char* rs_last_error(const rs_handle* h) { return h ? h->err.c_str() : "null handle"; }
 extern "C" int rs_n_vars(const rs_handle* h) { return h ? h->n_vars : RS_EINVAL; }
 extern "C" int rs_n_slices(const rs_handle* h) { return h ? h->n_slices : RS_EINVAL; }
+/* HIP devices visible to this process (a launcher picks `device = local_rank % rs_device_count()`) */
+extern "C" int rs_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : RS_EHIP;
+}
 
 // ------------------------------------------------------------------ fading tables
 

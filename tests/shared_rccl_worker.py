@@ -46,7 +46,9 @@ def main():
     rank, world, id_file, n, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
     ia, sf, seq = batch(n * world, steps)
     lo, hi = rank * n, (rank + 1) * n
-    agent = SharedVecKBRL(n, [10] * 5, 200, capacity=256, budget=16, max_rounds=3, first_env=lo)
+    from ranslice import _lib
+    device = rank % _lib.device_count()       # one GPU per rank where the box has them
+    agent = SharedVecKBRL(n, [10] * 5, 200, capacity=256, budget=16, max_rounds=3, first_env=lo, device=device)
     if world > 1 or os.environ.get('RCCL_WORLD1'):
         if rank == 0:
             uid = SharedVecKBRL.unique_id()
@@ -69,7 +71,7 @@ def main():
         a, _ = agent.select_action(nxt[lo:hi])
         acts.append(a)
     d, sizes = digest(agent)
-    print('RESULT %d %s %s %s' % (rank, d, sizes, hashlib.sha256(np.stack(acts).tobytes()).hexdigest()), flush=True)
+    print('RESULT %d %s %s %s device=%d' % (rank, d, sizes, hashlib.sha256(np.stack(acts).tobytes()).hexdigest(), device), flush=True)
     agent.close()
 
 

@@ -200,3 +200,55 @@ def test_graph_replay_equals_stepwise_full_size():
         outs.append((f['obs'].tobytes(), f['reward'].tobytes(), f['violations'].tobytes(), env.l1_info().tobytes()))
         env.close()
     assert outs[0] == outs[1]
+
+
+def test_config5_per_gpu_shard_graph_loop_vs_oracle():
+    """BASELINE config 5's per-GPU shard (65,536 replicas / 8 GPUs = 8,192 per GPU) in its loop form: the scripted loop
+    replayed from a captured hipGraph (rs_run_random(graph=True)), checked against the oracle on sampled replicas --
+    among them the shard's last ones and replicas on both sides of the 4,096 boundary -- after 60, 61 and 121 steps:
+    observations (f32 bits), rewards, labels, violations and the info sums (f64 bits).  The replica ids are those of
+    rank 3 of the 8-GPU run (global ids 24,576..32,767), so the seeds are the ones that rank would use."""
+    from ranslice.vec_env import VecRanSlice
+    n, rank = 8192, 3
+    first = rank * n
+    sample = [0, 1, 17, 63, 64, 1000, 4095, 4096, 4097, 6000, 8190, 8191]
+    marks = (60, 61, 121)
+    cfg = make_config(0, n_envs=n)
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
+        fut = ex.map(_oracle_script_run_ids, [(0, replica_seed(0, first + r), r, marks[-1], COLS, ACTION_SEED + rank)
+                                              for r in sample], chunksize=1)
+        env = VecRanSlice(n_envs=n, cfg=cfg, fading=_fading())
+        env.reset(seeds=replica_seeds(0, first, n))
+        hip = {}
+        done = 0
+        for mk in marks:
+            env.run_random(ACTION_SEED + rank, done, mk - done, graph=True)   # bench.py's per-rank script seed
+            done = mk
+            f = env.fetch()
+            hip[mk] = (f['actions'][sample].copy(), f['obs'][sample].copy(), f['reward'][sample].copy(),
+                       f['labels'][sample].copy(), f['violations'][sample].copy(), env.l1_info()[sample].copy())
+        env.close()
+        ref = list(fut)
+    for k, r in enumerate(sample):
+        for mk in marks:
+            a, obs, rew, lab, viol, info = ref[k][mk - 1]
+            h = hip[mk]
+            assert (h[0][k] == a).all(), ('actions', r, mk)
+            assert h[1][k].tobytes() == obs.tobytes(), ('obs', r, mk)
+            assert h[2][k] == rew and (h[3][k] == lab).all() and (h[4][k] == viol).all(), ('reward/labels', r, mk)
+            assert h[5][k].tobytes() == info.tobytes(), ('info', r, mk)
+
+
+def _oracle_script_run_ids(args):
+    """as _oracle_script_run with the script seed given (a rank's own seed) and the replica's LOCAL index in it"""
+    scenario, seed, replica, steps, cols, action_seed = args
+    cfg = make_config(scenario, n_envs=1)
+    o = po.OracleEnv(cfg, [synth_fading(t, cols) for t in range(3)])
+    o.set_seed(seed)
+    o.reset()
+    out = []
+    for i in range(steps):
+        a = po.random_actions(cfg, action_seed, i, replica)
+        r = o.step(a)
+        out.append((a, r['obs'].copy(), r['reward'], r['labels'].copy(), r['violations'].copy(), r['info'].copy()))
+    return out

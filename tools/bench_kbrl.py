@@ -15,7 +15,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
 import numpy as np  # noqa: E402
 from ranslice.config import make_config, EMBB_A, EMBB_SEC  # noqa: E402
-from ranslice.fading import synth_fading  # noqa: E402
+from ranslice.fading import synth_traces  # noqa: E402
 from ranslice.kbrl_dev import VecKBRL  # noqa: E402
 from ranslice.vec_env import VecRanSlice  # noqa: E402
 
@@ -25,12 +25,15 @@ def main():
     ap.add_argument('--envs', type=int, default=4096)
     ap.add_argument('--steps', type=int, default=300)
     ap.add_argument('--warmup', type=int, default=100)
-    ap.add_argument('--capacity', type=int, default=256)
+    ap.add_argument('--capacity', type=int, default=4096)
+    ap.add_argument('--pool-gb', type=float, default=64.0)
+    ap.add_argument('--profile', default='sos', help='synthetic trace profile: sos | tdl')
     args = ap.parse_args()
     N = args.envs
     cfg = make_config(0, n_envs=N)
-    env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, 10000) for t in range(3)])
-    agent = VecKBRL(N, [10] * 5, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=args.capacity)
+    env = VecRanSlice(n_envs=N, cfg=cfg, fading=synth_traces(10000, args.profile))
+    agent = VecKBRL(N, [10] * 5, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=args.capacity,
+                    pool_bytes=int(args.pool_gb * 2 ** 30))
     rng = np.random.default_rng(0)
     ia = rng.integers(EMBB_A[0], EMBB_A[1], size=(N, 5)).astype(np.int32)   # scenario_creator.py:220-221
     sf = rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, 5)).astype(np.int32)
@@ -57,14 +60,16 @@ def main():
     env_ms, _ = env.kernel_time_ms()
     out = env.fetch()
     evals = s1[3] - s0[3]
-    m = [agent.learner(e, s)['m'] for e in range(0, N, max(1, N // 16)) for s in range(5)]
+    sizes = agent.dictionary_sizes()
+    pool = agent.pool()
     print(json.dumps({
         'config': 'scenario_0, %d envs + KBRL agent per env, closed loop on device, dictionary capacity %d' % (N, args.capacity),
         'env_steps_per_s': N * args.steps / dt, 'ms_per_step': 1e3 * dt / args.steps,
         'embb_kernel_ms': env_ms, 'kb_kernel_ms_mean_of_update_and_select': kb_ms, 'kb_launches': kb_n,
         'kernel_evaluations_per_s': evals / dt, 'predicts_per_env_step': (s1[0] - s0[0]) / (N * args.steps),
         'mistakes_per_env_step': (s1[1] - s0[1]) / (N * args.steps),
-        'mean_dictionary_size_sample': float(np.mean(m)), 'max_dictionary_size_sample': int(np.max(m)),
+        'dictionary_size_mean': float(sizes.mean()), 'dictionary_size_max': int(sizes.max()),
+        'dictionary_size_p50_p90_p99': [float(np.percentile(sizes, q)) for q in (50, 90, 99)], 'pool': pool,
         'mean_action_sum': float(out['actions'].sum(axis=1).mean()),
         'violations_per_env_step_last': float(out['violations'].sum(axis=1).mean()),
     }))
