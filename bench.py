@@ -28,8 +28,10 @@ The JSON line also carries
                  reference on golden tapes) timed on this box's host cores on a bounded sample of
                  the same workload -- a reported baseline, never the thing measured above;
   kbrl         : (1 GPU) BASELINE config 3 -- the same 4096 replicas with one KBRL agent each, closed loop on
-                 the device: env-steps/s, RBF kernel evaluations/s, the flop rate of the scoring against the
-                 78.6 TFLOP/s f64 peak.
+                 the device, at two points of learning: steps 100-300 (dictionaries of tens of landmarks) and from
+                 step 3000 (hundreds): env-steps/s, per-phase kernel times, kernel evaluations/s, dictionary sizes
+                 and the pool in use.
+  python bench.py --scaling 1,2,4,8 prints ONE line with the curve over N and the CPU baseline.
 """
 import argparse
 import json
@@ -56,10 +58,10 @@ F64_PEAK_TFLOPS = 78.6     # MI355X f64 vector / matrix peak
 BURN_BLOCK = 500
 BURN_MAX = 8000
 
-# bytes of persistent simulator state the step kernel reads and writes per task / per active UE
-# (network-slicing_amd/csrc/rs_device.h): header 5 x 4 B; UE 3 f64 + 9 i32 + 8 burst i32
-STATE_TASK_BYTES = 20
-STATE_UE_BYTES = 3 * 8 + 9 * 4 + 8 * 4
+# bytes of persistent simulator state the step kernel reads and writes per task / per active UE (DESIGN.md §3,
+# network-slicing_amd/csrc/rs_device.h): task header 6 x 4 B; UE 3 f64 + 9 i32 + 16 u16 burst end-time codes = 92 B
+STATE_TASK_BYTES = 6 * 4
+STATE_UE_BYTES = 3 * 8 + 9 * 4 + 16 * 2
 
 
 def _cpu_worker(args):
@@ -139,81 +141,143 @@ def _free_port():
     return p
 
 
-def kbrl_record(n_envs, device, steps, warmup):
-    """BASELINE config 3 on this GPU: closed loop with one KBRL agent per replica (kb_step_resident)."""
+KBRL_CAPACITY = 4096          # a limit, not a reservation: dictionaries take their storage from the pool as they grow
+KBRL_POOL_BYTES = 64 << 30
+KBRL_LATE_STEP = 3000         # second measurement point: dictionaries of several hundred landmarks
+
+
+def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
+    """BASELINE config 3 on this GPU: closed loop with one KBRL agent per replica (kb_step_resident), measured twice:
+    early in learning (steps `warmup`..`warmup + steps`, the point of rounds 1-2) and from step `late_step` on, where the
+    dictionaries hold what a run of that length holds."""
     import ctypes as C
-    from ranslice import _lib
     from ranslice.config import make_config, EMBB_A, EMBB_SEC
-    from ranslice.fading import synth_fading
+    from ranslice.fading import synth_traces
     from ranslice.kbrl_dev import VecKBRL
     from ranslice.vec_env import VecRanSlice
+    profile = os.environ.get('KBRL_TRACES', 'sos')        # (developer knob) synthetic trace profile of this leg
+    cap = int(os.environ.get('KBRL_CAPACITY', KBRL_CAPACITY))
     cfg = make_config(SCENARIO, n_envs=n_envs)
-    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=[synth_fading(t, FADING_COLS) for t in range(3)], device=device)
-    agent, capacity = None, None
-    for cap in ([int(os.environ['KBRL_CAPACITY'])] if os.environ.get('KBRL_CAPACITY') else [1024, 512, 256]):  # (developer knob)
-        try:
-            agent = VecKBRL(n_envs, [10] * cfg.n_embb, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=cap,
-                            device=device)
-            capacity = cap
-            break
-        except _lib.RanSliceError:
-            agent = None
-    if agent is None:
-        env.close()
-        return None
+    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=synth_traces(FADING_COLS, profile), device=device)
+    agent = VecKBRL(n_envs, [10] * cfg.n_embb, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=cap, device=device,
+                    pool_bytes=KBRL_POOL_BYTES)
     rng = np.random.default_rng(0)
     ia = rng.integers(EMBB_A[0], EMBB_A[1], size=(n_envs, cfg.n_embb)).astype(np.int32)   # scenario_creator.py:220-221
     sf = rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(n_envs, cfg.n_embb)).astype(np.int32)
     env.reset()
     agent.reset(ia, sf)
     env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+    done = [0]
 
     def run(k):
         for _ in range(k):
             agent.step_resident(env)
             env.step_resident()
-    run(warmup)
-    env.synchronize()
-    agent.synchronize()
-    s0 = agent.stats()
-    agent.set_kernel_timing(True)
-    env.set_kernel_timing(True)
-    t0 = time.perf_counter()
-    run(steps)
-    env.synchronize()
-    agent.synchronize()          # also raises if any dictionary overflowed its capacity
-    dt = time.perf_counter() - t0
-    s1 = agent.stats()
-    kb_ms, kb_n = agent.kernel_time_ms()
-    env_ms, _ = env.kernel_time_ms()
-    sizes = agent.dictionary_sizes()
-    evals = s1[3] - s0[3]
+        done[0] += k
     d = 11   # eMBB learner: 10 state variables + the candidate allocation
-    flops = evals * (3 * d + 3)   # SURVEY.md 8d: distance 3d + 1, exp counted as 1, k.coeff 2  (per landmark x candidate)
+
+    def point(k):
+        env.synchronize()
+        agent.synchronize()
+        s0 = agent.stats()
+        agent.set_kernel_timing(True)
+        env.set_kernel_timing(True)
+        first = done[0]
+        t0 = time.perf_counter()
+        run(k)
+        env.synchronize()
+        agent.synchronize()          # raises on a device-side error flag
+        dt = time.perf_counter() - t0
+        s1 = agent.stats()
+        ph = agent.phase_times_ms()
+        env_ms, _ = env.kernel_time_ms()
+        agent.set_kernel_timing(False)
+        env.set_kernel_timing(False)
+        sizes = agent.dictionary_sizes()
+        evals = s1[3] - s0[3]
+        # what the table-factorised scoring actually executes per (landmark, candidate) pair: one FMA + one LDS read
+        # (2 flop); per landmark and pass one exp and the 3 (d - 1) flop of its distance.  SURVEY.md 8d's model -- the
+        # (3 d + 3) flop of a direct evaluation per pair -- is kept beside it for comparison with rounds 1-2.
+        passes = 2.0 + (s1[1] - s0[1]) / float(n_envs * cfg.n_embb * k)   # update pass, select pass, one per repair
+        exps = passes * float(sizes.sum()) * k
+        return {
+            'steps': [first, first + k], 'value': n_envs * k / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / k,
+            'embb_kernel_ms': env_ms, 'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
+            'kernel_evaluations_per_s': evals / dt, 'exps_per_s_estimate': exps / dt,
+            'predicts_per_env_step': (s1[0] - s0[0]) / (n_envs * k),
+            'mistakes_per_env_step': (s1[1] - s0[1]) / (n_envs * k),
+            'direct_model_tflops': evals * (3 * d + 3) / dt / 1e12,
+            'direct_model_frac_of_f64_peak': evals * (3 * d + 3) / dt / 1e12 / F64_PEAK_TFLOPS,
+            'dictionary_size_mean': float(np.mean(sizes)), 'dictionary_size_max': int(np.max(sizes)),
+            'dictionary_size_p50_p90_p99': [float(np.percentile(sizes, q)) for q in (50, 90, 99)],
+            'pool': agent.pool(),
+        }
+    run(warmup)
+    early = point(steps)
+    late = None
+    if late_step and late_step > done[0]:
+        run(late_step - done[0])
+        late = point(steps)
     rec = {
-        'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device, steps %d-%d of '
-                    'learning' % (n_envs, warmup, warmup + steps),
-        'dictionary_capacity': capacity,
-        'value': n_envs * steps / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / steps,
-        'embb_kernel_ms': env_ms, 'kb_kernel_ms_mean_of_update_and_select': kb_ms,
-        'kernel_evaluations_per_s': evals / dt,
-        'predicts_per_env_step': (s1[0] - s0[0]) / (n_envs * steps),
-        'mistakes_per_env_step': (s1[1] - s0[1]) / (n_envs * steps),
-        'flops_model': '(3 d + 3) flop per kernel evaluation, d = 11 (SURVEY.md 8d)',
-        'achieved_tflops': flops / dt / 1e12, 'peak_tflops_f64': F64_PEAK_TFLOPS,
-        'frac_of_f64_peak': flops / dt / 1e12 / F64_PEAK_TFLOPS,
-        'dictionary_size_mean': float(np.mean(sizes)), 'dictionary_size_max': int(np.max(sizes)),
+        'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device (%s traces)'
+                    % (n_envs, profile),
+        'dictionary_capacity': cap, 'pool_bytes': KBRL_POOL_BYTES,
+        'value': early['value'], 'unit': 'env-steps/s', 'ms_per_step': early['ms_per_step'],
+        'early': early, 'late': late,
+        'scoring': 'k(l_j, x_c) = E_j G[|a_j - c|]: one exp per landmark and pass, one FMA + one LDS read per (landmark, '
+                   'candidate); no MFMA in these kernels (a one-column product; DESIGN.md §4 KBRL)',
+        'peak_tflops_f64': F64_PEAK_TFLOPS,
     }
     ppath = os.path.join(ROOT, 'profiles', 'kbrl_mfma_share.json')
     if os.path.exists(ppath):
         try:
             with open(ppath) as f:
-                rec['profiled_mfma_share'] = json.load(f)
+                rec['profiled_counters'] = json.load(f)
         except Exception:
             pass
     env.close()
     agent.close()
     return rec
+
+
+def run_scaling(args):
+    """--scaling 1,2,4,8: the whole report from one command -- the CPU baseline once, then this script once per N (each
+    an independent launch: N = 1 in a child process, N > 1 through the launcher), one JSON line with the curve.  Ns
+    beyond the devices of the box are listed as skipped."""
+    from ranslice import _lib
+    ns = [int(x) for x in args.scaling.split(',') if x]
+    ndev = _lib.device_count()
+    cpu = None if args.no_cpu_baseline else cpu_baseline(1000, args.cpu_steps)
+    curve = []
+    for n in ns:
+        if n > ndev:
+            curve.append({'n_gpus': n, 'skipped': 'the box has %d GPU(s)' % ndev})
+            continue
+        cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(n), '--steps', str(args.steps), '--warmup',
+               str(args.warmup), '--envs-per-gpu', str(args.envs_per_gpu), '--no-cpu-baseline', '--no-kbrl']
+        if args.burn_in >= 0:
+            cmd += ['--burn-in', str(args.burn_in)]
+        if args.graph:
+            cmd += ['--graph']
+        env = dict(os.environ)
+        for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+            env.pop(k, None)
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+        lines = [x for x in out.stdout.splitlines() if x.startswith('{')]
+        if out.returncode != 0 or not lines:
+            curve.append({'n_gpus': n, 'error': 'rc %d' % out.returncode})
+            continue
+        line = json.loads(lines[-1])
+        curve.append({'n_gpus': n, 'value': line['value'], 'ms_per_step': line['ms_per_step'],
+                      'roofline_frac': line['roofline']['frac'], 'kernel_ms': line['roofline']['kernel_ms'],
+                      'global_envs': line['config']['global_envs']})
+    base = next((c['value'] for c in curve if c.get('n_gpus') == 1 and 'value' in c), None)
+    for c in curve:
+        if base and 'value' in c:
+            c['per_gpu_vs_1gpu'] = c['value'] / c['n_gpus'] / base
+    print(json.dumps({'metric': 'env-steps/sec (batched RanSlice.step, scenario_0)', 'unit': 'env-steps/s',
+                      'scaling': 'weak', 'curve': curve, 'cpu_baseline': cpu, 'dtype': 'f64', 'data': 'synthetic'}),
+          flush=True)
 
 
 def main():
@@ -232,7 +296,12 @@ def main():
                          'roofline is then taken from a separate event-timed pass of 100 steps')
     ap.add_argument('--cpu-steps', type=int, default=3000)
     ap.add_argument('--cpu-baseline-json', default=None, help=argparse.SUPPRESS)
+    ap.add_argument('--scaling', default='', help='e.g. 1,2,4,8: run every N in turn and print ONE line with the curve and '
+                                                  'the CPU baseline (Ns beyond the devices of the box are skipped)')
     args = ap.parse_args()
+    if args.scaling:
+        run_scaling(args)
+        return
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -288,6 +288,9 @@ int kb_get_sizes(kb_handle* k, int32_t* m);
  * exhausted (both keep learning by projection -- build-defined, the reference's SVvariable is unbounded; any may be NULL) */
 int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_bytes, int32_t* n_saturated, int32_t* n_pool_full);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
+/* the same per phase: ms[0] / n[0] the update phase (update_control_kernel and its repair kernels; shared mode: the scan
+ * kernels), ms[1] / n[1] select_kernel */
+int kb_phase_times_ms(kb_handle* k, double ms[2], int64_t n[2]);
 int kb_set_kernel_timing(kb_handle* k, int enable);
 /* waits for the agent's stream and reports an internal error flag raised by any kernel since kb_reset (the
  * device-resident loop kb_step_resident does not check on its own); dictionaries at capacity are not errors (kb_get_pool) */

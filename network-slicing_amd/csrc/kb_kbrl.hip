@@ -9,7 +9,7 @@
 // a POOL shared by all dictionaries of the handle and grows 64 landmarks at a time, like the reference's np.vstack /
 // np.append / np.column_stack do one landmark at a time (projectron.py:17-21,52-57): when landmark 64 b arrives the
 // learner's own workgroup takes "shell" b from a bump allocator --
-//     [ vector page: 22 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
+//     [ vector page: 30 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
 //     [ 2 b + 1 tiles of 64 x 64 doubles  ]  Kinv tiles (b,0) .. (b,b), then (0,b) .. (b-1,b)
 // and records its pool offset in the dictionary's shell table.  Nothing is ever moved or freed before kb_reset, so
 // the capacity is bounded by the pool (device memory), not by a per-learner reservation: a handle of 4096 x 5
@@ -48,8 +48,14 @@ namespace kb {
 #define KB_ROW_KF 19      //   kernel column K_f of the sample being learned (also Projectron's cached K_f, projectron.py:34)
 #define KB_ROW_DS 20      //   d* = Kinv K_f
 #define KB_ROW_IDX 21     //   64 x int32 grid index a_j of the last coordinate (-1: off the grid), 64 x int32 chain link
-#define KB_VEC_ROWS 22
+#define KB_ROW_PART 22    //   8 rows: the partial sums of d* over the row classes j mod 8 (matvec_colsum)
+#define KB_VEC_ROWS 30
 #define KB_VEC (KB_VEC_ROWS * KB_CH)
+#ifndef KB_OCC
+#define KB_OCC 4        // waves per SIMD the one-wave kernels are built for
+#endif
+#define KB_SMALL_M 192     // dictionaries below this repair their mistakes on one wave, larger ones on a workgroup
+#define KB_HEAVY_THREADS 512
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 
 typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
@@ -63,6 +69,7 @@ struct KbDev {
     int32_t shared;   // 1: one dictionary per slice shared by all replicas (build-defined extension)
     int32_t first_env; // global id of local replica 0 (shared mode proposals carry global ids)
     int32_t serial_apply; // shared mode: apply a full dictionary's proposals one by one as well (KBRL_SERIAL_APPLY, tests)
+    int32_t heavy_m;      // dictionaries of this many landmarks repair their mistakes in update_heavy_kernel
     uint64_t pool_doubles;
 };
 
@@ -88,6 +95,8 @@ struct KbState {
     double* acc;       // [n_envs][S][n_prbs]
     int32_t* err;      // [n_envs]  bit 8: a dictionary is at its capacity, bit 16: the pool is exhausted
     uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
+    int32_t* heavy;    // [4 + T]: large learners queued, next to take, small learners queued, -; then the task ids (large
+                       // from the front, small from the back)
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
 };
 
@@ -140,6 +149,7 @@ struct Lds {
     double G[KB_GTAB];
     double x[KB_DMAX];
     double red[16];
+    double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
     int ired[8];
 };
 
@@ -228,6 +238,26 @@ __device__ __forceinline__ double dist0(const double* P, int lane, int d, const 
 // MODE 0: compute D0 / E for the state in sm.x and keep them in the dictionary's rows (the learner owns its dictionary)
 // MODE 1: reuse the E row (same state, coefficients may have changed)
 // MODE 2: compute E, store nothing (shared dictionaries: many learners read the same pages)
+// the rows of one chunk a scoring pass needs, loaded one chunk ahead of their use
+template <int MODE>
+struct ChunkRows {
+    double v[MODE == 1 ? 1 : 10];  // MODE 1: E; else the first ten coordinates (eMBB learners) for D0
+    double co, lam;
+    int a;
+};
+template <int MODE>
+__device__ __forceinline__ void load_chunk(const double* P, int lane, int d, ChunkRows<MODE>& R) {
+    if (MODE == 1) {
+        R.v[0] = P[KB_ROW_E * KB_CH + lane];
+    } else if (d - 1 == 10) {
+#pragma unroll
+        for (int q = 0; q < 10; ++q) R.v[q] = P[q * KB_CH + lane];
+    }
+    R.co = P[KB_ROW_CO * KB_CH + lane];
+    R.a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
+    R.lam = P[(d - 1) * KB_CH + lane];
+}
+
 template <int NG, int MODE>
 __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm,
                                            int g0, double (&f)[NG]) {
@@ -240,25 +270,36 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
     }
     const int nch = (m + 63) >> 6;
     const char* Gb = (const char*)sm.G;
+    ChunkRows<MODE> R, Rn;
+    load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
     for (int b = 0; b < nch; ++b) {
         double* P = vec_page(K, sh, b);
+        R = Rn;
+        if (b + 1 < nch) load_chunk<MODE>(vec_page(K, sh, b + 1), lane, d, Rn);
         const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
         double E;
         if (MODE == 1) {
-            E = P[KB_ROW_E * KB_CH + lane];
+            E = R.v[0];
         } else {
-            const double d0 = dist0(P, lane, d, sm.x);
+            double d0 = 0.0;
+            if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82)
+#pragma unroll
+                for (int q = 0; q < 10; ++q) {
+                    const double t = R.v[q] - sm.x[q];
+                    d0 += t * t;
+                }
+            } else {
+                d0 = dist0(P, lane, d, sm.x);
+            }
             E = rs_exp_nonpos(-D.gamma * d0);
             if (MODE == 0) {
                 P[KB_ROW_D0 * KB_CH + lane] = d0;
                 P[KB_ROW_E * KB_CH + lane] = E;
             }
         }
-        const double co = P[KB_ROW_CO * KB_CH + lane];
-        const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
-        const double lam = P[(d - 1) * KB_CH + lane];
-        const double w = lane < cnt ? co * E : 0.0;
-        const int a8 = lane < cnt ? a * 8 : 0;
+        const double lam = R.lam;
+        const double w = lane < cnt ? R.co * E : 0.0;
+        const int a8 = lane < cnt ? R.a * 8 : 0;
         // lanes past the end of the dictionary carry w = 0 on the grid: the loop may run to the next multiple of four
         for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
 #pragma unroll
@@ -387,40 +428,59 @@ __device__ __forceinline__ void kernel_column_full(const KbDev& D, const KbState
     __syncthreads();
 }
 
-// d* = Kinv K_f -> DS row.  Kinv is symmetric bit for bit (it only ever receives (d_i d_j) / delta), so the thread that
-// owns output i walks COLUMN i: rows j = 0, 1, ... of the tiles (b_j, b_i), coalesced across the threads of a wave, one
-// sequential sum per output and no cross-lane reduction.  The order does not depend on the block size.
+// d* = Kinv K_f -> DS row.  Kinv is symmetric bit for bit (it only ever receives (d_i d_j) / delta), so output i is
+// summed down COLUMN i: no cross-lane reduction, loads coalesced along the tile rows.  The sum of a column is formed in a
+// fixed shape that does not depend on the block size or on how many columns a lane owns: eight partial sums over the row
+// classes j mod 8 (each in increasing j, fused multiply-adds), then ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).
+// A work unit is (64 W columns, one row class); the waves of the block share the units, eight rows are in flight per
+// lane (W doubles each), and the partial sums meet in eight rows of the vector pages.
+template <int W>
 __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* sh, int m) {
-    const int nb = (m + 63) >> 6, nt = blockDim.x, lane = threadIdx.x & 63;
-    for (int i0 = threadIdx.x; i0 < nb * 64; i0 += nt * 4) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        int bi[4];
+    static_assert(W == 1 || W == 2 || W == 4, "columns per lane");
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ncg = (nb + W - 1) / W;  // groups of W column blocks
+    const int bsub = lane / (64 / W), coff = (lane % (64 / W)) * W;  // this lane's column block within the group, column in it
+    for (int u = wave; u < ncg * 8; u += nw) {
+        const int cg = u >> 3, sg = u & 7;
+        const int bi = cg * W + bsub;
+        const bool on = bi < nb;
+        double acc[W];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) bi[k] = (i0 + k * nt) >> 6;  // wave-uniform
+        for (int c = 0; c < W; ++c) acc[c] = 0.0;
         for (int bj = 0; bj < nb; ++bj) {
-            const int rows = m - 64 * bj < 64 ? m - 64 * bj : 64;
             const double kfv = vec_page(K, sh, bj)[KB_ROW_KF * KB_CH + lane];
-            const double* tp[4];
+            const double* tp = kinv_tile(K, sh, bj, on ? bi : 0) + coff;
+            const int rows = m - 64 * bj < 64 ? m - 64 * bj : 64;
+            double v[8][W];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) tp[k] = kinv_tile(K, sh, bj, bi[k] < nb ? bi[k] : 0) + lane;
-            for (int r0 = 0; r0 < rows; r0 += 4) {
+            for (int k = 0; k < 8; ++k) {
+                const int r = sg + 8 * k;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + u;
-                    if (r < rows) {
-                        const double kfr = readlane_f64(kfv, r);
+                for (int c = 0; c < W; ++c) v[k][c] = (on && r < rows) ? tp[r * 64 + c] : 0.0;
+            }
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (bi[k] < nb) acc[k] = __builtin_fma(tp[k][r * 64], kfr, acc[k]);
-                    }
+            for (int k = 0; k < 8; ++k) {
+                const int r = sg + 8 * k;
+                if (r < rows) {
+                    const double kfr = readlane_f64(kfv, r);
+#pragma unroll
+                    for (int c = 0; c < W; ++c) acc[c] = __builtin_fma(v[k][c], kfr, acc[c]);
                 }
             }
         }
+        if (on) {
+            double* o = vec_page(K, sh, bi) + (KB_ROW_PART + sg) * KB_CH + coff;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int i = i0 + k * nt;
-            if (i < m) *vec_at(K, sh, KB_ROW_DS, i) = acc[k];
+            for (int c = 0; c < W; ++c) o[c] = acc[c];
         }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double* P = vec_page(K, sh, i >> 6) + (i & 63);
+        const double p0 = P[(KB_ROW_PART + 0) * KB_CH], p1 = P[(KB_ROW_PART + 1) * KB_CH], p2 = P[(KB_ROW_PART + 2) * KB_CH],
+                     p3 = P[(KB_ROW_PART + 3) * KB_CH], p4 = P[(KB_ROW_PART + 4) * KB_CH], p5 = P[(KB_ROW_PART + 5) * KB_CH],
+                     p6 = P[(KB_ROW_PART + 6) * KB_CH], p7 = P[(KB_ROW_PART + 7) * KB_CH];
+        P[KB_ROW_DS * KB_CH] = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
     }
     __syncthreads();
 }
@@ -461,7 +521,10 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         dot = (double)(float)(ds * kf0);
         __syncthreads();
     } else {
-        matvec_colsum(K, sh, m);
+        if (blockDim.x >= 256)
+            matvec_colsum<4>(K, sh, m);
+        else
+            matvec_colsum<2>(K, sh, m);
         if (threadIdx.x < 64) {
             const double v = wave_dot256_rows(K, sh, KB_ROW_DS, KB_ROW_KF, m);
             if (threadIdx.x == 0) sm.red[15] = v;
@@ -528,21 +591,28 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         const int m1 = m + 1, nb = (m1 + 63) >> 6;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
         const double inv = 1.0 / delta;
-        // one tile row per wave per step: d_i broadcast from the row block's lanes, d_j in this lane
-        for (int tb = 0; tb < nb * nb; ++tb) {
+        // a work unit is 16 rows of a tile: all 16 loads of a lane are in flight before the first store (d_i broadcast
+        // from the row block's lanes, d_j in this lane)
+        for (int u = wave; u < nb * nb * 4; u += nw) {
+            const int tb = u >> 2, r0 = (u & 3) * 16;
             const int bi = tb / nb, bj = tb - bi * nb;
-            double* T = kinv_tile(K, sh, bi, bj);
+            const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
+            const int j = 64 * bj + lane;
+            if (r0 >= rows) continue;  // (wave-uniform)
+            double* T = kinv_tile(K, sh, bi, bj) + lane;
             const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
             const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
-            const int j = 64 * bj + lane;
-            const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
-            for (int r = wave; r < rows; r += nw) {
-                const int i = 64 * bi + r;
+            double old[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = r0 + k, i = 64 * bi + r;
+                old[k] = (r < rows && i < m && j < m) ? T[r * 64] : 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int r = r0 + k;
                 const double dsi = readlane_f64(dsi_v, r);
-                if (j < m1) {
-                    const double old = (i < m && j < m) ? T[r * 64 + lane] : 0.0;
-                    T[r * 64 + lane] = old + (dsi * dsj) * inv;
-                }
+                if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) * inv;
             }
         }
     }
@@ -605,8 +675,97 @@ __device__ __forceinline__ void stage_state(const KbDev& D, const float* state, 
     if ((int)threadIdx.x < d - 1) sm.x[threadIdx.x] = (double)state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
 }
 
-// KBRL_Control.update_control for one learner (kbrl_control.py:83-112): one wave
-__global__ __launch_bounds__(64) void update_control_kernel(CtlArgs A) {
+// The augmentation loop of update_control (kbrl_control.py:102-112) from candidate c_from on, given the scores f of all
+// candidates: find the next mistake in order, apply that one Projectron update, rescore, repeat.  Runs on the whole
+// block: the scoring passes are wave 0's (its lanes are the candidates) and are handed to the other waves through LDS,
+// the Projectron update (mat-vec, rank-1 update) is shared by all threads.
+struct LoopStats {
+    uint64_t n_pred, n_mist, n_grow, n_eval;
+};
+
+__device__ __forceinline__ void share_scores(double (&f)[4], Lds& sm) {
+    if (blockDim.x == 64) return;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sm.fbuf[g * 64 + threadIdx.x] = f[g];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) f[g] = sm.fbuf[g * 64 + (threadIdx.x & 63)];
+}
+
+__device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, double (&f)[4]) {
+    if (threadIdx.x < 64) score<4, 1>(D, K, sh, m, d, sm, 0, f);
+    share_scores(f, sm);
+}
+
+__device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, int task, int env, int dict, int m, int d, int y,
+                                            int c_from, int c_to, double (&f)[4], Lds& sm, LoopStats& st) {
+    const uint64_t* sh = shells_of(D, K, dict);
+    const int n = D.n_prbs;
+    while (c_from <= c_to) {
+        int zeros;
+        const int cstar = first_mistake(f, y, c_from, c_to, &zeros);
+        const int last = cstar < 0 ? c_to : cstar;
+        st.n_pred += (uint64_t)(last - c_from + 1);
+        // the predictions made on the way each consume a tie-break draw when f == 0 (Q11)
+        if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
+        if (cstar < 0) break;
+        st.n_mist += 1;
+        kernel_column_from_d0(D, K, sh, m, d, (double)cstar / (double)n);
+        int branch;
+        double delta;
+        bool saturated;
+        const int m_new = apply_update(D, K, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta, &saturated);
+        // A FULL dictionary that met a sample it would have added cannot represent this region: the remaining
+        // candidates would meet the same wall one O(m^2) projection at a time, so the augmentation of this learner
+        // stops for this step (build-defined; the reference's dictionary is unbounded; the oracle does the same)
+        if (saturated) break;
+        c_from = cstar + 1;
+        const uint64_t left = (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0);
+        if (branch == 2 && m_new > m && m >= 2) {
+            st.n_grow += 1;
+            // The dictionary grew by the landmark (state, c*/n) with coefficient y and nothing else changed: in the
+            // order the scores are summed it is one more term, E = 1 (same state).  The float32 regime of a
+            // single-landmark dictionary (kernel.py:16) keeps the full pass.
+            const int lane = threadIdx.x & 63;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                int o = cstar - (64 * g + lane);
+                o = o < 0 ? -o : o;
+                f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
+            }
+            st.n_eval += left;
+        } else {  // projection (every coefficient moved), or the first two landmarks
+            if (branch == 2 && m_new > m) st.n_grow += 1;
+            rescore(D, K, sh, m_new, d, sm, f);
+            st.n_eval += left * (uint64_t)m_new;
+        }
+        m = m_new;
+    }
+    return m;
+}
+
+__device__ __forceinline__ void flush_stats(const KbState& K, int task, int dict, int m, const LoopStats& st) {
+    if (threadIdx.x == 0) {
+        K.m[dict] = m;
+        if (st.n_mist) K.kf_owner[dict] = -1;  // the K_f row no longer holds a Projectron.predict's cache (Q12 guard)
+        uint64_t* o = K.stats + (size_t)task * 4;
+        o[0] += st.n_pred;
+        o[1] += st.n_mist;
+        o[2] += st.n_grow;
+        o[3] += st.n_eval;
+    }
+}
+
+// KBRL_Control.update_control for one learner (kbrl_control.py:83-112): one wave scores every candidate of the state,
+// does the accuracy bookkeeping and looks for the first mistake of the augmentation range.  Nine learners in ten have none
+// and are done.  The others are queued for update_heavy_kernel (a whole workgroup per learner for the O(m^2) Projectron
+// updates), which resumes exactly here; the INLINE instance keeps learners below D.heavy_m landmarks and repairs them
+// itself (one wave; KBRL_HEAVY_M, tests).
+template <bool INLINE>
+__global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel(CtlArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
@@ -620,70 +779,87 @@ __global__ __launch_bounds__(64) void update_control_kernel(CtlArgs A) {
     __syncthreads();
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
-    uint64_t n_pred = 0, n_mist = 0, n_grow = 0, n_eval = 0;
+    LoopStats st = {1, 0, 0, (uint64_t)m};
 
     // ---- the classifier on every candidate of this state (the augmentation range contains a_i)
     double f[4];
     score<4, 0>(D, K, sh, m, d, sm, 0, f);
-    n_pred += 1;
-    n_eval += (uint64_t)m;
     control_bookkeeping(D, K, task, env, s, m, f_of(f, a_i), y, A.hits, sm);
 
     // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
-    int c_from = y == 1 ? a_i : 0;
+    const int c_from = y == 1 ? a_i : 0;
     const int c_to = y == 1 ? n : a_i;
-    n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
-    while (c_from <= c_to) {
+    st.n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
+    if (!INLINE || m >= D.heavy_m) {
         int zeros;
-        const int cstar = first_mistake(f, y, c_from, c_to, &zeros);
-        const int last = cstar < 0 ? c_to : cstar;
-        n_pred += (uint64_t)(last - c_from + 1);
-        // the predictions made on the way each consume a tie-break draw when f == 0 (Q11)
-        if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
-        if (cstar < 0) break;
-        n_mist += 1;
-        kernel_column_from_d0(D, K, sh, m, d, (double)cstar / (double)n);
-        int branch;
-        double delta;
-        bool saturated;
-        const int m_new = apply_update(D, K, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta, &saturated);
-        // A FULL dictionary that met a sample it would have added cannot represent this region: the remaining
-        // candidates would meet the same wall one O(m^2) projection at a time, so the augmentation of this learner
-        // stops for this step (build-defined; the reference's dictionary is unbounded; the oracle does the same)
-        if (saturated) break;
-        c_from = cstar + 1;
-        if (branch == 2 && m_new > m) {
-            n_grow += 1;
-            // The dictionary grew by the landmark (state, c*/n) with coefficient y and nothing else changed: in the
-            // order the scores are summed it is one more term, E = 1 (same state).  The float32 regime of a
-            // single-landmark dictionary (kernel.py:16) keeps the full pass.
-            if (m >= 2) {
-                const int lane = threadIdx.x & 63;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    int o = cstar - (64 * g + lane);
-                    o = o < 0 ? -o : o;
-                    f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
+        if (first_mistake(f, y, c_from, c_to, &zeros) >= 0) {
+            if (threadIdx.x == 0) {
+                if (m >= KB_SMALL_M || INLINE) {
+                    const int slot = atomicAdd(&K.heavy[0], 1);
+                    K.heavy[4 + slot] = task;
+                } else {  // from the far end of the same array
+                    const int slot = atomicAdd(&K.heavy[2], 1);
+                    K.heavy[4 + D.n_envs * D.S - 1 - slot] = task;
                 }
-                n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0);
-            } else {
-                score<4, 1>(D, K, sh, m_new, d, sm, 0, f);
-                n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0) * (uint64_t)m_new;
             }
-        } else {  // projection: every coefficient moved
-            score<4, 1>(D, K, sh, m_new, d, sm, 0, f);
-            n_eval += (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0) * (uint64_t)m_new;
+            flush_stats(K, task, dict, m, st);
+            return;
         }
-        m = m_new;
     }
-    if (threadIdx.x == 0) {
-        K.m[dict] = m;
-        if (n_mist) K.kf_owner[dict] = -1;  // the K_f row no longer holds a Projectron.predict's cache (Q12 guard)
-        uint64_t* st = K.stats + (size_t)task * 4;
-        st[0] += n_pred;
-        st[1] += n_mist;
-        st[2] += n_grow;
-        st[3] += n_eval;
+    if (INLINE) {
+        m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, f, sm, st);
+    } else {  // no mistake anywhere in the range: the predictions of the whole range were made (their ties draw, Q11)
+        int zeros;
+        (void)first_mistake(f, y, c_from, c_to, &zeros);
+        st.n_pred += (uint64_t)(c_to - c_from + 1);
+        if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
+    }
+    flush_stats(K, task, dict, m, st);
+}
+
+// the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: one wave each, all at once
+// (update_small_kernel; the launch is as wide as the batch, workgroups beyond the queue leave at once); larger ones: a
+// workgroup of eight waves each, taken one at a time by persistent workgroups (update_heavy_kernel).
+__device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& sm) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    const int env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, n = D.n_prbs;
+    const int dict = dict_of(D, task);
+    const uint64_t* sh = shells_of(D, K, dict);
+    int m = K.m[dict];
+    stage_state(D, A.state, env, s, d, sm);
+    __syncthreads();
+    const int a_i = A.action[env * D.S + s];
+    const int y = A.labels[env * D.S + s];
+    LoopStats st = {0, 0, 0, 0};
+    double f[4];
+    rescore(D, K, sh, m, d, sm, f);  // the E row is the one update_control_kernel left for this state
+    m = augment_loop(D, K, task, env, dict, m, d, y, y == 1 ? a_i : 0, y == 1 ? n : a_i, f, sm, st);
+    flush_stats(K, task, dict, m, st);
+}
+
+__global__ __launch_bounds__(64) void update_small_kernel(CtlArgs A) {
+    const KbState& K = A.K;
+    if ((int)blockIdx.x >= K.heavy[2]) return;
+    __shared__ Lds sm;
+    load_gtab(K, sm);
+    repair_learner(A, K.heavy[4 + A.D.n_envs * A.D.S - 1 - blockIdx.x], sm);
+}
+
+__global__ __launch_bounds__(KB_HEAVY_THREADS) void update_heavy_kernel(CtlArgs A) {
+    const KbState& K = A.K;
+    __shared__ Lds sm;
+    const int count = K.heavy[0];
+    if (count == 0) return;
+    load_gtab(K, sm);
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) sm.ired[7] = atomicAdd(&K.heavy[1], 1);
+        __syncthreads();
+        const int slot = sm.ired[7];
+        if (slot >= count) break;
+        repair_learner(A, K.heavy[4 + slot], sm);
     }
 }
 
@@ -726,7 +902,7 @@ __device__ __forceinline__ int select_scan(const KbDev& D, const KbState& K, con
     return found;
 }
 
-__global__ __launch_bounds__(64) void select_kernel(SelArgs A) {
+__global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
@@ -1064,8 +1240,9 @@ __global__ __launch_bounds__(256) void shared_cols_kernel(KbDev D, KbState K, co
     }
 }
 
-// d* = Kinv k_f for all proposals of the full dictionaries, each output summed as matvec_colsum does (column walk,
-// rows in increasing order, fused multiply-add): a thread owns output i and walks the proposals four at a time
+// d* = Kinv k_f for all proposals of the full dictionaries, each output summed exactly as matvec_colsum does (column
+// walk; eight partial sums over the row classes j mod 8, fused multiply-adds in increasing j; the same tree): a lane owns
+// output i and walks the proposals four at a time
 __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
     const int s = blockIdx.x;
     const int m = K.m[s];
@@ -1081,21 +1258,25 @@ __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, 
     const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
     for (int wk = wave; wk < nwork; wk += nw) {
         const int bi = wk % nb, p0 = (wk / nb) * 4;
-        double a[4] = {0.0, 0.0, 0.0, 0.0};
+        double a[8][4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[u][r] = 0.0;
         for (int bj = 0; bj < nb; ++bj) {
             const int rows = m - 64 * bj < 64 ? m - 64 * bj : 64;
             const double* tp = kinv_tile(K, sh, bj, bi) + lane;
             double kfv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) kfv[r] = KF[(size_t)(p0 + r < np ? p0 + r : p0) * capr + 64 * bj + lane];
-            for (int r0 = 0; r0 < rows; r0 += 2) {
+            for (int r0 = 0; r0 < rows; r0 += 8) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < 8; ++u) {  // row r0 + u is of class u (64 bj is a multiple of eight)
                     const int rr = r0 + u;
                     if (rr < rows) {
                         const double kv = tp[rr * 64];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a[r] = __builtin_fma(kv, readlane_f64(kfv[r], rr), a[r]);
+                        for (int r = 0; r < 4; ++r) a[u][r] = __builtin_fma(kv, readlane_f64(kfv[r], rr), a[u][r]);
                     }
                 }
             }
@@ -1104,7 +1285,8 @@ __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, 
         if (i < m) {
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (p0 + r < np) DS[(size_t)(p0 + r) * capr + i] = a[r];
+                if (p0 + r < np)
+                    DS[(size_t)(p0 + r) * capr + i] = ((a[0][r] + a[1][r]) + (a[2][r] + a[3][r])) + ((a[4][r] + a[5][r]) + (a[6][r] + a[7][r]));
         }
     }
 }
@@ -1313,6 +1495,8 @@ __global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K,
             kinv[e] = kinv_tile(K, sh, i >> 6, j >> 6)[(i & 63) * 64 + (j & 63)];
         }
 }
+
+__global__ void heavy_reset_kernel(KbState K) { K.heavy[0] = K.heavy[1] = K.heavy[2] = K.heavy[3] = 0; }
 
 __global__ void kb_gtab_kernel(KbDev D, KbState K) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -180,6 +180,14 @@ class VecKBRL:
         self._check(self.L.kb_kernel_time_ms(self.h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
+    def phase_times_ms(self):
+        """mean device time of the timed launches since the last call: dict(update_ms, select_ms, n_update, n_select) --
+        the update phase is update_control_kernel plus the repair kernels"""
+        ms = (C.c_double * 2)()
+        n = (C.c_int64 * 2)()
+        self._check(self.L.kb_phase_times_ms(self.h, ms, n))
+        return dict(update_ms=ms[0], select_ms=ms[1], n_update=n[0], n_select=n[1])
+
     def synchronize(self):
         self._check(self.L.kb_synchronize(self.h))
 

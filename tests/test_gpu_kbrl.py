@@ -434,12 +434,17 @@ def test_projectron_long_golden_to_790_landmarks(golden_dir):
     ag.close()
 
 
-@pytest.mark.parametrize('name,min_m', [('g15_kbrl_long_s0', 200), ('g16_kbrl_long_tdl_s0', 0)])
-def test_kbrl_control_long_golden(golden_dir, name, min_m):
+@pytest.mark.parametrize('name,min_m,heavy_m', [('g15_kbrl_long_s0', 200, None), ('g16_kbrl_long_tdl_s0', 0, None),
+                                                ('g15_kbrl_long_s0', 200, 100), ('g16_kbrl_long_tdl_s0', 0, 1000000)])
+def test_kbrl_control_long_golden(golden_dir, monkeypatch, name, min_m, heavy_m):
     """G15 / G16: KBRL_Control teacher-forced over the reference's 2,200 recorded steps of scenario_0 (G15: dictionaries
     of several hundred landmarks): every hit, selected action, adjusted flag, margin, security factor and dictionary
-    size; final landmarks exact, coefficients 1e-6"""
+    size; final landmarks exact, coefficients 1e-6.  By default every learner with a mistake to repair is finished by
+    update_heavy_kernel (a workgroup each); KBRL_HEAVY_M = h keeps learners below h landmarks in the one-wave kernel (the
+    last two cases: a mix of both paths, and the one-wave path alone)."""
     from ranslice.kbrl_dev import VecKBRL
+    if heavy_m is not None:
+        monkeypatch.setenv('KBRL_HEAVY_M', str(heavy_m))
     g = _load(golden_dir, name)
     dims, n_prbs = _dims(0)
     ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=4096)
