@@ -265,6 +265,10 @@ int kb_comm_unique_id(void* id128);
 int kb_comm_init(kb_handle* k, const void* id128, int rank, int world);
 int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t budget,
                    int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
+/* kb_step_resident for a shared-dictionary agent: the learning step above on the simulator's own device buffers (previous
+ * observation, the action `env` just executed, its labels), then select_action of the new observation into the
+ * simulator's action buffer.  Only the per-round "anything left" flag crosses PCIe. */
+int kb_shared_step_resident(kb_handle* k, rs_handle* env, int32_t budget, int32_t max_rounds, int32_t* rounds_out);
 /* The merge of kb_shared_step on a caller-supplied gathered buffer (what ncclAllGather delivers): `world` blocks of
  * [S proposer counts][S][budget][KB_PROP_WIDTH] doubles -> merged proposals [S][budget][KB_PROP_WIDTH], their counts [S],
  * how many of rank `me`'s made it [S], and the proposers of all ranks.  Lets a single process check the device merge

@@ -97,6 +97,15 @@ struct KbState {
     uint64_t* stats;   // [T][4]: predicts, mistakes, grows, kernel evaluations (candidates x landmarks)
     int32_t* heavy;    // [4 + T]: large learners queued, next to take, small learners queued, -; then the task ids (large
                        // from the front, small from the back)
+    // the queued large learners between the kernels of the repair rounds (heavy_*_kernel), by queue slot
+    int32_t* hv_cfrom;  // [T] first candidate of the range not yet examined
+    int32_t* hv_cstar;  // [T] the mistake whose kernel column is in the K_f row
+    int32_t* hv_state;  // [T] 1: a repair is pending, 0: done
+    int32_t* hv_grew;   // [T] 1: the round's update inserted a landmark: Kinv still needs its rank-1 update
+    int32_t* hv_m;      // [T] dictionary size before that insertion
+    int32_t* hv_pend;   // [T][2] predictions / exact ties of the segment up to hv_cstar, counted when it is applied
+    double* hv_delta;   // [T]
+    double* hv_f;       // [T][256] the scores of the candidates
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
 };
 
@@ -435,12 +444,12 @@ __device__ __forceinline__ void kernel_column_full(const KbDev& D, const KbState
 // A work unit is (64 W columns, one row class); the waves of the block share the units, eight rows are in flight per
 // lane (W doubles each), and the partial sums meet in eight rows of the vector pages.
 template <int W>
-__device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* sh, int m) {
+__device__ __forceinline__ void matvec_partials(const KbState& K, const uint64_t* sh, int m, int u0, int ustride) {
     static_assert(W == 1 || W == 2 || W == 4, "columns per lane");
-    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
     const int ncg = (nb + W - 1) / W;  // groups of W column blocks
     const int bsub = lane / (64 / W), coff = (lane % (64 / W)) * W;  // this lane's column block within the group, column in it
-    for (int u = wave; u < ncg * 8; u += nw) {
+    for (int u = u0; u < ncg * 8; u += ustride) {
         const int cg = u >> 3, sg = u & 7;
         const int bi = cg * W + bsub;
         const bool on = bi < nb;
@@ -474,7 +483,9 @@ __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* 
             for (int c = 0; c < W; ++c) o[c] = acc[c];
         }
     }
-    __syncthreads();
+}
+
+__device__ __forceinline__ void matvec_combine(const KbState& K, const uint64_t* sh, int m) {
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
         double* P = vec_page(K, sh, i >> 6) + (i & 63);
         const double p0 = P[(KB_ROW_PART + 0) * KB_CH], p1 = P[(KB_ROW_PART + 1) * KB_CH], p2 = P[(KB_ROW_PART + 2) * KB_CH],
@@ -483,6 +494,43 @@ __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* 
         P[KB_ROW_DS * KB_CH] = ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7));
     }
     __syncthreads();
+}
+
+template <int W>
+__device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* sh, int m) {
+    matvec_partials<W>(K, sh, m, threadIdx.x >> 6, blockDim.x >> 6);
+    __syncthreads();
+    matvec_combine(K, sh, m);
+}
+
+// Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta (projectron.py:54-58) over the m1 = m + 1 landmarks, d* (with
+// its -1) in the DS row.  A work unit is 16 rows of a tile: all 16 loads of a lane are in flight before the first store
+// (d_i broadcast from the row block's lanes, d_j in this lane).  Every entry is formed as old + (d_i d_j) (1 / delta).
+__device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh, int m, double delta, int u0, int ustride) {
+    const int m1 = m + 1, nb = (m1 + 63) >> 6, lane = threadIdx.x & 63;
+    const double inv = 1.0 / delta;
+    for (int u = u0; u < nb * nb * 4; u += ustride) {
+        const int tb = u >> 2, r0 = (u & 3) * 16;
+        const int bi = tb / nb, bj = tb - bi * nb;
+        const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
+        const int j = 64 * bj + lane;
+        if (r0 >= rows) continue;  // (wave-uniform)
+        double* T = kinv_tile(K, sh, bi, bj) + lane;
+        const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
+        const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
+        double old[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = r0 + k, i = 64 * bi + r;
+            old[k] = (r < rows && i < m && j < m) ? T[r * 64] : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int r = r0 + k;
+            const double dsi = readlane_f64(dsi_v, r);
+            if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) * inv;
+        }
+    }
 }
 
 // take shell b for the dictionary (thread 0; everybody learns the outcome).  false: capacity or pool exhausted.
@@ -505,26 +553,18 @@ __device__ __forceinline__ bool take_shell(const KbDev& D, const KbState& K, int
     return ok;
 }
 
-// Projectron.update (projectron.py:39-60) for x = (x[0..d-2], t_last) whose kernel column is in the K_f row.
-// Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.  Runs on the whole block (64,
-// 256 or 1024 threads); every sum is formed in an order that does not depend on the block size.
-__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, const double* x, double t_last,
-                            int a_last, int y, Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
+// The part of Projectron.update (projectron.py:41-60) that follows d* = Kinv K_f (DS row): delta, the decision, and the
+// projection or the insertion.  With defer_rank1 the O(m^2) update of Kinv is left to the caller (rank1_units with the
+// returned delta).  Returns the new m.  branch: 1 = projection onto the dictionary, 2 = dictionary grew.
+__device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, const double* x, double t_last,
+                             int a_last, int y, Lds& sm, int* branch, double* delta_out, bool* saturated, bool defer_rank1) {
     const uint64_t* sh = shells_of(D, K, dict);
     double dot;
     if (m <= 1) {
-        float kinv = m == 0 ? 0.0f : 1.0f;
         const float kf0 = m == 0 ? 0.0f : (float)*vec_at(K, sh, KB_ROW_KF, 0);
-        float ds = kinv * kf0;
-        __syncthreads();
-        if (threadIdx.x == 0 && m == 1) *vec_at(K, sh, KB_ROW_DS, 0) = (double)ds;
+        const float ds = m == 0 ? 0.0f : (float)*vec_at(K, sh, KB_ROW_DS, 0);
         dot = (double)(float)(ds * kf0);
-        __syncthreads();
     } else {
-        if (blockDim.x >= 256)
-            matvec_colsum<4>(K, sh, m);
-        else
-            matvec_colsum<2>(K, sh, m);
         if (threadIdx.x < 64) {
             const double v = wave_dot256_rows(K, sh, KB_ROW_DS, KB_ROW_KF, m);
             if (threadIdx.x == 0) sm.red[15] = v;
@@ -562,7 +602,7 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         return m;
     }
     *branch = 2;
-    // SVvariable.extend / insert; Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta
+    // SVvariable.extend / insert
     {
         double* P = vec_page(K, sh, m >> 6);
         const int l = m & 63;
@@ -587,37 +627,31 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
     __syncthreads();
     if (m == 0) {
         if (threadIdx.x == 0) kinv_tile(K, sh, 0, 0)[0] = 1.0;
-    } else {
-        const int m1 = m + 1, nb = (m1 + 63) >> 6;
-        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-        const double inv = 1.0 / delta;
-        // a work unit is 16 rows of a tile: all 16 loads of a lane are in flight before the first store (d_i broadcast
-        // from the row block's lanes, d_j in this lane)
-        for (int u = wave; u < nb * nb * 4; u += nw) {
-            const int tb = u >> 2, r0 = (u & 3) * 16;
-            const int bi = tb / nb, bj = tb - bi * nb;
-            const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
-            const int j = 64 * bj + lane;
-            if (r0 >= rows) continue;  // (wave-uniform)
-            double* T = kinv_tile(K, sh, bi, bj) + lane;
-            const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
-            const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
-            double old[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = r0 + k, i = 64 * bi + r;
-                old[k] = (r < rows && i < m && j < m) ? T[r * 64] : 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const int r = r0 + k;
-                const double dsi = readlane_f64(dsi_v, r);
-                if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) * inv;
-            }
-        }
+    } else if (!defer_rank1) {
+        rank1_units(K, sh, m, delta, threadIdx.x >> 6, blockDim.x >> 6);
     }
     __syncthreads();
     return m + 1;
+}
+
+// Projectron.update (projectron.py:39-60) for x = (x[0..d-2], t_last) whose kernel column is in the K_f row.
+// Returns the new m.  Runs on the whole block (64, 256, 512 or 1024 threads); every sum is formed in an order that does
+// not depend on the block size.
+__device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_env, int m, int d, const double* x, double t_last,
+                            int a_last, int y, Lds& sm, int* branch, double* delta_out, bool* saturated = nullptr) {
+    const uint64_t* sh = shells_of(D, K, dict);
+    if (m == 1) {
+        // Kinv is the 1-element float32 array [1 / Kii]; K_f is float32 (projectron.py:29,59)
+        __syncthreads();
+        if (threadIdx.x == 0) *vec_at(K, sh, KB_ROW_DS, 0) = (double)(1.0f * (float)*vec_at(K, sh, KB_ROW_KF, 0));
+        __syncthreads();
+    } else if (m >= 2) {
+        if (blockDim.x >= 256)
+            matvec_colsum<4>(K, sh, m);
+        else
+            matvec_colsum<2>(K, sh, m);
+    }
+    return finish_update(D, K, dict, err_env, m, d, x, t_last, a_last, y, sm, branch, delta_out, saturated, false);
 }
 
 struct CtlArgs {
@@ -792,15 +826,29 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     st.n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
     if (!INLINE || m >= D.heavy_m) {
         int zeros;
-        if (first_mistake(f, y, c_from, c_to, &zeros) >= 0) {
-            if (threadIdx.x == 0) {
-                if (m >= KB_SMALL_M || INLINE) {
-                    const int slot = atomicAdd(&K.heavy[0], 1);
+        const int cst = first_mistake(f, y, c_from, c_to, &zeros);
+        if (cst >= 0) {
+            if (m >= KB_SMALL_M || INLINE) {
+                // the first repair is prepared here: scores, range, the mistake and its kernel column
+                int slot = 0;
+                if (threadIdx.x == 0) slot = atomicAdd(&K.heavy[0], 1);
+                slot = __builtin_amdgcn_readfirstlane(slot);
+                const int lane = threadIdx.x & 63;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) K.hv_f[(size_t)slot * 256 + 64 * g + lane] = f[g];
+                kernel_column_from_d0(D, K, sh, m, d, (double)cst / (double)n);
+                if (threadIdx.x == 0) {
                     K.heavy[4 + slot] = task;
-                } else {  // from the far end of the same array
-                    const int slot = atomicAdd(&K.heavy[2], 1);
-                    K.heavy[4 + D.n_envs * D.S - 1 - slot] = task;
+                    K.hv_cfrom[slot] = c_from;
+                    K.hv_cstar[slot] = cst;
+                    K.hv_pend[2 * slot] = cst - c_from + 1;
+                    K.hv_pend[2 * slot + 1] = zeros;
+                    K.hv_grew[slot] = 0;
+                    K.hv_state[slot] = 1;
                 }
+            } else if (threadIdx.x == 0) {  // small dictionaries: from the far end of the same array
+                const int slot = atomicAdd(&K.heavy[2], 1);
+                K.heavy[4 + D.n_envs * D.S - 1 - slot] = task;
             }
             flush_stats(K, task, dict, m, st);
             return;
@@ -817,9 +865,8 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     flush_stats(K, task, dict, m, st);
 }
 
-// the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: one wave each, all at once
-// (update_small_kernel; the launch is as wide as the batch, workgroups beyond the queue leave at once); larger ones: a
-// workgroup of eight waves each, taken one at a time by persistent workgroups (update_heavy_kernel).
+// the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: a workgroup of four waves each, all at
+// once (update_small_kernel; workgroups beyond the queue leave at once); larger ones: the repair rounds below.
 __device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& sm) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
@@ -839,27 +886,162 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& 
     flush_stats(K, task, dict, m, st);
 }
 
-__global__ __launch_bounds__(64) void update_small_kernel(CtlArgs A) {
+__global__ __launch_bounds__(256) void update_small_kernel(CtlArgs A) {
     const KbState& K = A.K;
-    if ((int)blockIdx.x >= K.heavy[2]) return;
+    const int count = K.heavy[2];
+    if ((int)blockIdx.x >= count) return;
     __shared__ Lds sm;
     load_gtab(K, sm);
-    repair_learner(A, K.heavy[4 + A.D.n_envs * A.D.S - 1 - blockIdx.x], sm);
+    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        __syncthreads();
+        repair_learner(A, K.heavy[4 + A.D.n_envs * A.D.S - 1 - slot], sm);
+    }
 }
 
+// ---- the repair rounds of the large learners.  One Projectron update of a dictionary of m landmarks reads m^2 doubles
+// of Kinv (d* = Kinv K_f) and, when it inserts, rewrites them (rank-1 update): against a dictionary of a thousand
+// landmarks that is 8 + 16 MB, far more than one workgroup should stream on its own while the rest of the chip waits.  So
+// the queued learners advance together, one repair per round, in three kernels as wide as the chip:
+//   heavy_matvec_kernel   the partial sums of d* of every pending learner, its work units spread over gridDim.y blocks
+//   heavy_finish_kernel   per learner: d*, delta, the decision, projection or insertion; then the scores of what is left
+//                         of the range, the next mistake and its kernel column -- or done
+//   heavy_rank1_kernel    Kinv's rank-1 update of the learners that inserted, units spread as above
+// After KB rounds (kb_api.hip) whatever is still pending is finished learner by learner by update_heavy_kernel.
+__global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
+    const int count = K.heavy[0];
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        if (K.hv_state[slot] != 1) continue;
+        const int dict = dict_of(D, K.heavy[4 + slot]);
+        matvec_partials<1>(K, shells_of(D, K, dict), K.m[dict], blockIdx.y * nw + wave, gridDim.y * nw);
+    }
+}
+
+__global__ __launch_bounds__(256) void heavy_rank1_kernel(KbDev D, KbState K) {
+    const int count = K.heavy[0];
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        if (K.hv_grew[slot] != 1) continue;
+        const int dict = dict_of(D, K.heavy[4 + slot]);
+        rank1_units(K, shells_of(D, K, dict), K.hv_m[slot], K.hv_delta[slot], blockIdx.y * nw + wave, gridDim.y * nw);
+    }
+}
+
+__global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    __shared__ Lds sm;
+    const int count = K.heavy[0];
+    if ((int)blockIdx.x >= count) return;
+    load_gtab(K, sm);
+    const int lane = threadIdx.x & 63;
+    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
+        __syncthreads();
+        if (threadIdx.x == 0) K.hv_grew[slot] = 0;  // the previous round's rank-1 update has been made
+        if (K.hv_state[slot] != 1) continue;
+        const int task = K.heavy[4 + slot], env = task / D.S, s = task - env * D.S;
+        const int d = D.dims[s] + 1, n = D.n_prbs;
+        const int dict = dict_of(D, task);
+        const uint64_t* sh = shells_of(D, K, dict);
+        const int m = K.m[dict];
+        stage_state(D, A.state, env, s, d, sm);
+        __syncthreads();
+        const int a_i = A.action[env * D.S + s];
+        const int y = A.labels[env * D.S + s];
+        const int c_to = y == 1 ? n : a_i;
+        const int cstar = K.hv_cstar[slot];
+        LoopStats st = {(uint64_t)K.hv_pend[2 * slot], 1, 0, 0};
+        if (threadIdx.x == 0 && K.hv_pend[2 * slot + 1] > 0) K.tie_ctr[task] += (uint32_t)K.hv_pend[2 * slot + 1];  // Q11
+        matvec_combine(K, sh, m);
+        int branch;
+        double delta;
+        bool saturated;
+        const int m_new = finish_update(D, K, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta,
+                                        &saturated, true);
+        int state = 1;
+        if (saturated) {
+            state = 0;  // (augment_loop's rule: a full dictionary stops augmenting for the step)
+        } else {
+            double f[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) f[g] = K.hv_f[(size_t)slot * 256 + 64 * g + lane];
+            const int c_from = cstar + 1;
+            const uint64_t left = (uint64_t)(c_to - c_from + 1 > 0 ? c_to - c_from + 1 : 0);
+            if (branch == 2 && m_new > m) {
+                st.n_grow = 1;
+                if (threadIdx.x == 0) {
+                    K.hv_grew[slot] = 1;
+                    K.hv_m[slot] = m;
+                    K.hv_delta[slot] = delta;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {  // one more term, E = 1 (augment_loop)
+                    int o = cstar - (64 * g + lane);
+                    o = o < 0 ? -o : o;
+                    f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
+                }
+                st.n_eval += left;
+            } else {
+                rescore(D, K, sh, m_new, d, sm, f);
+                st.n_eval += left * (uint64_t)m_new;
+            }
+            int zeros = 0;
+            const int next = c_from <= c_to ? first_mistake(f, y, c_from, c_to, &zeros) : -1;
+            if (next < 0) {
+                st.n_pred += left;
+                if (zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
+                state = 0;
+            } else {
+                kernel_column_from_d0(D, K, sh, m_new, d, (double)next / (double)n);
+                if (threadIdx.x < 64) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) K.hv_f[(size_t)slot * 256 + 64 * g + lane] = f[g];
+                }
+                if (threadIdx.x == 0) {
+                    K.hv_cfrom[slot] = c_from;
+                    K.hv_cstar[slot] = next;
+                    K.hv_pend[2 * slot] = next - c_from + 1;
+                    K.hv_pend[2 * slot + 1] = zeros;
+                }
+            }
+        }
+        if (threadIdx.x == 0) K.hv_state[slot] = state;
+        flush_stats(K, task, dict, m_new, st);
+    }
+}
+
+// what the rounds left pending (and, without rounds, every queued large learner): persistent workgroups take the
+// learners one at a time and run the loop to its end
 __global__ __launch_bounds__(KB_HEAVY_THREADS) void update_heavy_kernel(CtlArgs A) {
+    const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
     const int count = K.heavy[0];
     if (count == 0) return;
     load_gtab(K, sm);
+    const int lane = threadIdx.x & 63;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) sm.ired[7] = atomicAdd(&K.heavy[1], 1);
         __syncthreads();
         const int slot = sm.ired[7];
         if (slot >= count) break;
-        repair_learner(A, K.heavy[4 + slot], sm);
+        if (K.hv_state[slot] != 1) continue;
+        const int task = K.heavy[4 + slot], env = task / D.S, s = task - env * D.S;
+        const int d = D.dims[s] + 1, n = D.n_prbs;
+        const int dict = dict_of(D, task);
+        int m = K.m[dict];
+        stage_state(D, A.state, env, s, d, sm);
+        __syncthreads();
+        const int a_i = A.action[env * D.S + s];
+        const int y = A.labels[env * D.S + s];
+        LoopStats st = {0, 0, 0, 0};
+        double f[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = K.hv_f[(size_t)slot * 256 + 64 * g + lane];
+        m = augment_loop(D, K, task, env, dict, m, d, y, K.hv_cfrom[slot], y == 1 ? n : a_i, f, sm, st);
+        if (threadIdx.x == 0) K.hv_state[slot] = 0;
+        flush_stats(K, task, dict, m, st);
     }
 }
 

@@ -15,7 +15,6 @@
 #include "rs_mmtc.hip"
 #include "rs_order.hip"
 #include "rs_mux.hip"
-#include "rs_lane.hip"
 
 using namespace rs;
 
@@ -100,8 +99,6 @@ struct rs_handle {
     int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
     int n_ran = 0;                                // RAN slices (info rows): n_embb + n_mmtc
     bool mux = false;                             // rs_config.l1_multiplex
-    bool lane_engine = false;                     // eMBB step in lane-per-task form (rs_lane.hip): own per-UE layout
-    rs::LaneWork lane_w = {};
     int64_t* d_run = nullptr;    // device-side run state read by the step kernels: [0] slots since reset,
                                  // [1] step index and [2] seed of the on-device action script (rs_run_random)
     hipGraph_t graph = nullptr;  // two captured steps (one per parity of the order counters) of rs_run_random
@@ -143,6 +140,11 @@ static int dalloc(rs_handle* h, T** p, size_t n) {
 
 // ------------------------------------------------------------------ mMTC host helpers
 
+// dynamic LDS of mtc_mux_step_kernel: the shared FIFO (two words per entry) and the device tables of every mMTC RAN slice
+static size_t mtc_mux_lds_bytes(int cap, int n_mmtc) {
+    return ((size_t)2 * cap * n_mmtc + (size_t)n_mmtc * MTC_DEV_MAX) * sizeof(int32_t);
+}
+
 static int mtc_alloc(rs_handle* h, rs::MtcState* m, size_t n_tasks, const RsDev& d) {
     memset(m, 0, sizeof *m);
     m->n_tasks = n_tasks;
@@ -152,6 +154,18 @@ static int mtc_alloc(rs_handle* h, rs::MtcState* m, size_t n_tasks, const RsDev&
         d.mtc_n_period <= 0 || d.mtc_n_period > 8) {
         h->err = "rs_create: mMTC configuration out of range (<=1024 devices, queue capacity <=2048)";
         return RS_EINVAL;
+    }
+    if (d.mux) {
+        // mtc_mux_step_kernel keeps the FIFO and the device tables of ALL mMTC RAN slices of a replica in LDS: ask for
+        // what it needs now (the default limit on dynamic LDS is 64 KB; six slices at capacity 1024 need 72 KB) instead of
+        // failing at the first step
+        const size_t lds = mtc_mux_lds_bytes(d.mtc_cap, d.n_mmtc);
+        if (lds > 160 * 1024 - 4096) {
+            h->err = "rs_create: l1_multiplex with this many mMTC RAN slices and this queue capacity needs more LDS than a CU has";
+            return RS_EINVAL;
+        }
+        if (lds > 48 * 1024)
+            HIPCHK(h, hipFuncSetAttribute((const void*)rs::mtc_mux_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     for (int i = 0; i < d.mtc_n_period; ++i)
         if (d.mtc_period_set[i] < d.slots) {
@@ -327,7 +341,14 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         cfg->pf_granularity <= 0 || (cfg->max_ue != 0 && cfg->max_ue != (cfg->l1_multiplex ? RS_MUX_UE : RS_GROUP)) ||
         (cfg->l1_multiplex && (cfg->n_embb > 6 || cfg->n_mmtc > RS_MUX_RAN)) ||
         (cfg->max_bursts != 0 && cfg->max_bursts != RS_BURSTS)) {
-        h->err = "rs_create: unsupported configuration (n_prbs <= 256, max_ue in {0,32}, max_bursts in {0,8})";
+        h->err = "rs_create: unsupported configuration (n_prbs <= 256; max_ue 0 or 32, 64 with l1_multiplex; max_bursts 0 or 16; "
+                 "l1_multiplex: at most 6 eMBB and 8 mMTC RAN slices)";
+        return RS_EINVAL;
+    }
+    if (cfg->l1_multiplex && cfg->n_embb == 0) {
+        // the reference always creates the eMBB L1 slice in this mode, even with no eMBB RAN slice to serve
+        // (scenario_creator.py:170-172), which gives the action an entry nothing uses; not mirrored
+        h->err = "rs_create: l1_multiplex needs at least one eMBB RAN slice";
         return RS_EINVAL;
     }
     {
@@ -450,13 +471,8 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     for (int i = 0; i < 3; ++i) d.norm_mmtc[i] = cfg->norm_mmtc[i];
 
     int rc;
-    // Lane-per-task engine (rs_lane.hip): exact, but measured 4-12x slower than the group kernels at every batch size
-    // (its per-UE state sits in HBM behind dependent loads and every lane walks its own fading column), so nothing
-    // selects it; RANSLICE_LANE=1 turns it on (tests, tools/lane_check.sh).
-    h->lane_engine = false;
-    if (const char* e = getenv("RANSLICE_LANE")) h->lane_engine = !h->mux && h->n_tasks > 0 && atoi(e) != 0;
     const size_t T = (size_t)h->n_tasks, N = (size_t)cfg->n_envs;
-    const size_t U = (h->lane_engine ? (T + 63) / 64 * 64 : T) * RS_GROUP;  // the lane-major layout fills whole waves
+    const size_t U = T * RS_GROUP;
     RsState& s = h->st;
 #define DA(p, n)                                   \
     if ((rc = dalloc(h, &(p), (n))) != RS_OK) return rc
@@ -466,10 +482,6 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(s.u_hold_at, U); DA(s.u_e_snr, U); DA(s.u_findex, U); DA(s.u_bits, U); DA(s.u_prbs, U);
     DA(s.u_vbr_at, U); DA(s.u_ctr, U); DA(s.u_serial, U); DA(s.u_flags, U);
     DA(s.u_burst, U * RS_BURSTS);
-    if (h->lane_engine) {
-        DA(h->lane_w.evt, U); DA(h->lane_w.nact, U); DA(h->lane_w.q, U); DA(h->lane_w.rate, U);
-        DA(h->lane_w.thl, U); DA(h->lane_w.m, U);
-    }
     DA(s.seeds, N); DA(s.err, N);
     DA(h->d_actions, N * h->n_slices);
     DA(h->d_obs, N * h->n_vars);
@@ -717,7 +729,7 @@ static int launch_step(rs_handle* h) {
             ma.violations = h->d_viol;
             ma.info = h->d_info;
             ma.err = h->st.err;
-            const size_t lds = ((size_t)2 * h->mst.cap * h->cfg.n_mmtc + (size_t)h->cfg.n_mmtc * MTC_DEV_MAX) * sizeof(int32_t);
+            const size_t lds = mtc_mux_lds_bytes(h->mst.cap, h->cfg.n_mmtc);
             hipLaunchKernelGGL(rs::mtc_mux_step_kernel, dim3((unsigned)h->cfg.n_envs), dim3(64), lds, h->stream, ma);
         }
         hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,
@@ -776,18 +788,6 @@ static int launch_step(rs_handle* h) {
                 else hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
             }
         };
-        if (h->lane_engine) {
-            if (h->trace_on) {
-                h->err = "the allocation trace needs the group engine (RANSLICE_LANE=0)";
-                return RS_ESTATE;
-            }
-            rs::LaneArgs la;
-            la.a = a;
-            la.w = h->lane_w;
-            if (h->timing) HIPCHK(h, hipEventRecord(e0, h->stream));
-            hipLaunchKernelGGL(embb_lane_step_kernel, dim3((unsigned)((h->n_tasks + 255) / 256)), dim3(256), 0, h->stream, la);
-            if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
-        } else {
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
         // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)
         if (h->order_mode > 0) {
@@ -809,7 +809,6 @@ static int launch_step(rs_handle* h) {
         if (h->group < 32) {
             a.replay = 1;
             launch(32);
-        }
         }
     }
     if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);

@@ -53,7 +53,7 @@ class Evaluator():
 class BatchedEvaluator(Evaluator):
     """All runs of one (scenario, accuracy range) at once: run i = replica i."""
 
-    def evaluate_all(self, runs, device=0, capacity=4096, verbose=True):
+    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=0, verbose=True):
         import ctypes as C
         from ranslice import config as _c
         from ranslice.kbrl_dev import VecKBRL
@@ -83,7 +83,7 @@ class BatchedEvaluator(Evaluator):
         env = VecRanSlice(n_envs=n, cfg=cfg, fading=fading, device=device)
         dims = [len(sc.state_variables_embb)] * n_embb + [len(sc.state_variables_mmtc)] * n_mmtc
         agent = VecKBRL(n, dims, n_prbs, alfa=sc.alfa, accuracy_range=tuple(self.a_range), capacity=capacity,
-                        device=device)
+                        device=device, pool_bytes=pool_bytes)
         env.reset(seeds=env_seeds)
         agent.reset(ia, sf, seeds=ag_seeds)
         agent.history_begin(self.steps)

@@ -13,7 +13,7 @@ RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
 KB_EXPORTS = (
     'kb_create', 'kb_destroy', 'kb_last_error', 'kb_reset', 'kb_update_control', 'kb_select_action',
     'kb_step_resident', 'kb_predict', 'kb_update', 'kb_get_learner', 'kb_get_control', 'kb_set_adjusted',
-    'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
+    'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
 )
 
 EXPORTS = (
@@ -104,6 +104,7 @@ def load():
     L.kb_comm_unique_id.argtypes = [vp]
     L.kb_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.kb_shared_step.argtypes = [vp, fp, ip, ip, C.c_int32, C.c_int32, ip, ip]
+    L.kb_shared_step_resident.argtypes = [vp, vp, C.c_int32, C.c_int32, ip]
     L.kb_shared_merge.argtypes = [vp, dp, C.c_int32, C.c_int32, C.c_int32, dp, ip, ip, ip]
     L.rs_device_count.argtypes = []
     L.kb_kernel_time_ms.argtypes = [vp, dp, i64p]

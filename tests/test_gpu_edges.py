@@ -224,13 +224,13 @@ def test_schedule_hint_does_not_change_results(golden_dir, group):
             assert inf.tobytes() == infos[0].tobytes()
 
 
-def _mux_compare(golden_dir, scenario, n_envs, steps, churn, seed0, trace):
+def _mux_compare(golden_dir, scenario, n_envs, steps, churn, seed0, trace, **shape):
     from oracle import pyoracle as po
     from ranslice.vec_env import VecRanSlice
     fading = _fading(golden_dir)
 
     def cfgf(n):
-        c = make_config(scenario, n_envs=n, L1_level=False)
+        c = make_config(scenario, n_envs=n, L1_level=False, **shape)
         return _churn(c) if churn else c
     env = VecRanSlice(n_envs=n_envs, cfg=cfgf(n_envs), fading=fading, seed=seed0)
     n_l1 = (env.cfg.n_embb > 0) + (env.cfg.n_mmtc > 0)
@@ -244,7 +244,7 @@ def _mux_compare(golden_dir, scenario, n_envs, steps, churn, seed0, trace):
         o.set_seed(replica_seed(seed0, r))
         o.reset()
         oracles.append(o)
-    rng = np.random.default_rng(17 + scenario)
+    rng = np.random.default_rng(17 + (scenario or 0))
     n_prbs = env.n_prbs
     for i in range(steps):
         if i % 4 == 0:
@@ -330,3 +330,18 @@ def test_multiplexed_drop_in_env(golden_dir):
     assert set(info['l1_info'][0][0]) == set(sc.state_variables_embb) and 'delay' in info['l1_info'][1][1]
     assert info['SLA_labels'].shape == (2,) and isinstance(r, float)
     sc.set_fading(None)
+
+
+def test_multiplexed_l1_many_mmtc_slices(golden_dir):
+    """L1_level=False with six and eight mMTC RAN slices behind the one FIFO: mtc_mux_step_kernel then needs 72 / 96 KB of
+    dynamic LDS (FIFO + device tables of every slice), above the 64 KB a launch gets by default -- rs_create asks for it
+    (ADVICE r2).  Bit-exact against the oracle; a mode without any eMBB RAN slice is refused at create."""
+    from ranslice import _lib
+    from ranslice.vec_env import VecRanSlice
+    for n_mmtc in (6, 8):
+        _mux_compare(golden_dir, None, n_envs=6, steps=8, churn=False, seed0=90 + n_mmtc, trace=False, n_prbs=100, n_embb=1,
+                     n_mmtc=n_mmtc)
+    with pytest.raises(_lib.RanSliceError) as e:
+        VecRanSlice(n_envs=2, cfg=make_config(None, n_envs=2, L1_level=False, n_prbs=100, n_embb=0, n_mmtc=2),
+                    fading=_fading(golden_dir))
+    assert e.value.code == _lib.RS_EINVAL and 'eMBB' in str(e.value)

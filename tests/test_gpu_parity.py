@@ -287,19 +287,6 @@ def test_action_validation(golden_dir):
     env.close()
 
 
-@pytest.mark.parametrize('scenario', [0, 1])
-def test_lane_engine_matches_oracle(golden_dir, scenario, monkeypatch):
-    """The lane-per-task form of the eMBB step (rs_lane.hip: one lane walks the UEs of a task one after the other;
-    selected from 8192 replicas per GPU on, forced here): every replica against the oracle -- observations, rewards,
-    labels, violations and the ten info sums per slice, bit for bit -- with the high-churn traffic configuration
-    (arrivals, CAC, departures, bursts), the NaN-column trace, random and agent-like (wide, contested) allocations."""
-    monkeypatch.setenv('RANSLICE_LANE', '1')
-    _compare(scenario, n_envs=70, steps=16, fading=_small_fading(golden_dir), churn=True, seed0=5100 + scenario,
-             check_trace=False)
-    _compare(scenario, n_envs=70, steps=12, fading=_small_fading(golden_dir), churn=True, seed0=5200 + scenario,
-             check_trace=False, actions=_wide_actions)
-
-
 @pytest.mark.parametrize('gran,window', [(1, 50), (3, 50), (4, 7), (2, 3)])
 def test_pf_granularity_and_window_variants(golden_dir, gran, window):
     """The PF allocation's shortcuts (closed forms, the run test without the divide, block rounds with their "full

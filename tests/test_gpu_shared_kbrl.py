@@ -325,3 +325,55 @@ def test_device_exchange_two_ranks_over_rccl(tmp_path):
             pytest.skip('RCCL does not form a 2-rank communicator on a single device: %s' % err[-300:])
         assert False, err[-3000:]
     assert _result(two[0][1]) == _result(two[1][1]) == _result(whole[0][1])
+
+
+def test_shared_resident_loop_equals_host_loop():
+    """kb_shared_step_resident (the shared learning step and select_action on the simulator's own device buffers) == the
+    same closed loop driven through host buffers (env.step / update_control / select_action): selected actions at every
+    step, dictionaries bit for bit at the end (scenario_2, 512 replicas)"""
+    import ctypes as C
+    from ranslice.config import EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import SharedVecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps = 512, 14
+    cfg = make_config(2, n_envs=N)
+    fading = [synth_fading(t, 4000) for t in range(3)]
+    dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
+    rng = np.random.default_rng(5)
+    ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+    sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+
+    def make():
+        env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading)
+        agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=256)
+        state = env.reset()
+        agent.reset(ia, sf)
+        return env, agent, state
+    env, agent, state = make()
+    action = ia.copy()
+    host_actions = []
+    for i in range(steps):
+        obs, rew, _, info = env.step(action)
+        agent.update_control(state, action, info['SLA_labels'])
+        action, adj = agent.select_action(obs)
+        state = obs
+        host_actions.append(action.copy())
+    host_dicts = [agent.learner(0, s, with_kinv=True) for s in range(len(dims))]
+    env.close(); agent.close()
+    env, agent, state = make()
+    a0 = np.ascontiguousarray(ia)
+    env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+    for i in range(steps):
+        agent.step_resident(env)
+        assert (env.fetch()['actions'] == host_actions[i]).all(), i
+        if i + 1 < steps:
+            env.step_resident()
+    for s in range(len(dims)):
+        L = agent.learner(0, s, with_kinv=True)
+        assert L['m'] == host_dicts[s]['m'] and L['coeff'].tobytes() == host_dicts[s]['coeff'].tobytes()
+        assert L['kinv'].tobytes() == host_dicts[s]['kinv'].tobytes()
+    assert max(L['m'] for L in host_dicts) > 1
+    env.close(); agent.close()

@@ -1,3 +1,7 @@
+// NOT PART OF THE PRODUCT: the lane-per-task form of the eMBB step, kept as the record of an experiment (round 2: exact, 4-12x
+// slower than the group kernels at every batch size).  It was compiled into libranslice.so behind RANSLICE_LANE=1
+// until round 3; to build it again, include it from csrc/rs_api.hip after rs_embb.hip and restore the launch hook of
+// commit 5d583f7.
 // eMBB step, LANE-PER-TASK form (VERDICT r1 #3 asked for it for batches of >= 8192 replicas per GPU).
 //
 // embb_step_kernel (rs_embb.hip) gives a (replica, slice) task 16 lanes, of which three or four hold a UE: its

@@ -1,0 +1,37 @@
+#!/bin/bash
+# KBRL kernels (BASELINE config 3) under rocprofv3: kernel trace of the closed loop at two points of learning, then PMC
+# passes (one counter group per run, no tracing flags beside --pmc) of a shorter run.  Run on the GPU box:
+#   bash tools/profile_kbrl.sh <tag>      -> gpurun_out/<tag>_kbrl_*  (copy what is to be judged into profiles/)
+TAG=${1:-r03_x}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+mkdir -p $OUT
+export TMPDIR=/tmp
+cd /tmp
+for W in 100 3000; do
+  CMD="python tools/bench_kbrl.py --warmup $W --steps 200"
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/kt_${TAG}_$W -o t -- bash -c "cd $GRAFT_REPO_ROOT && $CMD > /tmp/kt_${TAG}_$W.json" > /tmp/kt_$W.log 2>&1
+  DB=$(find /tmp/kt_${TAG}_$W -name '*.db' | head -1)
+  { echo "# rocprofv3 --kernel-trace --stats of: $CMD   (the summary covers the warm-up as well; see the last-200 lines)"
+    echo "# the run's own line: $(cat /tmp/kt_${TAG}_$W.json)"
+    python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 200
+    for KN in 'kb::update_heavy_kernel' 'kb::update_small_kernel' 'void kb::update_control_kernel<false>' 'kb::select_kernel'; do
+      python - "$DB" "$KN" <<'PY'
+import sqlite3, sys
+c = sqlite3.connect(sys.argv[1])
+d = [r[0] for r in c.execute("select end - start from kernels where name like ? order by start desc limit 200", (sys.argv[2] + '%',))]
+if d:
+    print('# last %d launches of %s: mean %.0f ns (min %d, max %d)' % (len(d), sys.argv[2], sum(d) / len(d), min(d), max(d)))
+PY
+    done; } > $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
+  head -12 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt; tail -4 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
+done
+PCMD="python tools/bench_kbrl.py --warmup 1000 --steps 20"
+echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch over the last 20 launches of each kb:: kernel (dictionaries of ~100 landmarks on average)" > $OUT/${TAG}_kbrl_pmc.txt
+i=0
+for GRP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  timeout 900 rocprofv3 --pmc $GRP -d /tmp/kpmc_${TAG}_$i -o p -- bash -c "cd $GRAFT_REPO_ROOT && $PCMD" > /tmp/kpmc_$i.log 2>&1; echo "group $i ($GRP) rc=$?"
+  DB=$(find /tmp/kpmc_${TAG}_$i -name '*.db' | head -1)
+  [ -n "$DB" ] && python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 20 | grep -E "kb::" | grep "last 20" >> $OUT/${TAG}_kbrl_pmc.txt
+done
+cat $OUT/${TAG}_kbrl_pmc.txt

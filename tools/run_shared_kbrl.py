@@ -26,7 +26,9 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--budget', type=int, default=64)
     ap.add_argument('--rounds', type=int, default=4)
-    ap.add_argument('--capacity', type=int, default=256,
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--host-loop', action='store_true', help='drive the loop through host buffers (env.step / update_control)')
+    ap.add_argument('--capacity', type=int, default=1024,
                     help='landmarks per shared dictionary; a full dictionary projects instead of growing, and one '
                          'projection reads capacity^2 doubles of Kinv from a single workgroup')
     args = ap.parse_args()
@@ -68,27 +70,58 @@ def main():
     action = ia.copy()
     rounds = 0
     viol = 0.0
+    import ctypes as C
+    if args.host_loop:
+        # the same loop through host buffers (observations, labels and actions cross PCIe every step)
+        def run(k):
+            nonlocal state, action, rounds, viol
+            for _ in range(k):
+                obs, rew, _, info = env.step(action)
+                agent.update_control(state, action, info['SLA_labels'])
+                rounds += agent.rounds_last
+                action, adj = agent.select_action(obs)
+                state = obs
+                viol += float(info['total_violations'].mean())
+    else:
+        # device-resident: kb_shared_step_resident after rs_step_resident; only the per-round flag returns to the host
+        a0 = np.ascontiguousarray(ia)
+        env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+
+        def run(k):
+            nonlocal rounds
+            for _ in range(k):
+                agent.step_resident(env)
+                rounds += agent.rounds_last
+                env.step_resident()
+    run(args.warmup)
+    rounds, viol = 0, 0.0
+    env.synchronize()
+    agent.synchronize()
+    agent.set_kernel_timing(True)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        obs, rew, _, info = env.step(action)
-        agent.update_control(state, action, info['SLA_labels'])
-        rounds += agent.rounds_last
-        action, adj = agent.select_action(obs)
-        state = obs
-        viol += float(info['total_violations'].mean())
+    run(args.steps)
+    env.synchronize()
+    agent.synchronize()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     dt = max_over_ranks(time.perf_counter() - t0, device='cuda')
     sizes = [agent.learner(0, s)['m'] for s in range(len(dims))]
+    ph = agent.phase_times_ms()
+    if not args.host_loop:
+        f = env.fetch()
+        viol = float(f['violations'].sum(axis=1).mean()) * args.steps
+        action = f['actions']
     if rank == 0:
         print(json.dumps({'config': 'scenario_%d, %d envs x %d GPUs, shared KBRL dictionary per slice, RCCL all_gather merge'
                                     % (args.scenario, N, world), 'env_steps_per_s': world * N * args.steps / dt,
                           'ms_per_step': 1e3 * dt / args.steps, 'exchange_rounds_per_step': rounds / args.steps,
-                          'dictionary_sizes': sizes, 'violations_per_env_step': viol / args.steps,
+                          'loop': 'host buffers' if args.host_loop else 'device-resident (kb_shared_step_resident)',
+                          'capacity': args.capacity, 'scan_kernel_ms': ph['update_ms'], 'select_kernel_ms': ph['select_ms'],
+                          'dictionary_sizes': sizes, 'violations_per_env_step%s' % ('' if args.host_loop else '_last'): viol / args.steps,
                           'mean_prbs_last': float(action.sum(axis=1).mean())}))
     env.close(); agent.close()
     if use_dist:
