@@ -269,12 +269,13 @@ __device__ __forceinline__ void load_chunk(const double* P, int lane, int d, Chu
 
 template <int NG, int MODE>
 __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm,
-                                           int g0, double (&f)[NG]) {
+                                           int c_base, int ng, double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     int cb[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        cb[g] = (64 * (g0 + g) + lane) * 8;
+        const int c = c_base + 64 * g + lane;
+        cb[g] = (c < D.n_prbs ? c : D.n_prbs) * 8;  // lanes past the last candidate are never looked at
         f[g] = 0.0;
     }
     const int nch = (m + 63) >> 6;
@@ -319,9 +320,11 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
                 if (as8 >= 0) {
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
-                        int o = as8 - cb[g];
-                        o = o < 0 ? -o : o;
-                        f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
+                        if (g < ng) {  // (wave-uniform: only the groups the window reaches)
+                            int o = as8 - cb[g];
+                            o = o < 0 ? -o : o;
+                            f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
+                        }
                     }
                 } else {  // off-grid last coordinate: the exp itself
                     const double ls = readlane_f64(lam, jj);
@@ -338,7 +341,7 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
 
 // the single-landmark dictionary: numpy keeps k and coeff in float32 (kernel.py:16, projectron.py:9)
 template <int NG, int MODE>
-__device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, const uint64_t* sh, int d, const Lds& sm, int g0,
+__device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, const uint64_t* sh, int d, const Lds& sm, int c_base,
                                              double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     double* P = vec_page(K, sh, 0);
@@ -354,48 +357,60 @@ __device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, c
     const double lam = P[(d - 1) * KB_CH], co = P[KB_ROW_CO * KB_CH];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const double t = (double)(64 * (g0 + g) + lane) / (double)D.n_prbs;
+        const int c = c_base + 64 * g + lane;
+        const double t = (double)(c < D.n_prbs ? c : D.n_prbs) / (double)D.n_prbs;
         const double dl = lam - t;
         const double k = rs_exp(-D.gamma * (d0 + dl * dl));
         f[g] = (double)(float)((float)k * (float)co);
     }
 }
 
+// f[g] = f(c_base + 64 g + lane) for the first ng (<= NG) groups of 64 candidates
 template <int NG, int MODE>
-__device__ __forceinline__ void score(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm, int g0,
-                                      double (&f)[NG]) {
+__device__ __forceinline__ void score(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm, int c_base,
+                                      int ng, double (&f)[NG]) {
     if (m == 0) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) f[g] = 0.0;
     } else if (m == 1) {
-        score_single<NG, MODE>(D, K, sh, d, sm, g0, f);
+        score_single<NG, MODE>(D, K, sh, d, sm, c_base, f);
     } else {
-        score_pass<NG, MODE>(D, K, sh, m, d, sm, g0, f);
+        score_pass<NG, MODE>(D, K, sh, m, d, sm, c_base, ng, f);
     }
 }
 
+// the window of candidates a learner's scores cover: c_base + 64 g + lane, g < ng -- the augmentation range of the step
+// (kbrl_control.py:102-112: [a_i, n] after a fulfilled SLA, [0, a_i] after a violation), not all 256
+struct Win {
+    int base, ng;
+};
+__device__ __forceinline__ Win window_of(int c_from, int c_to) {
+    Win w = {c_from, (c_to - c_from) / 64 + 1};
+    return w;
+}
+
 // f of candidate c out of the four group registers (c's lane holds it): broadcast to the wave
-__device__ __forceinline__ double f_of(const double (&f)[4], int c) {
-    const int g = c >> 6, l = c & 63;
+__device__ __forceinline__ double f_of(const double (&f)[4], Win w, int c) {
+    const int g = (c - w.base) >> 6, l = (c - w.base) & 63;
     double v = g == 0 ? f[0] : (g == 1 ? f[1] : (g == 2 ? f[2] : f[3]));
     return readlane_f64(v, l);
 }
 
 // first candidate c in [c_from, c_to] (in order) with f(c) * y <= 0, or -1; *zeros = candidates with f == 0 among
 // [c_from, min(c_to, found)]
-__device__ __forceinline__ int first_mistake(const double (&f)[4], int y, int c_from, int c_to, int* zeros) {
+__device__ __forceinline__ int first_mistake(const double (&f)[4], Win w, int y, int c_from, int c_to, int* zeros) {
     const int lane = threadIdx.x & 63;
     int found = -1, nz = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int c = 64 * g + lane;
+        const int c = w.base + 64 * g + lane;
         const bool in = c >= c_from && c <= c_to;
         const unsigned long long bad = __ballot(in && f[g] * (double)y <= 0.0);
         const unsigned long long zer = __ballot(in && f[g] == 0.0);
         if (found < 0) {
             if (bad) {
                 const int l = __builtin_ctzll(bad);
-                found = 64 * g + l;
+                found = w.base + 64 * g + l;
                 nz += __builtin_popcountll(zer & ((l == 63) ? ~0ull : ((2ull << l) - 1ull)));
             } else {
                 nz += __builtin_popcountll(zer);
@@ -729,18 +744,19 @@ __device__ __forceinline__ void share_scores(double (&f)[4], Lds& sm) {
     for (int g = 0; g < 4; ++g) f[g] = sm.fbuf[g * 64 + (threadIdx.x & 63)];
 }
 
-__device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, double (&f)[4]) {
-    if (threadIdx.x < 64) score<4, 1>(D, K, sh, m, d, sm, 0, f);
+__device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, Win w,
+                                        double (&f)[4]) {
+    if (threadIdx.x < 64) score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
     share_scores(f, sm);
 }
 
 __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, int task, int env, int dict, int m, int d, int y,
-                                            int c_from, int c_to, double (&f)[4], Lds& sm, LoopStats& st) {
+                                            int c_from, int c_to, Win w, double (&f)[4], Lds& sm, LoopStats& st) {
     const uint64_t* sh = shells_of(D, K, dict);
     const int n = D.n_prbs;
     while (c_from <= c_to) {
         int zeros;
-        const int cstar = first_mistake(f, y, c_from, c_to, &zeros);
+        const int cstar = first_mistake(f, w, y, c_from, c_to, &zeros);
         const int last = cstar < 0 ? c_to : cstar;
         st.n_pred += (uint64_t)(last - c_from + 1);
         // the predictions made on the way each consume a tie-break draw when f == 0 (Q11)
@@ -766,14 +782,14 @@ __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, in
             const int lane = threadIdx.x & 63;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                int o = cstar - (64 * g + lane);
+                int o = cstar - (w.base + 64 * g + lane);
                 o = o < 0 ? -o : o;
-                f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
+                f[g] = __builtin_fma((double)y, sm.G[o < 255 ? o : 255], f[g]);
             }
             st.n_eval += left;
         } else {  // projection (every coefficient moved), or the first two landmarks
             if (branch == 2 && m_new > m) st.n_grow += 1;
-            rescore(D, K, sh, m_new, d, sm, f);
+            rescore(D, K, sh, m_new, d, sm, w, f);
             st.n_eval += left * (uint64_t)m_new;
         }
         m = m_new;
@@ -816,17 +832,18 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     LoopStats st = {1, 0, 0, (uint64_t)m};
 
     // ---- the classifier on every candidate of this state (the augmentation range contains a_i)
-    double f[4];
-    score<4, 0>(D, K, sh, m, d, sm, 0, f);
-    control_bookkeeping(D, K, task, env, s, m, f_of(f, a_i), y, A.hits, sm);
-
-    // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
     const int c_from = y == 1 ? a_i : 0;
     const int c_to = y == 1 ? n : a_i;
+    const Win w = window_of(c_from, c_to);
+    double f[4];
+    score<4, 0>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    control_bookkeeping(D, K, task, env, s, m, f_of(f, w, a_i), y, A.hits, sm);
+
+    // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
     st.n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
     if (!INLINE || m >= D.heavy_m) {
         int zeros;
-        const int cst = first_mistake(f, y, c_from, c_to, &zeros);
+        const int cst = first_mistake(f, w, y, c_from, c_to, &zeros);
         if (cst >= 0) {
             if (m >= KB_SMALL_M || INLINE) {
                 // the first repair is prepared here: scores, range, the mistake and its kernel column
@@ -855,10 +872,10 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
         }
     }
     if (INLINE) {
-        m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, f, sm, st);
+        m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, w, f, sm, st);
     } else {  // no mistake anywhere in the range: the predictions of the whole range were made (their ties draw, Q11)
         int zeros;
-        (void)first_mistake(f, y, c_from, c_to, &zeros);
+        (void)first_mistake(f, w, y, c_from, c_to, &zeros);
         st.n_pred += (uint64_t)(c_to - c_from + 1);
         if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
     }
@@ -880,9 +897,11 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& 
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
     LoopStats st = {0, 0, 0, 0};
+    const int c_from = y == 1 ? a_i : 0, c_to = y == 1 ? n : a_i;
+    const Win w = window_of(c_from, c_to);
     double f[4];
-    rescore(D, K, sh, m, d, sm, f);  // the E row is the one update_control_kernel left for this state
-    m = augment_loop(D, K, task, env, dict, m, d, y, y == 1 ? a_i : 0, y == 1 ? n : a_i, f, sm, st);
+    rescore(D, K, sh, m, d, sm, w, f);  // the E row is the one update_control_kernel left for this state
+    m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, w, f, sm, st);
     flush_stats(K, task, dict, m, st);
 }
 
@@ -949,6 +968,7 @@ __global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
         const int a_i = A.action[env * D.S + s];
         const int y = A.labels[env * D.S + s];
         const int c_to = y == 1 ? n : a_i;
+        const Win w = window_of(y == 1 ? a_i : 0, c_to);
         const int cstar = K.hv_cstar[slot];
         LoopStats st = {(uint64_t)K.hv_pend[2 * slot], 1, 0, 0};
         if (threadIdx.x == 0 && K.hv_pend[2 * slot + 1] > 0) K.tie_ctr[task] += (uint32_t)K.hv_pend[2 * slot + 1];  // Q11
@@ -976,17 +996,17 @@ __global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {  // one more term, E = 1 (augment_loop)
-                    int o = cstar - (64 * g + lane);
+                    int o = cstar - (w.base + 64 * g + lane);
                     o = o < 0 ? -o : o;
-                    f[g] = __builtin_fma((double)y, sm.G[o], f[g]);
+                    f[g] = __builtin_fma((double)y, sm.G[o < 255 ? o : 255], f[g]);
                 }
                 st.n_eval += left;
             } else {
-                rescore(D, K, sh, m_new, d, sm, f);
+                rescore(D, K, sh, m_new, d, sm, w, f);
                 st.n_eval += left * (uint64_t)m_new;
             }
             int zeros = 0;
-            const int next = c_from <= c_to ? first_mistake(f, y, c_from, c_to, &zeros) : -1;
+            const int next = c_from <= c_to ? first_mistake(f, w, y, c_from, c_to, &zeros) : -1;
             if (next < 0) {
                 st.n_pred += left;
                 if (zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
@@ -1039,7 +1059,8 @@ __global__ __launch_bounds__(KB_HEAVY_THREADS) void update_heavy_kernel(CtlArgs 
         double f[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) f[g] = K.hv_f[(size_t)slot * 256 + 64 * g + lane];
-        m = augment_loop(D, K, task, env, dict, m, d, y, K.hv_cfrom[slot], y == 1 ? n : a_i, f, sm, st);
+        m = augment_loop(D, K, task, env, dict, m, d, y, K.hv_cfrom[slot], y == 1 ? n : a_i, window_of(y == 1 ? a_i : 0, y == 1 ? n : a_i), f,
+                         sm, st);
         if (threadIdx.x == 0) K.hv_state[slot] = 0;
         flush_stats(K, task, dict, m, st);
     }
@@ -1062,9 +1083,9 @@ __device__ __forceinline__ int select_scan(const KbDev& D, const KbState& K, con
     for (int g = 0; 64 * g <= n && found < 0; ++g) {
         double f[1];
         if (g == 0)
-            score<1, MODE>(D, K, sh, m, d, sm, g, f);
+            score<1, MODE>(D, K, sh, m, d, sm, 64 * g, 1, f);
         else
-            score<1, MODE == 0 ? 1 : MODE>(D, K, sh, m, d, sm, g, f);
+            score<1, MODE == 0 ? 1 : MODE>(D, K, sh, m, d, sm, 64 * g, 1, f);
         const int c = 64 * g + lane;
         const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
         *n_scored += (uint64_t)(c1 - 64 * g + 1);
@@ -1235,19 +1256,20 @@ __global__ __launch_bounds__(64) void shared_scan_kernel(ScanArgs A) {
     load_gtab(K, sm);
     stage_state(D, A.state, env, s, d, sm);
     __syncthreads();
+    const Win w = window_of(y == 1 ? a_i : 0, c_to);
     double f[4];
-    score<4, 2>(D, K, sh, m, d, sm, 0, f);
+    score<4, 2>(D, K, sh, m, d, sm, w.base, w.ng, f);
     if (A.round == 0) {
         // y_pred, accuracy table, security factor: kbrl_control.py:88-101 (as update_control_kernel)
         n_pred += 1;
         n_eval += (uint64_t)m;
-        control_bookkeeping(D, K, task, env, s, m, f_of(f, a_i), y, A.hits, sm);
+        control_bookkeeping(D, K, task, env, s, m, f_of(f, w, a_i), y, A.hits, sm);
     }
     int cstar = -1;
     if (c_from >= 0 && c_from <= c_to) {
         n_eval += (uint64_t)(c_to - c_from + 1) * (uint64_t)m;
         int zeros;
-        cstar = first_mistake(f, y, c_from, c_to, &zeros);
+        cstar = first_mistake(f, w, y, c_from, c_to, &zeros);
         const int last = cstar >= 0 ? cstar : c_to;
         n_pred += (uint64_t)(last - c_from + 1);
         if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;  // Q11

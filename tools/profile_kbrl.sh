@@ -14,23 +14,23 @@ for W in 100 3000; do
   { echo "# rocprofv3 --kernel-trace --stats of: $CMD   (the summary covers the warm-up as well; see the last-200 lines)"
     echo "# the run's own line: $(cat /tmp/kt_${TAG}_$W.json)"
     python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 200
-    for KN in 'kb::update_heavy_kernel' 'kb::update_small_kernel' 'void kb::update_control_kernel<false>' 'kb::select_kernel'; do
+    for KN in 'void kb::update_control_kernel<false>' 'kb::update_small_kernel' 'kb::heavy_matvec_kernel' 'kb::heavy_finish_kernel' 'kb::heavy_rank1_kernel' 'kb::update_heavy_kernel' 'kb::select_kernel'; do
       python - "$DB" "$KN" <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
-d = [r[0] for r in c.execute("select end - start from kernels where name like ? order by start desc limit 200", (sys.argv[2] + '%',))]
+d = [r[0] for r in c.execute("select end - start from kernels where name like ? order by start desc limit ?", (sys.argv[2] + '%', 600 if 'heavy_' in sys.argv[2] and 'update' not in sys.argv[2] else 200))]
 if d:
-    print('# last %d launches of %s: mean %.0f ns (min %d, max %d)' % (len(d), sys.argv[2], sum(d) / len(d), min(d), max(d)))
+    print('# last %d launches of %s (= the last 200 steps): mean %.0f ns (min %d, max %d)' % (len(d), sys.argv[2], sum(d) / len(d), min(d), max(d)))
 PY
     done; } > $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
   head -12 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt; tail -4 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
 done
-PCMD="python tools/bench_kbrl.py --warmup 1000 --steps 20"
-echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch over the last 20 launches of each kb:: kernel (dictionaries of ~100 landmarks on average)" > $OUT/${TAG}_kbrl_pmc.txt
+PCMD="python tools/bench_kbrl.py --warmup 150 --steps 20"
+echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch over the last 20 launches of each kb:: kernel (steps 150-170 of learning: dictionaries of ~40 landmarks on average; counter collection costs ~20 ms per dispatch, so the late phase is not replayed under PMC)" > $OUT/${TAG}_kbrl_pmc.txt
 i=0
-for GRP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD" "FETCH_SIZE" "WRITE_SIZE"; do
+for GRP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD"; do
   i=$((i+1))
-  timeout 900 rocprofv3 --pmc $GRP -d /tmp/kpmc_${TAG}_$i -o p -- bash -c "cd $GRAFT_REPO_ROOT && $PCMD" > /tmp/kpmc_$i.log 2>&1; echo "group $i ($GRP) rc=$?"
+  timeout 300 rocprofv3 --pmc $GRP -d /tmp/kpmc_${TAG}_$i -o p -- bash -c "cd $GRAFT_REPO_ROOT && $PCMD" > /tmp/kpmc_$i.log 2>&1; echo "group $i ($GRP) rc=$?"
   DB=$(find /tmp/kpmc_${TAG}_$i -name '*.db' | head -1)
   [ -n "$DB" ] && python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 20 | grep -E "kb::" | grep "last 20" >> $OUT/${TAG}_kbrl_pmc.txt
 done

@@ -13,7 +13,7 @@ DB=$(find /tmp/prof_$TAG -name '*.db' | head -1)
   python -c "import json; l = json.loads(open('/tmp/prof_$TAG.json').read().strip().splitlines()[-1]); print('# the same run\'s bench line: %.0f env-steps/s, ms_per_step %.3f, roofline.kernel_ms %.4f (HIP events, %d timed launches), %.2f UEs/slice' % (l['value'], l['ms_per_step'], l['roofline']['kernel_ms'], l['roofline']['launches_timed'], l['roofline']['mean_ues_per_slice']))"
   python tools/rocpd_summary.py $DB --last 300; } > $OUT/${TAG}_kernel_trace_stats.txt
 head -14 $OUT/${TAG}_kernel_trace_stats.txt
-PCMD="python bench.py --steps 20 --warmup 5 --burn-in 1500 --no-cpu-baseline --no-kbrl"
+PCMD="python bench.py --steps 20 --warmup 5 --burn-in 500 --no-cpu-baseline --no-kbrl"   # (counter collection costs ~20 ms per dispatch: a short burn-in, 2.7 UEs/slice)
 echo "# rocprofv3 --pmc <counter> (one pass each) of: $PCMD ; per launch of embb_step_kernel<16,false>" > $OUT/${TAG}_pmc_hbm.txt
 for C in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $C -d /tmp/pmc_${TAG}_$C -o p -- bash -c "cd $GRAFT_REPO_ROOT && $PCMD" > /tmp/pmc_$C.log 2>&1; echo "$C rc=$?" )
@@ -31,11 +31,3 @@ for GRP in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_INSTS_VALU SQ_INSTS_SALU
   [ -n "$DB" ] && python tools/rocpd_summary.py $DB --last 20 | grep -E "embb_step_kernel<16" | grep "last 20" >> $OUT/${TAG}_pmc_sq.txt
 done
 cat $OUT/${TAG}_pmc_sq.txt
-# config 3 (agents in the loop): kernel trace of the bench's kbrl leg
-KCMD="python bench.py --steps 50 --warmup 5 --burn-in 300 --no-cpu-baseline --kbrl-steps 200"
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/kprof_$TAG -o t -- bash -c "cd $GRAFT_REPO_ROOT && $KCMD > /tmp/kprof_$TAG.json" > /tmp/kprof_$TAG.log 2>&1 )
-DB=$(find /tmp/kprof_$TAG -name '*.db' | head -1)
-{ echo "# rocprofv3 --kernel-trace --stats of: $KCMD  (random-script leg first, then the kbrl leg: BLOCK instance <16,false,true> + kb_* kernels)"
-  python -c "import json; l = json.loads(open('/tmp/kprof_$TAG.json').read().strip().splitlines()[-1]); k = l['kbrl']; print('# kbrl record of the same run: %.0f env-steps/s, ms_per_step %.3f, embb_kernel_ms %.3f, kb kernels %.3f ms each' % (k['value'], k['ms_per_step'], k['embb_kernel_ms'], k['kb_kernel_ms_mean_of_update_and_select']))"
-  python tools/rocpd_summary.py $DB; } > $OUT/${TAG}_kbrl_kernel_trace_stats.txt
-head -24 $OUT/${TAG}_kbrl_kernel_trace_stats.txt
