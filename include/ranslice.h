@@ -205,8 +205,8 @@ typedef struct kb_config {
     int32_t first_env;            /* shared mode: global id of this handle's replica 0 (rank * n_envs) */
     int64_t pool_bytes;           /* device memory all dictionaries of the handle grow in (landmarks, coefficients, Kinv:
                                      SVvariable / Projectron.Kinv, projectron.py:3-30, which the reference grows without
-                                     bound).  0: every dictionary at its capacity, or half of the free device memory,
-                                     whichever is smaller */
+                                     bound).  0: the smallest of every dictionary at its capacity, 1 GB + 2 MB per
+                                     dictionary, and half of the free device memory */
 } kb_config;
 
 typedef struct kb_handle kb_handle;

@@ -53,7 +53,7 @@ class Evaluator():
 class BatchedEvaluator(Evaluator):
     """All runs of one (scenario, accuracy range) at once: run i = replica i."""
 
-    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=0, verbose=True):
+    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True):
         import ctypes as C
         from ranslice import config as _c
         from ranslice.kbrl_dev import VecKBRL
