@@ -40,6 +40,8 @@ struct kb_handle {
     int budget_cap = 256;
     int heavy_blocks = 1024;
     int heavy_rounds = 3;
+    int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
+    bool rounds_always = false;
     int n_dict = 0;
     int T = 0, nv = 0;
     bool is_reset = false;
@@ -193,7 +195,12 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     D.eta = cfg->eta;
     D.shared = cfg->shared_dictionary ? 1 : 0;
     D.heavy_m = getenv("KBRL_HEAVY_M") ? atoi(getenv("KBRL_HEAVY_M")) : 0;  // developer knob; results do not depend on it
-    if (getenv("KBRL_ROUNDS")) k->heavy_rounds = atoi(getenv("KBRL_ROUNDS"));  // developer knob; results do not depend on it
+    if (getenv("KBRL_ROUNDS")) {  // developer knob (tests): that many rounds, always enqueued; results do not depend on it
+        k->heavy_rounds = atoi(getenv("KBRL_ROUNDS"));
+        k->rounds_always = true;
+    }
+    if (hipHostMalloc((void**)&k->h_seen, sizeof(int32_t), hipHostMallocMapped) != hipSuccess) k->h_seen = nullptr;
+    if (k->h_seen) *k->h_seen = 0;
     D.serial_apply = getenv("KBRL_SERIAL_APPLY") ? 1 : 0;  // test knob: the batched apply of full dictionaries off
     D.first_env = cfg->first_env;
     k->nv = o;
@@ -287,6 +294,7 @@ extern "C" void kb_destroy(kb_handle* k) {
     kb_comm_release(k);
     if (k->d_gather) (void)hipFree(k->d_gather);
     kb_history_release(k);
+    if (k->h_seen) (void)hipHostFree(k->h_seen);
     if (k->stream) (void)hipStreamDestroy(k->stream);
     delete k;
 }
@@ -314,6 +322,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 4, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
+    if (k->h_seen) *k->h_seen = 0;
     (void)hipFree(dseed);
     k->is_reset = true;
     return RS_OK;
@@ -379,13 +388,18 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         // each, taken by persistent workgroups
         const unsigned blocks = (unsigned)(k->T < k->heavy_blocks ? k->T : k->heavy_blocks);
         hipLaunchKernelGGL(kb::update_small_kernel, dim3((unsigned)(k->T < 4096 ? k->T : 4096)), dim3(256), 0, k->stream, a);
-        for (int r = 0; r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
+        // The rounds are nine launches that do nothing while no dictionary is large (early in learning): they are
+        // enqueued only once a recent step has queued a few large learners.  The host reads that count from pinned memory
+        // without waiting for the device, so it lags by the depth of the launch queue; until it catches up the clean-up
+        // kernel below, which is always launched, repairs them one workgroup each.  Results do not depend on it.
+        const bool rounds = k->rounds_always || (k->h_seen && *(volatile int32_t*)k->h_seen >= 8);
+        for (int r = 0; rounds && r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
             hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(1024, 16), dim3(256), 0, k->stream, k->D, k->K);
             hipLaunchKernelGGL(kb::heavy_finish_kernel, dim3(1024), dim3(256), 0, k->stream, a);
             hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3(1024, 16), dim3(256), 0, k->stream, k->D, k->K);
         }
         hipLaunchKernelGGL(kb::update_heavy_kernel, dim3(blocks), dim3(KB_HEAVY_THREADS), 0, k->stream, a);
-        hipLaunchKernelGGL(kb::heavy_reset_kernel, dim3(1), dim3(1), 0, k->stream, k->K);
+        hipLaunchKernelGGL(kb::heavy_reset_kernel, dim3(1), dim3(1), 0, k->stream, k->K, (volatile int32_t*)k->h_seen);
     }
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));  // the whole update phase
     return RS_OK;

@@ -1700,7 +1700,12 @@ __global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K,
         }
 }
 
-__global__ void heavy_reset_kernel(KbState K) { K.heavy[0] = K.heavy[1] = K.heavy[2] = K.heavy[3] = 0; }
+// end of the update phase: the queues are emptied for the next step; how many large learners were queued goes to a word of
+// host memory the launcher reads WITHOUT synchronising (it decides whether the next steps enqueue the repair rounds at all)
+__global__ void heavy_reset_kernel(KbState K, volatile int32_t* seen) {
+    if (seen) *seen = K.heavy[0];
+    K.heavy[0] = K.heavy[1] = K.heavy[2] = K.heavy[3] = 0;
+}
 
 __global__ void kb_gtab_kernel(KbDev D, KbState K) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;

@@ -434,17 +434,22 @@ def test_projectron_long_golden_to_790_landmarks(golden_dir):
     ag.close()
 
 
-@pytest.mark.parametrize('name,min_m,heavy_m', [('g15_kbrl_long_s0', 200, None), ('g16_kbrl_long_tdl_s0', 0, None),
-                                                ('g15_kbrl_long_s0', 200, 100), ('g16_kbrl_long_tdl_s0', 0, 1000000)])
-def test_kbrl_control_long_golden(golden_dir, monkeypatch, name, min_m, heavy_m):
+@pytest.mark.parametrize('name,min_m,heavy_m,rounds', [('g15_kbrl_long_s0', 200, None, None), ('g15_kbrl_long_s0', 200, None, 3),
+                                                       ('g16_kbrl_long_tdl_s0', 0, None, 2), ('g15_kbrl_long_s0', 200, 100, 1),
+                                                       ('g16_kbrl_long_tdl_s0', 0, 1000000, None)])
+def test_kbrl_control_long_golden(golden_dir, monkeypatch, name, min_m, heavy_m, rounds):
     """G15 / G16: KBRL_Control teacher-forced over the reference's 2,200 recorded steps of scenario_0 (G15: dictionaries
     of several hundred landmarks): every hit, selected action, adjusted flag, margin, security factor and dictionary
-    size; final landmarks exact, coefficients 1e-6.  By default every learner with a mistake to repair is finished by
-    update_heavy_kernel (a workgroup each); KBRL_HEAVY_M = h keeps learners below h landmarks in the one-wave kernel (the
-    last two cases: a mix of both paths, and the one-wave path alone)."""
+    size; final landmarks exact, coefficients 1e-6.  Learners with a mistake to repair are queued: small dictionaries for
+    update_small_kernel; large ones (192 landmarks and more) for the chip-wide repair rounds, which a single agent never
+    triggers on its own (they start once a step has queued eight large learners) -- KBRL_ROUNDS = r forces r rounds per
+    step, whatever is left goes to the per-learner clean-up, which does all of it in the first case.  KBRL_HEAVY_M = h
+    keeps learners below h landmarks in the one-wave kernel (a mix of paths, and the one-wave path alone)."""
     from ranslice.kbrl_dev import VecKBRL
     if heavy_m is not None:
         monkeypatch.setenv('KBRL_HEAVY_M', str(heavy_m))
+    if rounds is not None:
+        monkeypatch.setenv('KBRL_ROUNDS', str(rounds))
     g = _load(golden_dir, name)
     dims, n_prbs = _dims(0)
     ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=4096)
