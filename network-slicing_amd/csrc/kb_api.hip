@@ -267,13 +267,23 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.workb, D.shared ? (size_t)cfg->n_slices * 2 * k->budget_cap * kb::kb_capr(cfg->capacity) : 1, true);
     KA(k->d_props, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
     KA(k->d_counts, (size_t)cfg->n_slices, true);
-    KA(k->d_gstats, 4, true);
+    KA(k->d_gstats, 32, true);
     KA(k->d_block, (size_t)cfg->n_slices * (1 + (size_t)k->budget_cap * KB_PROP_W), true);
     KA(k->d_mprops, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
     KA(k->d_mcounts, (size_t)cfg->n_slices, true);
     KA(k->d_taken, (size_t)cfg->n_slices, true);
     KA(k->d_total, 1, true);
 #undef KA
+    if (D.shared) {
+        // shared_apply_kernel keeps the coefficient column of a full dictionary and the proposals' Gram block in LDS
+        const size_t lds = sizeof(double) * kb::kb_apply_lds_doubles(cfg->capacity, k->budget_cap);
+        if (lds > 150 * 1024) {
+            k->err = "kb_create: shared dictionaries hold at most ~14,000 landmarks (the batched apply keeps a column in LDS)";
+            return RS_EINVAL;
+        }
+        if (lds > 48 * 1024)
+            HIPCHK(k, hipFuncSetAttribute((const void*)kb::shared_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
     hipLaunchKernelGGL(kb::kb_gtab_kernel, dim3((KB_GTAB + 255) / 256), dim3(256), 0, k->stream, k->D, k->K);
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -283,6 +293,15 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
 extern "C" void kb_destroy(kb_handle* k) {
     if (!k) return;
     if (k->stream) (void)hipStreamSynchronize(k->stream);
+    if (k->D.shared && getenv("KBRL_APPLY_TIMES") && k->d_gstats) {  // developer aid: where shared_apply_kernel spends its time
+        uint64_t g[32];
+        if (hipMemcpy(g, k->d_gstats, sizeof g, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int s = 0; s < k->cfg.n_slices; ++s)
+                fprintf(stderr, "shared_apply slice %d: %.3f ms in total, %llu samples applied of %llu proposed\n", s,
+                        (double)g[8 + s] / 1e5, (unsigned long long)g[16 + s], (unsigned long long)g[24 + s]);
+        fprintf(stderr, "batched apply phases (ms in total): column + flags %.3f, Gram tiles %.3f, f0 %.3f, ordered walk %.3f, coefficient update %.3f\n",
+                (double)g[3] / 1e5, (double)g[4] / 1e5, (double)g[5] / 1e5, (double)g[6] / 1e5, (double)g[7] / 1e5);
+    }
     if (guards_on()) check_guards(k->guarded, "kb");
     for (auto& g : k->guarded) (void)hipFree(g.base);
     for (void* p : k->allocs) (void)hipFree(p);
@@ -319,7 +338,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.m, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.shell, 0, sizeof(uint64_t) * (size_t)k->n_dict * k->D.max_shells, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.head, 0xFF, sizeof(int32_t) * (size_t)k->n_dict * KB_HEAD, k->stream));
-    HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 4, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (k->h_seen) *k->h_seen = 0;
@@ -347,7 +366,7 @@ static void launch_shared_apply(kb_handle* k, const double* props, const int32_t
     const unsigned S = (unsigned)k->cfg.n_slices;
     hipLaunchKernelGGL(kb::shared_cols_kernel, dim3(S, KB_COLS_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, props, counts, budget);
     hipLaunchKernelGGL(kb::shared_matvec_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
-    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), sizeof(double) * ((size_t)kb::kb_capr(k->cfg.capacity) + (size_t)k->budget_cap), k->stream, k->D, k->K,
+    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), sizeof(double) * kb::kb_apply_lds_doubles(k->cfg.capacity, k->budget_cap), k->stream, k->D, k->K,
                        props, counts, budget, k->d_gstats);
 }
 

@@ -110,6 +110,9 @@ struct KbState {
 };
 
 __host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
+__host__ __device__ inline size_t kb_apply_lds_doubles(int cap, int budget) {  // shared_apply_kernel's dynamic LDS
+    return (size_t)kb_capr(cap) + (size_t)budget + 64 * 65 + 64 + (2 * 64 + 8) + 2 * 64 * 33;
+}
 __host__ __device__ inline uint64_t kb_shell_doubles(int b) { return (uint64_t)KB_VEC + (uint64_t)(2 * b + 1) * KB_TILE; }
 
 __device__ __forceinline__ const uint64_t* shells_of(const KbDev& D, const KbState& K, int dict) {
@@ -1495,13 +1498,23 @@ __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, 
     }
 }
 
-// the ordered part, by the slice's own workgroup (shared_apply_kernel): delta per proposal, then predict + projection in
-// list order.  co: the coefficient column in (dynamic) LDS.  Returns the number of mistakes.
+// The ordered part, by the slice's own workgroup (shared_apply_kernel).  A full dictionary only projects: proposal p is
+// still a mistake iff  f_p = k_p . coeff <= 0  for the coefficients as the EARLIER projections of the list left them,
+//     coeff = coeff_0 + sum_{q < p, applied} y_q d*_q    =>    f_p = k_p . coeff_0 + sum_{q < p, applied} y_q (k_p . d*_q),
+// so the only thing the order touches is a 64 x 64 matrix of scalars: the proposals' Gram block A = KF DS^T
+// (64 x 64 x m, a dense contraction: v_mfma_f64_16x16x4, one 16 x 16 tile per wave), f_p^0 = k_p . coeff_0 (one wave per
+// proposal, in parallel), then ONE wave walks the list -- 64 steps of a 64-lane dot -- and the coefficients take the
+// applied d*_q in list order, element by element exactly as the one-by-one path adds them (same bits).  Lists longer than
+// 64 go in sub-batches.  co: the coefficient column, flag / amat / f0 / wy: scratch in (dynamic) LDS.
+#define KB_SUB 64
 __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, const double* pr, int np, int budget,
-                                     double* co, double* flag) {
+                                     double* co, double* flag, double* amat, double* f0, double* wy, double* slab, uint64_t* gstats) {
+    unsigned long long tph = wall_clock64();
+#define KB_PH(i) if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd((unsigned long long*)&gstats[i], t_ - tph); tph = t_; }
     const int capr = kb_capr(D.cap);
     const uint64_t* sh = shells_of(D, K, s);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int kq = lane >> 4, li = lane & 15;
     const double* KF = K.workb + (size_t)s * 2 * budget * capr;
     const double* DS = KF + (size_t)budget * capr;
     for (int j = threadIdx.x; j < m; j += blockDim.x) co[j] = *vec_at(K, sh, KB_ROW_CO, j);
@@ -1513,28 +1526,105 @@ __device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, in
         if (lane == 0) flag[p] = delta > D.eta ? 1.0 : 0.0;
     }
     __syncthreads();
-    // ---- the proposals in order: predict against the evolving coefficients, project if still a mistake
+    KB_PH(3)
     uint64_t n_mist = 0;
-    if (wave == 0) {
-        bool sat = false;
-        for (int p = 0; p < np; ++p) {
-            const int y = (((int)pr[(size_t)p * KB_PROP_W + 1]) & 1) ? 1 : -1;
-            const double f = wave_dot256(KF + (size_t)p * capr, co, m);
-            if (f * (double)y <= 0.0) {
-                n_mist += 1;
-                sat = sat || flag[p] != 0.0;
-                const double* ds = DS + (size_t)p * capr;
-                for (int j = lane; j < m; j += 64) co[j] = co[j] + (double)y * ds[j];
+    bool sat = false;
+    for (int pb = 0; pb < np; pb += KB_SUB) {
+        const int ns = np - pb < KB_SUB ? np - pb : KB_SUB;
+        // ---- A[p][q] = k_p . d*_q: tile (ti, tj) by wave 4 ti + tj.  The operands go through LDS in slabs of 32 landmarks:
+        // all threads fetch the 64 x 32 blocks of KF and DS with coalesced loads (rows past the list read as zero), the
+        // waves take their MFMA operands from there (row stride 33: conflict-free)
+        {
+            kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ti = (wave & 15) >> 2, tj = wave & 3;
+            for (int k0 = 0; k0 < m; k0 += 32) {
+                __syncthreads();
+                for (int e = threadIdx.x; e < 64 * 32; e += blockDim.x) {
+                    const int r = e >> 5, c = e & 31, k = k0 + c;
+                    const bool in = r < ns && k < m;
+                    slab[r * 33 + c] = in ? KF[(size_t)(pb + r) * capr + k] : 0.0;
+                    slab[64 * 33 + r * 33 + c] = in ? DS[(size_t)(pb + r) * capr + k] : 0.0;
+                }
+                __syncthreads();
+                if (wave < 16) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const double a = slab[(16 * ti + li) * 33 + 4 * u + kq];
+                        const double b = slab[64 * 33 + (16 * tj + li) * 33 + 4 * u + kq];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                    }
+                }
+            }
+            // the lane holds A[16 ti + kq + 4 r][16 tj + li]
+            if (wave < 16) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) amat[(16 * ti + kq + 4 * r) * (KB_SUB + 1) + 16 * tj + li] = acc[r];
             }
         }
-        if (sat && lane == 0) atomicOr(&K.err[0], 8);  // a full dictionary met a sample it would have grown for
+        __syncthreads();
+        KB_PH(4)
+        // ---- f_p^0 against the coefficients as the previous sub-batch left them
+        for (int p = wave; p < ns; p += nw) {
+            const double v = wave_dot256(KF + (size_t)(pb + p) * capr, co, m);
+            if (lane == 0) f0[p] = v;
+        }
+        __syncthreads();
+        KB_PH(5)
+        // ---- the list in order: lane q keeps y_q if proposal q was applied
+        if (wave == 0) {
+            const int ylane = lane < ns ? ((((int)pr[(size_t)(pb + lane) * KB_PROP_W + 1]) & 1) ? 1 : -1) : 1;
+            const double f0l = lane < ns ? f0[lane] : 0.0, fl = lane < ns ? flag[pb + lane] : 0.0;
+            double wq = 0.0;
+            for (int p = 0; p < ns; ++p) {
+                double term = lane < p ? wq * amat[p * (KB_SUB + 1) + lane] : 0.0;
+                for (int dd = 32; dd >= 1; dd >>= 1) term += __shfl_xor(term, dd);
+                const int y = __builtin_amdgcn_readlane(ylane, p);
+                const double f = readlane_f64(f0l, p) + term;
+                const bool mistake = f * (double)y <= 0.0;
+                if (lane == p) wq = mistake ? (double)y : 0.0;
+                if (mistake) {
+                    n_mist += 1;
+                    sat = sat || readlane_f64(fl, p) != 0.0;
+                }
+            }
+            // the applied proposals, compacted in list order: (index, y)
+            const unsigned long long am = __ballot(wq != 0.0);
+            if (wq != 0.0) {
+                const int pos = __builtin_popcountll(am & ((1ull << lane) - 1ull));
+                wy[pos] = (double)lane;
+                wy[KB_SUB + pos] = wq;
+            }
+            if (lane == 0) wy[2 * KB_SUB] = (double)__builtin_popcountll(am);
+        }
+        __syncthreads();
+        KB_PH(6)
+        // ---- coeff_j takes the applied d*_q in list order (the one-by-one path's own expression), four loads in flight
+        const int napp = (int)wy[2 * KB_SUB];
+        for (int j = threadIdx.x; j < m; j += blockDim.x) {
+            double c = co[j];
+            for (int a0 = 0; a0 < napp; a0 += 4) {
+                double v[4], yy[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int a = a0 + u < napp ? a0 + u : a0;
+                    v[u] = DS[(size_t)(pb + (int)wy[a]) * capr + j];
+                    yy[u] = wy[KB_SUB + a];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (a0 + u < napp) c = c + yy[u] * v[u];
+            }
+            co[j] = c;
+        }
+        __syncthreads();
+        KB_PH(7)
     }
-    __syncthreads();
+    if (sat && threadIdx.x == 0) atomicOr(&K.err[0], 8);  // a full dictionary met a sample it would have grown for
     for (int j = threadIdx.x; j < m; j += blockDim.x) *vec_at(K, sh, KB_ROW_CO, j) = co[j];
     return n_mist;
 }
 
-// apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order.  Dynamic LDS: capr + budget doubles.
+// apply a merged proposal list to the dictionary of slice s = blockIdx.x, in order.  Dynamic LDS: kb_apply_lds_doubles().
 __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,
                                                          int budget, uint64_t* gstats) {
     extern __shared__ double kb_dyn_lds[];
@@ -1545,49 +1635,108 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     int m = K.m[s];
     const int np = counts[s] < budget ? counts[s] : budget;
     uint64_t n_mist = 0, n_grow = 0;
+    const unsigned long long t_in = wall_clock64();  // (developer aid: per-slice time and applied samples, gstats[8..])
     if (np > 0 && batch_applies(D, m)) {
         // kernel columns and d* of the whole list are in the work area (shared_cols_kernel, shared_matvec_kernel)
-        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, kb_dyn_lds,
-                                  kb_dyn_lds + kb_capr(D.cap));
-        if (threadIdx.x == 0) atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
+        double* p_co = kb_dyn_lds;
+        double* p_flag = p_co + kb_capr(D.cap);
+        double* p_amat = p_flag + budget;
+        double* p_f0 = p_amat + KB_SUB * (KB_SUB + 1);
+        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, p_co, p_flag, p_amat, p_f0,
+                                  p_f0 + KB_SUB, p_f0 + KB_SUB + (2 * KB_SUB + 8), gstats);
+        if (threadIdx.x == 0) {
+            atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
+            atomicAdd((unsigned long long*)&gstats[8 + s], wall_clock64() - t_in);
+            atomicAdd((unsigned long long*)&gstats[16 + s], (unsigned long long)n_mist);
+            atomicAdd((unsigned long long*)&gstats[24 + s], (unsigned long long)np);
+        }
         return;
     }
-    for (int i = 0; i < np; ++i) {
+    // A dictionary that can still grow: the proposals are predicted against it TOGETHER (a wave per proposal, each sum in
+    // the shape the one-by-one predict uses: kernel values in kernel_column_full's arithmetic, wave_dot256's partial
+    // sums), the first one in list order that is still a mistake is applied (Projectron.update), and what follows it is
+    // predicted again.  The list costs one parallel pass per APPLIED sample instead of one predict per proposal -- most
+    // of a round's proposals stop being mistakes once the first few are learned -- and every number is the one the
+    // one-by-one walk produces.
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6, lane = threadIdx.x & 63;
+    double* fp = kb_dyn_lds;  // [budget] predictions of the remaining proposals
+    int from = 0;
+    while (from < np) {
+        __syncthreads();
+        for (int i = from + wave; i < np; i += nw) {
+            const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
+            const double t = (double)(((int)p[1]) >> 2) / (double)D.n_prbs;
+            double part[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                for (int j = 64 * v + lane; j < m; j += 256) {
+                    const double* P = vec_page(K, sh, j >> 6);
+                    double d0 = 0.0;
+                    for (int q = 0; q < d - 1; ++q) {
+                        const double u = P[q * KB_CH + lane] - p[2 + q];
+                        d0 += u * u;
+                    }
+                    const double dl = P[(d - 1) * KB_CH + lane] - t;
+                    double k = rs_exp(-D.gamma * (d0 + dl * dl));
+                    if (m == 1) k = (double)(float)k;
+                    part[v] += k * P[KB_ROW_CO * KB_CH + lane];
+                }
+            }
+            for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
+            }
+            double f = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) f += __shfl(part[v], 0);
+            if (m == 1) {  // float32 while a single landmark is held (kernel.py:16, projectron.py:9)
+                const double* P = vec_page(K, sh, 0);
+                double d0 = 0.0;
+                for (int q = 0; q < d - 1; ++q) {
+                    const double u = P[q * KB_CH] - p[2 + q];
+                    d0 += u * u;
+                }
+                const double dl = P[(d - 1) * KB_CH] - t;
+                f = (double)(float)((float)rs_exp(-D.gamma * (d0 + dl * dl)) * (float)P[KB_ROW_CO * KB_CH]);
+            }
+            if (m == 0) f = 0.0;
+            if (lane == 0) fp[i] = f;
+        }
+        __syncthreads();
+        // the first remaining proposal, in order, that is still a mistake
+        if (threadIdx.x == 0) sm.ired[5] = 0x7fffffff;
+        __syncthreads();
+        for (int i = from + (int)threadIdx.x; i < np; i += blockDim.x) {
+            const int y = (((int)props[((size_t)s * budget + i) * KB_PROP_W + 1]) & 1) ? 1 : -1;
+            if (fp[i] * (double)y <= 0.0) atomicMin(&sm.ired[5], i);
+        }
+        __syncthreads();
+        const int i = sm.ired[5];
+        __syncthreads();
+        if (i == 0x7fffffff) break;
         const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
         const int packed = (int)p[1];
         const int c = packed >> 2, y = (packed & 1) ? 1 : -1;
-        __syncthreads();
         if ((int)threadIdx.x < d - 1) sm.x[threadIdx.x] = p[2 + threadIdx.x];
         __syncthreads();
-        // Projectron.predict on (state, c/n): f = k . coeff (float32 while a single landmark is held)
         const double t = (double)c / (double)D.n_prbs;
         kernel_column_full(D, K, sh, m, d, sm.x, t);
-        double f = 0.0;
-        if (m >= 2) {
-            if (threadIdx.x < 64) {
-                const double v = wave_dot256_rows(K, sh, KB_ROW_KF, KB_ROW_CO, m);
-                if (threadIdx.x == 0) sm.red[14] = v;
-            }
-            __syncthreads();
-            f = sm.red[14];
-            __syncthreads();
-        } else if (m == 1) {
-            f = (double)(float)((float)*vec_at(K, sh, KB_ROW_KF, 0) * (float)*vec_at(K, sh, KB_ROW_CO, 0));
-        }
-        if (f * (double)y <= 0.0) {  // still a mistake against the evolving dictionary
-            int branch;
-            double delta;
-            const int m_new = apply_update(D, K, s, 0, m, d, sm.x, t, c, y, sm, &branch, &delta);
-            n_mist += 1;
-            if (branch == 2 && m_new > m) n_grow += 1;
-            m = m_new;
-        }
+        int branch;
+        double delta;
+        const int m_new = apply_update(D, K, s, 0, m, d, sm.x, t, c, y, sm, &branch, &delta);
+        n_mist += 1;
+        if (branch == 2 && m_new > m) n_grow += 1;
+        m = m_new;
+        from = i + 1;
     }
     if (threadIdx.x == 0) {
         K.m[s] = m;
         if (np > 0) K.kf_owner[s] = -1;
         atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
         atomicAdd((unsigned long long*)&gstats[2], (unsigned long long)n_grow);
+        atomicAdd((unsigned long long*)&gstats[8 + s], wall_clock64() - t_in);
+        atomicAdd((unsigned long long*)&gstats[16 + s], (unsigned long long)n_mist);
+        atomicAdd((unsigned long long*)&gstats[24 + s], (unsigned long long)np);
     }
 }
 
