@@ -56,6 +56,7 @@ namespace kb {
 #endif
 #define KB_SMALL_M 192     // dictionaries below this repair their mistakes on one wave, larger ones on a workgroup
 #define KB_HEAVY_THREADS 512
+#define KB_E_TINY 1e-280   // below this E_j G[.] would leave the normal range: direct evaluation (score_pass)
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 
 typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
@@ -290,11 +291,10 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
         R = Rn;
         if (b + 1 < nch) load_chunk<MODE>(vec_page(K, sh, b + 1), lane, d, Rn);
         const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
-        double E;
+        double E, d0 = 0.0;
         if (MODE == 1) {
             E = R.v[0];
         } else {
-            double d0 = 0.0;
             if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82)
 #pragma unroll
                 for (int q = 0; q < 10; ++q) {
@@ -311,8 +311,14 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
             }
         }
         const double lam = R.lam;
-        const double w = lane < cnt ? R.co * E : 0.0;
-        const int a8 = lane < cnt ? R.a * 8 : 0;
+        // The product E_j G[.] is the kernel value to a few ulp only while E_j is a normal number.  An outlier state (a
+        // normalised queue of 60 against landmarks near 1) puts every E_j at 1e-300 and below, where the reference's
+        // exp(-gamma (D0 + dl^2)) is a handful of subnormal quanta or exactly zero (its f == 0 ties, kernel.py:26-27):
+        // such landmarks -- and those whose last coordinate is off the grid -- take the exponential itself.
+        const bool direct = lane < cnt && (R.a < 0 || !(E >= KB_E_TINY));
+        if (MODE == 1 && __ballot(direct)) d0 = P[KB_ROW_D0 * KB_CH + lane];
+        const double w = lane < cnt ? (direct ? R.co : R.co * E) : 0.0;
+        const int a8 = lane < cnt ? (direct ? -8 : R.a * 8) : 0;
         // lanes past the end of the dictionary carry w = 0 on the grid: the loop may run to the next multiple of four
         for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
 #pragma unroll
@@ -329,12 +335,12 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
                             f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
                         }
                     }
-                } else {  // off-grid last coordinate: the exp itself
-                    const double ls = readlane_f64(lam, jj);
+                } else {  // the exponential itself (ws carries coeff_j here)
+                    const double ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
 #pragma unroll
                     for (int g = 0; g < NG; ++g) {
                         const double dl = ls - (double)(cb[g] >> 3) / (double)D.n_prbs;
-                        f[g] = __builtin_fma(ws, rs_exp_nonpos(-D.gamma * (dl * dl)), f[g]);
+                        f[g] = __builtin_fma(ws, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
                     }
                 }
             }

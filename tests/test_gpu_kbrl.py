@@ -616,3 +616,64 @@ def test_pool_grows_on_demand_and_reports_exhaustion():
     with pytest.raises(_lib.RanSliceError):
         VecKBRL(64, [10] * 5, 200, capacity=1024, pool_bytes=1 << 20)     # not even one shell per dictionary
     ag.close()
+
+
+def test_long_closed_loop_with_repair_rounds_vs_oracle():
+    """BASELINE config 3's loop well past the start of learning: 4096 replicas of scenario_0 with one KBRL agent each, closed
+    on the device for 1,200 steps -- long enough for hundreds of dictionaries to pass 192 landmarks, so that the chip-wide
+    repair rounds (heavy_matvec / heavy_finish / heavy_rank1), the small-dictionary repair kernel and the per-learner
+    clean-up all take part, with the launcher switching the rounds on by itself.  16 sampled replicas against oracle env +
+    oracle agent on the same streams: executed actions, observations (bits), labels and selected actions at EVERY step,
+    dictionary sizes at the end.  (Kernel values differ by ulps between the two; a sign decision would have to sit within
+    1e-15 of zero to tell.)"""
+    import ctypes as C
+    from concurrent.futures import ProcessPoolExecutor
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps, cols, cap = 4096, 1200, 10000, 2048
+    scenario = 0
+    dims, n_prbs = _dims(scenario)
+    rng = np.random.default_rng(12)
+    ia = rng.integers(10, 35, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    sample = [0, 1, 63, 64, 255, 777, 1023, 1024, 2047, 2048, 3000, 3333, 4000, 4093, 4094, 4095]
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
+        fut = ex.map(_oracle_closed_loop, [(scenario, replica_seed(301, r), 9 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
+                     chunksize=1)
+        env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)],
+                          seed=301)
+        ag = VecKBRL(N, dims, n_prbs, capacity=cap, pool_bytes=48 << 30)
+        ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 9)
+        env.reset()
+        a0 = np.ascontiguousarray(ia)
+        env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        hip = []
+        executed = ia.copy()
+        for i in range(steps):
+            f = env.fetch()     # results of the step that executed `executed`
+            ag.step_resident(env)
+            nxt = env.fetch()['actions']
+            hip.append((executed[sample].copy(), f['obs'][sample].copy(), f['labels'][sample].copy(), nxt[sample].copy()))
+            executed = nxt
+            if i + 1 < steps:
+                env.step_resident()
+        ag.synchronize()
+        all_sizes = ag.dictionary_sizes()
+        sizes = [all_sizes[r].tolist() for r in sample]
+        pool = ag.pool()
+        env.close()
+        ag.close()
+        ref = list(fut)
+    assert (all_sizes >= 192).sum() >= 200, 'the run should have grown hundreds of large dictionaries: %d' % (all_sizes >= 192).sum()
+    assert pool['saturated'] == 0 and pool['pool_full'] == 0
+    for k, r in enumerate(sample):
+        steps_ref, m_ref = ref[k]
+        for i in range(steps):
+            act, obs, lab, hits, na, adj = steps_ref[i]
+            h = hip[i]
+            assert (h[0][k] == act).all(), ('executed action', r, i)
+            assert h[1][k].tobytes() == obs.tobytes(), ('obs', r, i)
+            assert (h[2][k] == lab).all(), ('labels', r, i)
+            assert (h[3][k] == na).all(), ('selected action', r, i, h[3][k], na)
+        assert sizes[k] == m_ref, (r, sizes[k], m_ref)
