@@ -315,10 +315,11 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
         // normalised queue of 60 against landmarks near 1) puts every E_j at 1e-300 and below, where the reference's
         // exp(-gamma (D0 + dl^2)) is a handful of subnormal quanta or exactly zero (its f == 0 ties, kernel.py:26-27):
         // such landmarks -- and those whose last coordinate is off the grid -- take the exponential itself.
-        const bool direct = lane < cnt && (R.a < 0 || !(E >= KB_E_TINY));
+        // (E_j == 0 exactly means -gamma D0 < -745.2: the kernel value is zero for every candidate, the landmark drops out)
+        const bool direct = lane < cnt && (R.a < 0 || (!(E >= KB_E_TINY) && E > 0.0));
         if (MODE == 1 && __ballot(direct)) d0 = P[KB_ROW_D0 * KB_CH + lane];
         const double w = lane < cnt ? (direct ? R.co : R.co * E) : 0.0;
-        const int a8 = lane < cnt ? (direct ? -8 : R.a * 8) : 0;
+        const int a8 = lane < cnt ? (direct ? -8 : (R.a < 0 ? 0 : R.a) * 8) : 0;
         // lanes past the end of the dictionary carry w = 0 on the grid: the loop may run to the next multiple of four
         for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
 #pragma unroll
