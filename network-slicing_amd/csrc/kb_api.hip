@@ -220,6 +220,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.heavy, T + 4, true);
     KA(K.hv_cfrom, T, true); KA(K.hv_cstar, T, true); KA(K.hv_state, T, true); KA(K.hv_grew, T, true); KA(K.hv_m, T, true);
     KA(K.hv_pend, 2 * T, true); KA(K.hv_delta, T, true); KA(K.hv_f, 256 * T, true);
+    KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true);
     {
         // The pool every dictionary of the handle grows in (kb_kbrl.hip, "Storage").  Upper bound on what can ever be
         // asked for: every dictionary at its capacity.  kb_config.pool_bytes == 0 picks a default below it.
@@ -412,10 +413,12 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         // without waiting for the device, so it lags by the depth of the launch queue; until it catches up the clean-up
         // kernel below, which is always launched, repairs them one workgroup each.  Results do not depend on it.
         const bool rounds = k->rounds_always || (k->h_seen && *(volatile int32_t*)k->h_seen >= 8);
+        if (rounds && k->heavy_rounds > 0) hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
         for (int r = 0; rounds && r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
-            hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(1024, 16), dim3(256), 0, k->stream, k->D, k->K);
+            hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
             hipLaunchKernelGGL(kb::heavy_finish_kernel, dim3(1024), dim3(256), 0, k->stream, a);
-            hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3(1024, 16), dim3(256), 0, k->stream, k->D, k->K);
+            hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
+            hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
         }
         hipLaunchKernelGGL(kb::update_heavy_kernel, dim3(blocks), dim3(KB_HEAVY_THREADS), 0, k->stream, a);
         hipLaunchKernelGGL(kb::heavy_reset_kernel, dim3(1), dim3(1), 0, k->stream, k->K, (volatile int32_t*)k->h_seen);

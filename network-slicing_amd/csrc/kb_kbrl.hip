@@ -106,6 +106,8 @@ struct KbState {
     int32_t* hv_m;      // [T] dictionary size before that insertion
     int32_t* hv_pend;   // [T][2] predictions / exact ties of the segment up to hv_cstar, counted when it is applied
     double* hv_delta;   // [T]
+    long long* hv_mvbase;  // [T + 1] prefix sums of the mat-vec work of the pending learners (heavy_plan_kernel)
+    long long* hv_r1base;  // [T + 1] prefix sums of the rank-1 work of the learners that inserted
     double* hv_f;       // [T][256] the scores of the candidates
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
 };
@@ -469,12 +471,12 @@ __device__ __forceinline__ void kernel_column_full(const KbDev& D, const KbState
 // A work unit is (64 W columns, one row class); the waves of the block share the units, eight rows are in flight per
 // lane (W doubles each), and the partial sums meet in eight rows of the vector pages.
 template <int W>
-__device__ __forceinline__ void matvec_partials(const KbState& K, const uint64_t* sh, int m, int u0, int ustride) {
+__device__ __forceinline__ void matvec_partials(const KbState& K, const uint64_t* sh, int m, int u0, int ustride, int u_end = 0x7fffffff) {
     static_assert(W == 1 || W == 2 || W == 4, "columns per lane");
     const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
     const int ncg = (nb + W - 1) / W;  // groups of W column blocks
     const int bsub = lane / (64 / W), coff = (lane % (64 / W)) * W;  // this lane's column block within the group, column in it
-    for (int u = u0; u < ncg * 8; u += ustride) {
+    for (int u = u0; u < ncg * 8 && u < u_end; u += ustride) {
         const int cg = u >> 3, sg = u & 7;
         const int bi = cg * W + bsub;
         const bool on = bi < nb;
@@ -531,10 +533,11 @@ __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* 
 // Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta (projectron.py:54-58) over the m1 = m + 1 landmarks, d* (with
 // its -1) in the DS row.  A work unit is 16 rows of a tile: all 16 loads of a lane are in flight before the first store
 // (d_i broadcast from the row block's lanes, d_j in this lane).  Every entry is formed as old + (d_i d_j) (1 / delta).
-__device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh, int m, double delta, int u0, int ustride) {
+__device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh, int m, double delta, int u0, int ustride,
+                                            int u_end = 0x7fffffff) {
     const int m1 = m + 1, nb = (m1 + 63) >> 6, lane = threadIdx.x & 63;
     const double inv = 1.0 / delta;
-    for (int u = u0; u < nb * nb * 4; u += ustride) {
+    for (int u = u0; u < nb * nb * 4 && u < u_end; u += ustride) {
         const int tb = u >> 2, r0 = (u & 3) * 16;
         const int bi = tb / nb, bj = tb - bi * nb;
         const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
@@ -936,23 +939,103 @@ __global__ __launch_bounds__(256) void update_small_kernel(CtlArgs A) {
 //                         of the range, the next mistake and its kernel column -- or done
 //   heavy_rank1_kernel    Kinv's rank-1 update of the learners that inserted, units spread as above
 // After KB rounds (kb_api.hip) whatever is still pending is finished learner by learner by update_heavy_kernel.
+// The work of a round is spread over the launch by COST, not by learner: a dictionary of 1,755 landmarks has sixty times
+// the mat-vec and rank-1 work of one of 229, and a fixed number of workgroups per learner left the launch waiting for its
+// largest one.  heavy_plan_kernel (one workgroup) lays the learners' work end to end -- mat-vec: n_b^2 x 8 tile-row
+// passes (a unit = one column block and row class, n_b passes), rank-1: n_b^2 x 4 units -- and every wave of the two wide
+// kernels takes an equal stretch of that line (whole units; one binary search for where its stretch begins).
+__global__ __launch_bounds__(1024) void heavy_plan_kernel(KbDev D, KbState K) {
+    __shared__ long long sc[2][1024];
+    const int count = K.heavy[0], t = threadIdx.x;
+    long long carry_mv = 0, carry_r1 = 0;
+    for (int base = 0; base < count; base += 1024) {
+        const int slot = base + t;
+        long long wmv = 0, wr1 = 0;
+        if (slot < count) {
+            if (K.hv_state[slot] == 1) {
+                const long long nb = (K.m[dict_of(D, K.heavy[4 + slot])] + 63) >> 6;
+                wmv = nb * nb * 8;
+            }
+            if (K.hv_grew[slot] == 1) {
+                const long long nb1 = (K.hv_m[slot] + 1 + 63) >> 6;
+                wr1 = nb1 * nb1 * 4;
+            }
+        }
+        __syncthreads();
+        sc[0][t] = wmv;
+        sc[1][t] = wr1;
+        __syncthreads();
+        long long imv = wmv, ir1 = wr1;
+        for (int dd = 1; dd < 1024; dd <<= 1) {  // Hillis-Steele inclusive scans
+            const long long a = t >= dd ? sc[0][t - dd] : 0, b = t >= dd ? sc[1][t - dd] : 0;
+            __syncthreads();
+            imv += a;
+            ir1 += b;
+            sc[0][t] = imv;
+            sc[1][t] = ir1;
+            __syncthreads();
+        }
+        if (slot < count) {
+            K.hv_mvbase[slot] = carry_mv + imv - wmv;
+            K.hv_r1base[slot] = carry_r1 + ir1 - wr1;
+        }
+        carry_mv += sc[0][1023];
+        carry_r1 += sc[1][1023];
+    }
+    if (t == 0) {
+        K.hv_mvbase[count] = carry_mv;
+        K.hv_r1base[count] = carry_r1;
+    }
+}
+
+// the stretch [lo, hi) of wave w of the launch on a work line of `total`; the slot whose work contains `lo`
+__device__ __forceinline__ int stretch_of(const long long* base, int count, long long* lo, long long* hi) {
+    const long long total = base[count];
+    const long long nwaves = (long long)gridDim.x * (blockDim.x >> 6), w = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    *lo = total * w / nwaves;
+    *hi = total * (w + 1) / nwaves;
+    if (*lo >= *hi) return -1;
+    int a = 0, b = count;  // last slot with base[slot] <= lo
+    while (b - a > 1) {
+        const int mid = (a + b) >> 1;
+        if (base[mid] <= *lo) a = mid; else b = mid;
+    }
+    return a;
+}
+
 __global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
     const int count = K.heavy[0];
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
-        if (K.hv_state[slot] != 1) continue;
+    if (count == 0) return;
+    long long lo, hi;
+    int slot = stretch_of(K.hv_mvbase, count, &lo, &hi);
+    if (slot < 0) return;
+    for (; slot < count && lo < hi; ++slot) {
+        const long long sb = K.hv_mvbase[slot], se = K.hv_mvbase[slot + 1];
+        if (se <= lo) continue;  // (no work of its own, or entirely before the stretch)
         const int dict = dict_of(D, K.heavy[4 + slot]);
-        matvec_partials<1>(K, shells_of(D, K, dict), K.m[dict], blockIdx.y * nw + wave, gridDim.y * nw);
+        const int m = K.m[dict];
+        const long long nb = (m + 63) >> 6;
+        // units whose first pass lies in [lo, hi)
+        const long long a = lo > sb ? lo - sb : 0, b = (hi < se ? hi : se) - sb;
+        const int u0 = (int)((a + nb - 1) / nb), u1 = (int)((b + nb - 1) / nb);
+        if (u0 < u1) matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
+        lo = se;
     }
 }
 
 __global__ __launch_bounds__(256) void heavy_rank1_kernel(KbDev D, KbState K) {
     const int count = K.heavy[0];
-    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
-        if (K.hv_grew[slot] != 1) continue;
+    if (count == 0) return;
+    long long lo, hi;
+    int slot = stretch_of(K.hv_r1base, count, &lo, &hi);
+    if (slot < 0) return;
+    for (; slot < count && lo < hi; ++slot) {
+        const long long sb = K.hv_r1base[slot], se = K.hv_r1base[slot + 1];
+        if (se <= lo) continue;
         const int dict = dict_of(D, K.heavy[4 + slot]);
-        rank1_units(K, shells_of(D, K, dict), K.hv_m[slot], K.hv_delta[slot], blockIdx.y * nw + wave, gridDim.y * nw);
+        const int u0 = (int)(lo > sb ? lo - sb : 0), u1 = (int)((hi < se ? hi : se) - sb);
+        if (u0 < u1) rank1_units(K, shells_of(D, K, dict), K.hv_m[slot], K.hv_delta[slot], u0, 1, u1);
+        lo = se;
     }
 }
 
