@@ -257,7 +257,7 @@ __device__ __forceinline__ double dist0(const double* P, int lane, int d, const 
 template <int MODE>
 struct ChunkRows {
     double v[MODE == 1 ? 1 : 10];  // MODE 1: E; else the first ten coordinates (eMBB learners) for D0
-    double co, lam;
+    double co;
     int a;
 };
 template <int MODE>
@@ -270,7 +270,6 @@ __device__ __forceinline__ void load_chunk(const double* P, int lane, int d, Chu
     }
     R.co = P[KB_ROW_CO * KB_CH + lane];
     R.a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
-    R.lam = P[(d - 1) * KB_CH + lane];
 }
 
 template <int NG, int MODE>
@@ -312,39 +311,44 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
                 P[KB_ROW_E * KB_CH + lane] = E;
             }
         }
-        const double lam = R.lam;
         // The product E_j G[.] is the kernel value to a few ulp only while E_j is a normal number.  An outlier state (a
         // normalised queue of 60 against landmarks near 1) puts every E_j at 1e-300 and below, where the reference's
         // exp(-gamma (D0 + dl^2)) is a handful of subnormal quanta or exactly zero (its f == 0 ties, kernel.py:26-27):
-        // such landmarks -- and those whose last coordinate is off the grid -- take the exponential itself.
-        // (E_j == 0 exactly means -gamma D0 < -745.2: the kernel value is zero for every candidate, the landmark drops out)
+        // such landmarks -- and those whose last coordinate is off the grid -- take the exponential itself, after the
+        // chunk's table terms (E_j == 0 exactly means -gamma D0 < -745.2: zero for every candidate, the landmark drops out).
         const bool direct = lane < cnt && (R.a < 0 || (!(E >= KB_E_TINY) && E > 0.0));
-        if (MODE == 1 && __ballot(direct)) d0 = P[KB_ROW_D0 * KB_CH + lane];
-        const double w = lane < cnt ? (direct ? R.co : R.co * E) : 0.0;
-        const int a8 = lane < cnt ? (direct ? -8 : (R.a < 0 ? 0 : R.a) * 8) : 0;
-        // lanes past the end of the dictionary carry w = 0 on the grid: the loop may run to the next multiple of four
+        const bool table = lane < cnt && !direct && R.a >= 0;
+        const double w = table ? R.co * E : 0.0;
+        const int a8 = table ? R.a * 8 : 0;
+        // lanes without a table term carry w = 0: the loop may run to the next multiple of four
         for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int jj = jj0 + u;
                 const double ws = readlane_f64(w, jj);
                 const int as8 = __builtin_amdgcn_readlane(a8, jj);
-                if (as8 >= 0) {
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        if (g < ng) {  // (wave-uniform: only the groups the window reaches)
-                            int o = as8 - cb[g];
-                            o = o < 0 ? -o : o;
-                            f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
-                        }
+                for (int g = 0; g < NG; ++g) {
+                    if (g < ng) {  // (wave-uniform: only the groups the window reaches)
+                        int o = as8 - cb[g];
+                        o = o < 0 ? -o : o;
+                        f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
                     }
-                } else {  // the exponential itself (ws carries coeff_j here)
-                    const double ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
+                }
+            }
+        }
+        unsigned long long dm = __ballot(direct);
+        if (dm) {
+            if (MODE == 1) d0 = P[KB_ROW_D0 * KB_CH + lane];
+            const double lam = P[(d - 1) * KB_CH + lane];
+            while (dm) {
+                const int jj = __builtin_ctzll(dm);
+                dm &= dm - 1ull;
+                const double cs = readlane_f64(R.co, jj), ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
 #pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const double dl = ls - (double)(cb[g] >> 3) / (double)D.n_prbs;
-                        f[g] = __builtin_fma(ws, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
-                    }
+                for (int g = 0; g < NG; ++g) {
+                    const double dl = ls - (double)(cb[g] >> 3) / (double)D.n_prbs;
+                    f[g] = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
                 }
             }
         }
