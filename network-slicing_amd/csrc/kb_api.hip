@@ -40,6 +40,7 @@ struct kb_handle {
     int budget_cap = 256;
     int heavy_blocks = 1024;
     int heavy_rounds = 3;
+    int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
     bool rounds_always = false;
     int n_dict = 0;
@@ -221,6 +222,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.hv_cfrom, T, true); KA(K.hv_cstar, T, true); KA(K.hv_state, T, true); KA(K.hv_grew, T, true); KA(K.hv_m, T, true);
     KA(K.hv_pend, 2 * T, true); KA(K.hv_delta, T, true); KA(K.hv_f, 256 * T, true);
     KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true);
+    KA(K.big, 2 * (1 + KB_BIG_MAX), true); KA(K.isbig, 2 * T, true);
     {
         // The pool every dictionary of the handle grows in (kb_kbrl.hip, "Storage").  Upper bound on what can ever be
         // asked for: every dictionary at its capacity.  kb_config.pool_bytes == 0 picks a default below it.
@@ -343,6 +345,9 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (k->h_seen) *k->h_seen = 0;
+    k->big_par = 0;
+    HIPCHK(k, hipMemset(k->K.big, 0, sizeof(int32_t) * 2 * (1 + KB_BIG_MAX)));
+    HIPCHK(k, hipMemset(k->K.isbig, 0, sizeof(int32_t) * 2 * T));
     (void)hipFree(dseed);
     k->is_reset = true;
     return RS_OK;
@@ -396,13 +401,15 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
     a.action = d_action;
     a.labels = d_labels;
     a.hits = k->d_hits;
+    a.big_par = k->D.shared ? -1 : k->big_par;
+    const unsigned grid1 = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
     if (k->D.heavy_m > 0)
-        hipLaunchKernelGGL(kb::update_control_kernel<true>, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
+        hipLaunchKernelGGL(kb::update_control_kernel<true>, dim3(grid1), dim3(64), 0, k->stream, a);
     else
-        hipLaunchKernelGGL(kb::update_control_kernel<false>, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
+        hipLaunchKernelGGL(kb::update_control_kernel<false>, dim3(grid1), dim3(64), 0, k->stream, a);
     if (!k->D.shared) {
         // the learners with a mistake to repair: small dictionaries one wave each, all at once; large ones a workgroup
         // each, taken by persistent workgroups
@@ -432,13 +439,15 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     a.D = k->D;
     a.K = k->K;
     a.state = d_state;
+    a.big_par = k->D.shared ? -1 : k->big_par;
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1, 1);
     if (rc != RS_OK) return rc;
-    hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
+    hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0)), dim3(64), 0, k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,
-                       k->K, d_action_out);
+                       k->K, d_action_out, a.big_par);
+    if (a.big_par >= 0) k->big_par = 1 - k->big_par;  // select_kernel wrote the other list for the launches that follow
     return RS_OK;
 }
 

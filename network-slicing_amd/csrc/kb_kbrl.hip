@@ -56,6 +56,8 @@ namespace kb {
 #endif
 #define KB_SMALL_M 192     // dictionaries below this repair their mistakes on one wave, larger ones on a workgroup
 #define KB_HEAVY_THREADS 512
+#define KB_BIG_M 320       // dictionaries from this size on are launched first by the one-wave kernels
+#define KB_BIG_MAX 4096    // at most this many (the rest keep their place)
 #define KB_E_TINY 1e-280   // below this E_j G[.] would leave the normal range: direct evaluation (score_pass)
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 
@@ -109,6 +111,9 @@ struct KbState {
     long long* hv_mvbase;  // [T + 1] prefix sums of the mat-vec work of the pending learners (heavy_plan_kernel)
     long long* hv_r1base;  // [T + 1] prefix sums of the rank-1 work of the learners that inserted
     double* hv_f;       // [T][256] the scores of the candidates
+    // launch order of the one-wave kernels: learners with large dictionaries first (their waves are the long ones)
+    int32_t* big;      // [2][1 + KB_BIG_MAX]: count, then the learners select_kernel found at KB_BIG_M landmarks or more
+    int32_t* isbig;    // [2][T] membership of that list
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
 };
 
@@ -693,7 +698,21 @@ struct CtlArgs {
     const int32_t* action;  // [n_envs][S]
     const int32_t* labels;  // [n_envs][S]
     int32_t* hits;          // [n_envs][S]
+    int32_t big_par;        // which of the two large-learner lists orders this launch (-1: none, block index = learner)
 };
+
+// The learner of a workgroup of the one-wave kernels.  With a list: the first KB_BIG_MAX workgroups take the listed (large)
+// learners, the others their own index unless it is listed; -1: nothing to do.  The list is the one select_kernel wrote
+// at the end of the previous step (dictionaries only grow, and not between that select and these launches).
+__device__ __forceinline__ int learner_of_block(const KbState& K, int T, int par) {
+    if (par < 0) return (int)blockIdx.x;
+    if ((int)blockIdx.x < KB_BIG_MAX) {
+        const int32_t* L = K.big + (size_t)par * (1 + KB_BIG_MAX);
+        return (int)blockIdx.x < L[0] ? L[1 + blockIdx.x] : -1;
+    }
+    const int t = (int)blockIdx.x - KB_BIG_MAX;
+    return t < T && !K.isbig[(size_t)par * T + t] ? t : -1;
+}
 
 // y_pred of update_control's first predict, the accuracy table and the security factor (kbrl_control.py:88-101)
 __device__ __forceinline__ int control_bookkeeping(const KbDev& D, const KbState& K, int task, int env, int s, int m, double f0, int y,
@@ -836,7 +855,9 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
-    const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
+    const int task = learner_of_block(K, D.n_envs * D.S, A.big_par);
+    if (task < 0) return;
+    const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
     const uint64_t* sh = shells_of(D, K, dict);
@@ -1167,6 +1188,7 @@ struct SelArgs {
     KbDev D;
     KbState K;
     const float* state;  // [n_envs][nv] new state
+    int32_t big_par;     // the list that orders this launch; the other one is written for the next step (-1: none)
 };
 
 // per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63): the smallest candidate the classifier
@@ -1206,11 +1228,27 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
-    const int task = blockIdx.x, env = task / D.S, s = task - env * D.S;
+    const int T = D.n_envs * D.S;
+    const int task = learner_of_block(K, T, A.big_par);
+    if (task < 0) return;
+    const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
     const uint64_t* sh = shells_of(D, K, dict);
     const int m = K.m[dict];
+    if (A.big_par >= 0 && threadIdx.x == 0) {  // the next step's list (the other of the two)
+        const int pw = 1 - A.big_par;
+        int listed = 0;
+        if (m >= KB_BIG_M) {
+            int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
+            const int slot = atomicAdd(&L[0], 1);
+            if (slot < KB_BIG_MAX) {
+                L[1 + slot] = task;
+                listed = 1;
+            }
+        }
+        K.isbig[(size_t)pw * T + task] = listed;
+    }
     load_gtab(K, sm);
     stage_state(D, A.state, env, s, d, sm);
     __syncthreads();
@@ -1242,8 +1280,14 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 }
 
 // cross-learner part of select_action + adjust_action (kbrl_control.py:65-78)
-__global__ void adjust_kernel(KbDev D, KbState K, int32_t* action_out) {
+__global__ void adjust_kernel(KbDev D, KbState K, int32_t* action_out, int big_par) {
     const int env = blockIdx.x * blockDim.x + threadIdx.x;
+    if (env == 0 && big_par >= 0) {  // the list select_kernel just used is the one the next select writes: empty it (a count past
+                                     // KB_BIG_MAX in the other one only means that some learners kept their place)
+        K.big[(size_t)big_par * (1 + KB_BIG_MAX)] = 0;
+        int32_t* Lw = K.big + (size_t)(1 - big_par) * (1 + KB_BIG_MAX);
+        if (Lw[0] > KB_BIG_MAX) Lw[0] = KB_BIG_MAX;
+    }
     if (env >= D.n_envs) return;
     long assigned = 0;
     for (int s = 0; s < D.S; ++s) assigned += K.action[env * D.S + s];
