@@ -38,7 +38,7 @@ struct kb_handle {
     void* comm = nullptr;          // ncclComm_t (RCCL), bound at run time
     int comm_rank = 0, comm_world = 1;
     int budget_cap = 256;
-    int heavy_blocks = 1024;
+    int heavy_blocks = 256;
     int heavy_rounds = 3;
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
