@@ -35,7 +35,14 @@ static hipError_t guarded_malloc(void** q, size_t bytes, std::vector<GuardedAllo
     const size_t padded = (bytes + 255) / 256 * 256;
     hipError_t e = hipMalloc(&b, padded + 2 * kGuard);
     if (e != hipSuccess) return e;
-    e = hipMemset(b, 0xA5, padded + 2 * kGuard);
+    // the bands on both sides (and, for buffers of ordinary size, the payload too, so that reads of unwritten memory
+    // show; a multi-gigabyte dictionary pool only gets its bands)
+    if (padded <= ((size_t)1 << 30)) {
+        e = hipMemset(b, 0xA5, padded + 2 * kGuard);
+    } else {
+        e = hipMemset(b, 0xA5, kGuard);
+        if (e == hipSuccess) e = hipMemset((char*)b + kGuard + padded, 0xA5, kGuard);
+    }
     if (e != hipSuccess) return e;
     reg->push_back({b, padded});
     *q = (char*)b + kGuard;
