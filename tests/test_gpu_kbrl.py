@@ -677,3 +677,46 @@ def test_long_closed_loop_with_repair_rounds_vs_oracle():
             assert (h[2][k] == lab).all(), ('labels', r, i)
             assert (h[3][k] == na).all(), ('selected action', r, i, h[3][k], na)
         assert sizes[k] == m_ref, (r, sizes[k], m_ref)
+
+
+def test_long_closed_loop_run_to_run_and_reset():
+    """Two runs of 4096 replicas x 900 closed-loop steps from the same seeds on ONE pair of handles (the second after
+    env.reset / kb_reset): identical selected actions at every 25th step, identical dictionary sizes and coefficients at
+    the end.  Between the runs the order in which learners take shells from the pool differs (atomics), and so does the step
+    at which the launcher starts enqueueing the repair rounds (it reads a counter from pinned memory without waiting for
+    the device) -- neither may show.  kb_reset hands the whole pool back."""
+    import ctypes as C
+    import hashlib
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps, cols = 4096, 900, 10000
+    dims, n_prbs = _dims(0)
+    rng = np.random.default_rng(13)
+    ia = rng.integers(10, 35, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)], seed=302)
+    ag = VecKBRL(N, dims, n_prbs, capacity=2048, pool_bytes=32 << 30)
+    results = []
+    for rep in range(2):
+        env.reset()
+        ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 11)
+        assert ag.pool()['used_bytes'] == 64 * 8
+        a0 = np.ascontiguousarray(ia)
+        env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        h = hashlib.sha256()
+        for i in range(steps):
+            ag.step_resident(env)
+            if i % 25 == 24:
+                h.update(env.fetch()['actions'].tobytes())
+            if i + 1 < steps:
+                env.step_resident()
+        ag.synchronize()
+        sizes = ag.dictionary_sizes()
+        co = b''.join(ag.learner(r, s)['coeff'].tobytes() for r in (0, 1000, 4095) for s in range(5))
+        results.append((h.hexdigest(), sizes.tobytes(), co, int((sizes >= 192).sum()), ag.pool()['used_bytes']))
+    assert results[0][3] >= 50, 'large dictionaries should have appeared: %d' % results[0][3]
+    assert results[0][:3] == results[1][:3]
+    assert results[0][4] == results[1][4]      # the same shells were taken, in whatever order
+    env.close()
+    ag.close()
