@@ -55,6 +55,7 @@ FADING_COLS = 10000
 ACTION_SEED = 2024
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 F64_PEAK_TFLOPS = 78.6     # MI355X f64 vector / matrix peak
+LDS_PAIRS_PEAK = 256 * 16 * 2.4e9   # 8-byte LDS reads per second: 256 CUs x 128 B/clk x 2.4 GHz
 BURN_BLOCK = 500
 BURN_MAX = 8000
 
@@ -206,6 +207,12 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
             'kernel_evaluations_per_s': evals / dt, 'exps_per_s_estimate': exps / dt,
             'predicts_per_env_step': (s1[0] - s0[0]) / (n_envs * k),
             'mistakes_per_env_step': (s1[1] - s0[1]) / (n_envs * k),
+            # what bounds the table-factorised scoring per (landmark, candidate) pair is one 8-byte LDS read (128 B/clk/CU) and
+            # three VALU instructions per 64 pairs, not flops: the LDS-side bound is 256 CUs x 16 pairs/clk x 2.4 GHz
+            'scoring_bound': {'bound': 'lds', 'achieved_pairs_per_s': evals / dt, 'peak_pairs_per_s': LDS_PAIRS_PEAK,
+                              'frac': evals / dt / LDS_PAIRS_PEAK,
+                              'note': 'the one-wave kernels are latency-bound (waves wait ~70 % of their cycles, '
+                                      'profiles/kbrl_mfma_share.json), not throughput-bound'},
             'direct_model_tflops': evals * (3 * d + 3) / dt / 1e12,
             'direct_model_frac_of_f64_peak': evals * (3 * d + 3) / dt / 1e12 / F64_PEAK_TFLOPS,
             'dictionary_size_mean': float(np.mean(sizes)), 'dictionary_size_max': int(np.max(sizes)),
