@@ -85,9 +85,11 @@ static GetErrorString_t GetErrorString = nullptr;
 static const int kDouble = 8;  // ncclFloat64 / ncclDouble
 static bool load() {
     if (lib) return true;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // RANSLICE_RCCL_LIB names the library to bind (a process that has already loaded an RCCL of its own -- e.g. through
+    // torch.distributed's nccl backend -- should point this at the same file so that one copy serves both)
+    const char* names[] = {getenv("RANSLICE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names)
-        if ((lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!lib) return false;
     GetUniqueId = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
