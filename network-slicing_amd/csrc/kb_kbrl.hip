@@ -1555,8 +1555,8 @@ __global__ __launch_bounds__(KB_RANK_THREADS) void shared_commit_kernel(KbDev D,
 // Work area per slice: KF [budget][capr] kernel columns, DS [budget][capr] d* = Kinv k_f.
 __device__ __forceinline__ bool batch_applies(const KbDev& D, int m) { return m >= D.cap && m >= 2 && !D.serial_apply; }
 
-#define KB_COLS_BLOCKS 16
-#define KB_MATVEC_BLOCKS 64
+#define KB_COLS_BLOCKS 64
+#define KB_MATVEC_BLOCKS 256
 
 // kernel columns of all proposals of the full dictionaries (kernel_column_full's arithmetic)
 __global__ __launch_bounds__(256) void shared_cols_kernel(KbDev D, KbState K, const double* props, const int32_t* counts,

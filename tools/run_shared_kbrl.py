@@ -24,8 +24,8 @@ def main():
     ap.add_argument('--scenario', type=int, default=2)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--budget', type=int, default=64)
-    ap.add_argument('--rounds', type=int, default=4)
+    ap.add_argument('--budget', type=int, default=256)
+    ap.add_argument('--rounds', type=int, default=1)
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--host-loop', action='store_true', help='drive the loop through host buffers (env.step / update_control)')
     ap.add_argument('--capacity', type=int, default=1024,
