@@ -270,6 +270,8 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_cursor, T, true);
     KA(k->d_cstar, T, true);
     KA(K.workb, D.shared ? (size_t)cfg->n_slices * 2 * k->budget_cap * kb::kb_capr(cfg->capacity) : 1, true);
+    KA(K.workg, D.shared ? (size_t)cfg->n_slices * k->budget_cap * k->budget_cap : 1, true);
+    KA(K.workf, D.shared ? (size_t)cfg->n_slices * k->budget_cap : 1, true);
     KA(k->d_props, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
     KA(k->d_counts, (size_t)cfg->n_slices, true);
     KA(k->d_gstats, 32, true);
@@ -304,8 +306,6 @@ extern "C" void kb_destroy(kb_handle* k) {
             for (int s = 0; s < k->cfg.n_slices; ++s)
                 fprintf(stderr, "shared_apply slice %d: %.3f ms in total, %llu samples applied of %llu proposed\n", s,
                         (double)g[8 + s] / 1e5, (unsigned long long)g[16 + s], (unsigned long long)g[24 + s]);
-        fprintf(stderr, "batched apply phases (ms in total): column + flags %.3f, Gram tiles %.3f, f0 %.3f, ordered walk %.3f, coefficient update %.3f\n",
-                (double)g[3] / 1e5, (double)g[4] / 1e5, (double)g[5] / 1e5, (double)g[6] / 1e5, (double)g[7] / 1e5);
     }
     if (guards_on()) check_guards(k->guarded, "kb");
     for (auto& g : k->guarded) (void)hipFree(g.base);
@@ -374,8 +374,9 @@ static void launch_shared_apply(kb_handle* k, const double* props, const int32_t
     const unsigned S = (unsigned)k->cfg.n_slices;
     hipLaunchKernelGGL(kb::shared_cols_kernel, dim3(S, KB_COLS_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, props, counts, budget);
     hipLaunchKernelGGL(kb::shared_matvec_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
-    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), sizeof(double) * kb::kb_apply_lds_doubles(k->cfg.capacity, k->budget_cap), k->stream, k->D, k->K,
-                       props, counts, budget, k->d_gstats);
+    hipLaunchKernelGGL(kb::shared_gram_kernel, dim3(S, 128), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
+    const size_t lds = sizeof(double) * kb::kb_apply_lds_doubles(k->cfg.capacity, k->budget_cap);
+    hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), lds, k->stream, k->D, k->K, props, counts, budget, k->d_gstats);
 }
 
 static int kb_time_begin(kb_handle* k, hipEvent_t* e1, int kind = 0) {

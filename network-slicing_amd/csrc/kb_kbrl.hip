@@ -115,11 +115,13 @@ struct KbState {
     int32_t* big;      // [2][1 + KB_BIG_MAX]: count, then the learners select_kernel found at KB_BIG_M landmarks or more
     int32_t* isbig;    // [2][T] membership of that list
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
+    double* workg;     // shared mode: [S][budget_cap][budget_cap] the proposals' Gram block (shared_gram_kernel)
+    double* workf;     // shared mode: [S][budget_cap] f_p^0
 };
 
 __host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
 __host__ __device__ inline size_t kb_apply_lds_doubles(int cap, int budget) {  // shared_apply_kernel's dynamic LDS
-    return (size_t)kb_capr(cap) + (size_t)budget + 64 * 65 + 64 + (2 * 64 + 8) + 2 * 64 * 33;
+    return (size_t)kb_capr(cap) + 4 * (size_t)budget;
 }
 __host__ __device__ inline uint64_t kb_shell_doubles(int b) { return (uint64_t)KB_VEC + (uint64_t)(2 * b + 1) * KB_TILE; }
 
@@ -1636,129 +1638,162 @@ __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, 
     }
 }
 
-// The ordered part, by the slice's own workgroup (shared_apply_kernel).  A full dictionary only projects: proposal p is
-// still a mistake iff  f_p = k_p . coeff <= 0  for the coefficients as the EARLIER projections of the list left them,
+// A full dictionary only projects: proposal p is still a mistake iff  f_p = k_p . coeff <= 0  for the coefficients as the
+// EARLIER projections of the list left them,
 //     coeff = coeff_0 + sum_{q < p, applied} y_q d*_q    =>    f_p = k_p . coeff_0 + sum_{q < p, applied} y_q (k_p . d*_q),
-// so the only thing the order touches is a 64 x 64 matrix of scalars: the proposals' Gram block A = KF DS^T
-// (64 x 64 x m, a dense contraction: v_mfma_f64_16x16x4, one 16 x 16 tile per wave), f_p^0 = k_p . coeff_0 (one wave per
-// proposal, in parallel), then ONE wave walks the list -- 64 steps of a 64-lane dot -- and the coefficients take the
-// applied d*_q in list order, element by element exactly as the one-by-one path adds them (same bits).  Lists longer than
-// 64 go in sub-batches.  co: the coefficient column, flag / amat / f0 / wy: scratch in (dynamic) LDS.
-#define KB_SUB 64
-__device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, const double* pr, int np, int budget,
-                                     double* co, double* flag, double* amat, double* f0, double* wy, double* slab, uint64_t* gstats) {
-    unsigned long long tph = wall_clock64();
-#define KB_PH(i) if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd((unsigned long long*)&gstats[i], t_ - tph); tph = t_; }
+// so all the order touches is a matrix of scalars: the proposals' Gram block A = KF DS^T (n_p x n_p x m).
+// shared_gram_kernel forms it as a dense contraction on the matrix cores -- v_mfma_f64_16x16x4, one 16 x 16 tile per wave,
+// the lower block triangle only, as wide as the chip -- together with f_p^0 = k_p . coeff_0 (a wave per proposal);
+// shared_apply_kernel then walks the list with one wave (a dot over the earlier proposals per step, rows of A prefetched)
+// and gives the coefficients the applied d*_q in list order, element by element exactly as the one-by-one path adds them
+// (same bits).
+__global__ __launch_bounds__(256) void shared_gram_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!batch_applies(D, m)) return;
+    const int np = counts[s] < budget ? counts[s] : budget;
     const int capr = kb_capr(D.cap);
-    const uint64_t* sh = shells_of(D, K, s);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int kq = lane >> 4, li = lane & 15;
+    const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15;
     const double* KF = K.workb + (size_t)s * 2 * budget * capr;
     const double* DS = KF + (size_t)budget * capr;
-    for (int j = threadIdx.x; j < m; j += blockDim.x) co[j] = *vec_at(K, sh, KB_ROW_CO, j);
-    // ---- delta = 1 - k_f . d* per proposal (only the "saturated" flag depends on it here)
-    for (int p = wave; p < np; p += nw) {
-        const double dot = wave_dot256(DS + (size_t)p * capr, KF + (size_t)p * capr, m);
-        double delta = 1.0 - dot;
-        delta = delta > 0.0 ? delta : 0.0;
-        if (lane == 0) flag[p] = delta > D.eta ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    KB_PH(3)
-    uint64_t n_mist = 0;
-    bool sat = false;
-    for (int pb = 0; pb < np; pb += KB_SUB) {
-        const int ns = np - pb < KB_SUB ? np - pb : KB_SUB;
-        // ---- A[p][q] = k_p . d*_q: tile (ti, tj) by wave 4 ti + tj.  The operands go through LDS in slabs of 32 landmarks:
-        // all threads fetch the 64 x 32 blocks of KF and DS with coalesced loads (rows past the list read as zero), the
-        // waves take their MFMA operands from there (row stride 33: conflict-free)
-        {
-            kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-            const int ti = (wave & 15) >> 2, tj = wave & 3;
-            for (int k0 = 0; k0 < m; k0 += 32) {
-                __syncthreads();
-                for (int e = threadIdx.x; e < 64 * 32; e += blockDim.x) {
-                    const int r = e >> 5, c = e & 31, k = k0 + c;
-                    const bool in = r < ns && k < m;
-                    slab[r * 33 + c] = in ? KF[(size_t)(pb + r) * capr + k] : 0.0;
-                    slab[64 * 33 + r * 33 + c] = in ? DS[(size_t)(pb + r) * capr + k] : 0.0;
-                }
-                __syncthreads();
-                if (wave < 16) {
+    double* A = K.workg + (size_t)s * budget * budget;
+    double* F0 = K.workf + (size_t)s * budget;
+    const int nt = (np + 15) >> 4, ntile = nt * (nt + 1) / 2;
+    const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    for (int wk = wave; wk < ntile + np; wk += nw) {
+        if (wk >= ntile) {  // f_p^0 (the one-by-one path's own dot)
+            const int p = wk - ntile;
+            const uint64_t* sh = shells_of(D, K, s);
+            double part[4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        const double a = slab[(16 * ti + li) * 33 + 4 * u + kq];
-                        const double b = slab[64 * 33 + (16 * tj + li) * 33 + 4 * u + kq];
-                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-                    }
-                }
+            for (int v = 0; v < 4; ++v) {
+                part[v] = 0.0;
+                for (int j = 64 * v + lane; j < m; j += 256) part[v] += KF[(size_t)p * capr + j] * vec_page(K, sh, j >> 6)[KB_ROW_CO * KB_CH + lane];
             }
-            // the lane holds A[16 ti + kq + 4 r][16 tj + li]
-            if (wave < 16) {
+            for (int dd = 32; dd >= 1; dd >>= 1) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) amat[(16 * ti + kq + 4 * r) * (KB_SUB + 1) + 16 * tj + li] = acc[r];
+                for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
             }
+            double t = 0.0;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) t += __shfl(part[v], 0);
+            if (lane == 0) F0[p] = t;
+            continue;
         }
-        __syncthreads();
-        KB_PH(4)
-        // ---- f_p^0 against the coefficients as the previous sub-batch left them
-        for (int p = wave; p < ns; p += nw) {
-            const double v = wave_dot256(KF + (size_t)(pb + p) * capr, co, m);
-            if (lane == 0) f0[p] = v;
-        }
-        __syncthreads();
-        KB_PH(5)
-        // ---- the list in order: lane q keeps y_q if proposal q was applied
-        if (wave == 0) {
-            const int ylane = lane < ns ? ((((int)pr[(size_t)(pb + lane) * KB_PROP_W + 1]) & 1) ? 1 : -1) : 1;
-            const double f0l = lane < ns ? f0[lane] : 0.0, fl = lane < ns ? flag[pb + lane] : 0.0;
-            double wq = 0.0;
-            for (int p = 0; p < ns; ++p) {
-                double term = lane < p ? wq * amat[p * (KB_SUB + 1) + lane] : 0.0;
-                for (int dd = 32; dd >= 1; dd >>= 1) term += __shfl_xor(term, dd);
-                const int y = __builtin_amdgcn_readlane(ylane, p);
-                const double f = readlane_f64(f0l, p) + term;
-                const bool mistake = f * (double)y <= 0.0;
-                if (lane == p) wq = mistake ? (double)y : 0.0;
-                if (mistake) {
-                    n_mist += 1;
-                    sat = sat || readlane_f64(fl, p) != 0.0;
-                }
-            }
-            // the applied proposals, compacted in list order: (index, y)
-            const unsigned long long am = __ballot(wq != 0.0);
-            if (wq != 0.0) {
-                const int pos = __builtin_popcountll(am & ((1ull << lane) - 1ull));
-                wy[pos] = (double)lane;
-                wy[KB_SUB + pos] = wq;
-            }
-            if (lane == 0) wy[2 * KB_SUB] = (double)__builtin_popcountll(am);
-        }
-        __syncthreads();
-        KB_PH(6)
-        // ---- coeff_j takes the applied d*_q in list order (the one-by-one path's own expression), four loads in flight
-        const int napp = (int)wy[2 * KB_SUB];
-        for (int j = threadIdx.x; j < m; j += blockDim.x) {
-            double c = co[j];
-            for (int a0 = 0; a0 < napp; a0 += 4) {
-                double v[4], yy[4];
+        // tile (ti, tj), tj <= ti, of A[p][q] = k_p . d*_q.  MFMA step u of a 16-landmark slab contracts landmarks
+        // k0 + 4 kq + u (any pairing of k works as long as both operands use it): four consecutive doubles per lane and slab
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= wk) ++ti;
+        const int tj = wk - ti * (ti + 1) / 2;
+        const int pa = 16 * ti + li, qb = 16 * tj + li;
+        const double* ar = KF + (size_t)(pa < np ? pa : 0) * capr;
+        const double* br = DS + (size_t)(qb < np ? qb : 0) * capr;
+        kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+        for (int k0 = 0; k0 < m; k0 += 32) {
+            double a[8], b[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int a = a0 + u < napp ? a0 + u : a0;
-                    v[u] = DS[(size_t)(pb + (int)wy[a]) * capr + j];
-                    yy[u] = wy[KB_SUB + a];
+                    const int k = k0 + 16 * h + 4 * kq + u;
+                    a[4 * h + u] = (pa < np && k < m) ? ar[k] : 0.0;
+                    b[4 * h + u] = (qb < np && k < m) ? br[k] : 0.0;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (a0 + u < napp) c = c + yy[u] * v[u];
-            }
-            co[j] = c;
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
-        __syncthreads();
-        KB_PH(7)
+        // the lane holds A[16 ti + kq + 4 r][16 tj + li]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = 16 * ti + kq + 4 * r, q = 16 * tj + li;
+            if (p < np && q < np) A[(size_t)q * budget + p] = acc[r];  // stored by COLUMN: the walk reads column q when q is applied
+        }
     }
-    if (sat && threadIdx.x == 0) atomicOr(&K.err[0], 8);  // a full dictionary met a sample it would have grown for
-    for (int j = threadIdx.x; j < m; j += blockDim.x) *vec_at(K, sh, KB_ROW_CO, j) = co[j];
+}
+
+// the ordered part, by the slice's own workgroup: co = the coefficient column, wl = scratch (4 x budget doubles), in LDS
+__device__ uint64_t apply_full_batch(const KbDev& D, const KbState& K, int s, int m, const double* pr, int np, int budget,
+                                     double* co, double* wl) {
+    const int capr = kb_capr(D.cap);
+    const uint64_t* sh = shells_of(D, K, s);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double* DS = K.workb + (size_t)s * 2 * budget * capr + (size_t)budget * capr;
+    const double* A = K.workg + (size_t)s * budget * budget;
+    const double* F0 = K.workf + (size_t)s * budget;
+    double* wq = wl;               // [budget] y_q of the applied proposals, 0 for the others
+    double* lst = wl + budget;     // [budget] the applied proposals, compacted in list order
+    double* cnt = wl + 2 * budget; // [1]
+    for (int j = threadIdx.x; j < m; j += blockDim.x) co[j] = *vec_at(K, sh, KB_ROW_CO, j);
+    for (int q = threadIdx.x; q < budget; q += blockDim.x) wq[q] = 0.0;
+    __syncthreads();
+    uint64_t n_mist = 0;
+    if (wave == 0) {
+        bool sat = false;
+        int napp = 0;
+        const int nq = (np + 63) >> 6;  // lanes hold proposals lane, lane + 64, ...
+        // lane l keeps g_p = sum_{applied q < p} y_q A[p][q] for its proposals p = l, l + 64, ...: nothing is summed across
+        // lanes; when proposal q is applied every lane adds its piece of A's column q (prefetched two steps ahead)
+        double g[4] = {0.0, 0.0, 0.0, 0.0}, f0v[4];
+        int yv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int q = lane + 64 * k;
+            yv[k] = q < np ? ((((int)pr[(size_t)q * KB_PROP_W + 1]) & 1) ? 1 : -1) : 1;
+            f0v[k] = q < np ? F0[q] : 0.0;
+        }
+        double nxt[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) nxt[h][k] = (h < np && k < nq && lane + 64 * k < np) ? A[(size_t)h * budget + lane + 64 * k] : 0.0;
+        for (int p = 0; p < np; ++p) {
+            double col[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                col[k] = nxt[p & 1][k];
+                nxt[p & 1][k] = (p + 2 < np && k < nq && lane + 64 * k < np) ? A[(size_t)(p + 2) * budget + lane + 64 * k] : 0.0;
+            }
+            const int pk = p >> 6, pl = p & 63;
+            const int y = __builtin_amdgcn_readlane(pk == 0 ? yv[0] : (pk == 1 ? yv[1] : (pk == 2 ? yv[2] : yv[3])), pl);
+            const double f = readlane_f64(pk == 0 ? f0v[0] + g[0] : (pk == 1 ? f0v[1] + g[1] : (pk == 2 ? f0v[2] + g[2] : f0v[3] + g[3])), pl);
+            if (f * (double)y <= 0.0) {
+                n_mist += 1;
+                // delta = 1 - k_p . d*_p is the Gram block's diagonal: a full dictionary met a sample it would have grown for
+                const double dg = readlane_f64(pk == 0 ? col[0] : (pk == 1 ? col[1] : (pk == 2 ? col[2] : col[3])), pl);
+                const double delta = 1.0 - dg;
+                sat = sat || (delta > 0.0 ? delta : 0.0) > D.eta;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (lane + 64 * k > p) g[k] = __builtin_fma((double)y, col[k], g[k]);
+                if (lane == 0) {
+                    wq[p] = (double)y;
+                    lst[napp] = (double)p;
+                }
+                napp += 1;
+            }
+        }
+        if (lane == 0) cnt[0] = (double)napp;
+        if (sat && lane == 0) atomicOr(&K.err[0], 8);
+    }
+    __syncthreads();
+    // ---- coeff_j takes the applied d*_q in list order (the one-by-one path's own expression), four loads in flight
+    const int napp = (int)cnt[0];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+        double c = co[j];
+        for (int a0 = 0; a0 < napp; a0 += 4) {
+            double v[4], yy[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = (int)lst[a0 + u < napp ? a0 + u : a0];
+                v[u] = DS[(size_t)q * capr + j];
+                yy[u] = wq[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (a0 + u < napp) c = c + yy[u] * v[u];
+        }
+        *vec_at(K, sh, KB_ROW_CO, j) = c;
+    }
     return n_mist;
 }
 
@@ -1776,12 +1811,8 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     const unsigned long long t_in = wall_clock64();  // (developer aid: per-slice time and applied samples, gstats[8..])
     if (np > 0 && batch_applies(D, m)) {
         // kernel columns and d* of the whole list are in the work area (shared_cols_kernel, shared_matvec_kernel)
-        double* p_co = kb_dyn_lds;
-        double* p_flag = p_co + kb_capr(D.cap);
-        double* p_amat = p_flag + budget;
-        double* p_f0 = p_amat + KB_SUB * (KB_SUB + 1);
-        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, p_co, p_flag, p_amat, p_f0,
-                                  p_f0 + KB_SUB, p_f0 + KB_SUB + (2 * KB_SUB + 8), gstats);
+        n_mist = apply_full_batch(D, K, s, m, props + (size_t)s * budget * KB_PROP_W, np, budget, kb_dyn_lds,
+                                  kb_dyn_lds + kb_capr(D.cap));
         if (threadIdx.x == 0) {
             atomicAdd((unsigned long long*)&gstats[1], (unsigned long long)n_mist);
             atomicAdd((unsigned long long*)&gstats[8 + s], wall_clock64() - t_in);
