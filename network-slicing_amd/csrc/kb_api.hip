@@ -270,6 +270,10 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_cursor, T, true);
     KA(k->d_cstar, T, true);
     KA(K.workb, D.shared ? (size_t)cfg->n_slices * 2 * k->budget_cap * kb::kb_capr(cfg->capacity) : 1, true);
+    KA(K.offgrid, ND, true);
+    KA(K.workq, D.shared ? (size_t)cfg->n_slices * 16 * kb::kb_capr(cfg->capacity) * 16 : 1, true);
+    KA(K.workF, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N * 256 : 1, true);
+    KA(K.workE, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N : 1, true);
     KA(K.workg, D.shared ? (size_t)cfg->n_slices * k->budget_cap * k->budget_cap : 1, true);
     KA(K.workf, D.shared ? (size_t)cfg->n_slices * k->budget_cap : 1, true);
     KA(k->d_props, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
@@ -343,6 +347,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.m, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.shell, 0, sizeof(uint64_t) * (size_t)k->n_dict * k->D.max_shells, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.head, 0xFF, sizeof(int32_t) * (size_t)k->n_dict * KB_HEAD, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.offgrid, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -377,6 +382,14 @@ static void launch_shared_apply(kb_handle* k, const double* props, const int32_t
     hipLaunchKernelGGL(kb::shared_gram_kernel, dim3(S, 128), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
     const size_t lds = sizeof(double) * kb::kb_apply_lds_doubles(k->cfg.capacity, k->budget_cap);
     hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), lds, k->stream, k->D, k->K, props, counts, budget, k->d_gstats);
+}
+
+// the scores of the large shared dictionaries for all replicas at once (F = E Q on MFMA); shared_scan_kernel picks them up
+static void launch_shared_gemm(kb_handle* k, const float* d_state) {
+    const unsigned S = (unsigned)k->cfg.n_slices, rts = (unsigned)((k->cfg.n_envs + 15) / 16);
+    const unsigned chunks = (unsigned)((k->cfg.n_prbs / 16 + 1 + 7) / 8);
+    hipLaunchKernelGGL(kb::shared_q_kernel, dim3(S, 64), dim3(256), 0, k->stream, k->D, k->K);
+    hipLaunchKernelGGL(kb::shared_fgemm_kernel, dim3(S, rts, chunks * (KB_GEMM_KS / 4)), dim3(256), 0, k->stream, k->D, k->K, d_state);
 }
 
 static int kb_time_begin(kb_handle* k, hipEvent_t* e1, int kind = 0) {
@@ -805,6 +818,7 @@ extern "C" int kb_shared_scan(kb_handle* k, const float* state, const int32_t* a
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
+    launch_shared_gemm(k, a.state);
     hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::shared_collect_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, k->d_state, k->d_labels,
@@ -873,6 +887,7 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         hipEvent_t e1;
         int rc = kb_time_begin(k, &e1);
         if (rc != RS_OK) return rc;
+        launch_shared_gemm(k, a.state);
         hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
         if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
         hipLaunchKernelGGL(kb::shared_collect_block_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, d_state,

@@ -58,6 +58,8 @@ namespace kb {
 #define KB_HEAVY_THREADS 512
 #define KB_BIG_M 320       // dictionaries from this size on are launched first by the one-wave kernels
 #define KB_BIG_MAX 4096    // at most this many (the rest keep their place)
+#define KB_GEMM_M 256      // shared dictionaries from this size on are scored for all replicas at once as F = E Q on MFMA
+#define KB_GEMM_KS 8       // the landmarks are split in this many parts (one wave each per 16 replicas)
 #define KB_E_TINY 1e-280   // below this E_j G[.] would leave the normal range: direct evaluation (score_pass)
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 
@@ -115,6 +117,10 @@ struct KbState {
     int32_t* big;      // [2][1 + KB_BIG_MAX]: count, then the learners select_kernel found at KB_BIG_M landmarks or more
     int32_t* isbig;    // [2][T] membership of that list
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
+    int32_t* offgrid;  // [ND] landmarks whose last coordinate is off the candidate grid (inserted through kb_update)
+    double* workq;     // shared mode: [S][16][capr][16] Q[j][c] = coeff_j G[|a_j - c|] in MFMA B-operand tiles (shared_q_kernel)
+    double* workF;     // shared mode: [S][KB_GEMM_KS][n_envs][256] partial scores F = E Q (shared_fgemm_kernel)
+    double* workE;     // shared mode: [S][KB_GEMM_KS][n_envs] largest E_j a replica met in its part of the landmarks
     double* workg;     // shared mode: [S][budget_cap][budget_cap] the proposals' Gram block (shared_gram_kernel)
     double* workf;     // shared mode: [S][budget_cap] f_p^0
 };
@@ -654,6 +660,7 @@ __device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err
             P[KB_ROW_DS * KB_CH + l] = -1.0;
             int32_t* ix = (int32_t*)(P + KB_ROW_IDX * KB_CH);
             ix[l] = a_last;
+            if (a_last < 0) K.offgrid[dict] += 1;
             if (a_last >= 0) {  // chain of the landmarks with this grid index, newest first
                 int32_t* hd = K.head + (size_t)dict * KB_HEAD;
                 ix[64 + l] = hd[a_last];
@@ -1375,6 +1382,117 @@ struct ScanArgs {
     int32_t round;
 };
 
+// ---- a large shared dictionary scores ALL replicas of the rank at once.  With E[r][j] = exp(-gamma |l_j[:d-1] - state_r|^2)
+// (the RBF Gram block of replicas x landmarks) and Q[j][c] = coeff_j G[|a_j - c|] (landmarks x candidates),
+//     F[r][c] = sum_j E[r][j] Q[j][c]
+// is a dense contraction: v_mfma_f64_16x16x4, a wave per (16 replicas, part of the landmarks, 8 candidate tiles); the A
+// operand E is produced in place (each lane the distance and the exp of its own (replica, landmark) pair), B comes from
+// the tiles shared_q_kernel lays out.  shared_scan_kernel then only adds the KB_GEMM_KS partial sums of its window.  A
+// replica whose E_j are ALL below 1e-250 (an outlier state, see score_pass) keeps the streaming pass and its direct
+// exponentials; so does a dictionary with off-grid landmarks.
+__device__ __forceinline__ bool gemm_applies(const KbDev& D, const KbState& K, int s, int m) {
+    return D.shared && m >= KB_GEMM_M && K.offgrid[s] == 0;
+}
+
+__global__ __launch_bounds__(256) void shared_q_kernel(KbDev D, KbState K) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!gemm_applies(D, K, s, m)) return;
+    __shared__ double G[KB_GTAB];
+    for (int k = threadIdx.x; k < KB_GTAB; k += blockDim.x) G[k] = K.gtab[k];
+    __syncthreads();
+    const int capr = kb_capr(D.cap), mp = (m + 3) & ~3;
+    const uint64_t* sh = shells_of(D, K, s);
+    double* Q = K.workq + (size_t)s * 16 * capr * 16;
+    const int nt = D.n_prbs / 16 + 1;  // tiles that cover candidates 0..n_prbs
+    for (int e = blockIdx.y * blockDim.x + threadIdx.x; e < nt * mp * 16; e += gridDim.y * blockDim.x) {
+        const int nn = e & 15, j = (e >> 4) % mp, ct = (e >> 4) / mp;
+        double v = 0.0;
+        if (j < m) {
+            const double* P = vec_page(K, sh, j >> 6);
+            const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[j & 63];
+            int o = a - (16 * ct + nn);
+            o = o < 0 ? -o : o;
+            v = P[KB_ROW_CO * KB_CH + (j & 63)] * G[o < 255 ? o : 255];
+        }
+        Q[((size_t)ct * capr + j) * 16 + nn] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void shared_fgemm_kernel(KbDev D, KbState K, const float* state) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!gemm_applies(D, K, s, m)) return;
+    const int rt = blockIdx.y, ch = blockIdx.z / (KB_GEMM_KS / 4), kp = (blockIdx.z % (KB_GEMM_KS / 4)) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, kq = lane >> 4, li = lane & 15;
+    const int d = D.dims[s] + 1, N = D.n_envs, capr = kb_capr(D.cap);
+    const int nt = D.n_prbs / 16 + 1, ct0 = 8 * ch;
+    const int ntc = nt - ct0 < 8 ? nt - ct0 : 8;
+    if (ntc <= 0) return;
+    const uint64_t* sh = shells_of(D, K, s);
+    const double* Q = K.workq + (size_t)s * 16 * capr * 16;
+    const int r = 16 * rt + li;
+    double sx[KB_DMAX - 1];
+#pragma unroll
+    for (int q = 0; q < KB_DMAX - 1; ++q) sx[q] = (q < d - 1 && r < N) ? (double)state[(size_t)r * D.nv + D.off[s] + q] : 0.0;
+    kb_f64x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = (kb_f64x4){0.0, 0.0, 0.0, 0.0};
+    double emax = 0.0;
+    const int nk = (m + 3) >> 2, per = (nk + KB_GEMM_KS - 1) / KB_GEMM_KS;
+    const int k_lo = kp * per, k_hi = (kp + 1) * per < nk ? (kp + 1) * per : nk;
+    // two slabs of four landmarks per trip: all their loads (coordinates, Q tiles) are issued before the first use
+    for (int ks = k_lo; ks < k_hi; ks += 2) {
+        double E2[2], b2[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int j = 4 * (ks + h) + kq;
+            const bool valid = ks + h < k_hi && j < m;
+            const double* P = vec_page(K, sh, (valid ? j : 0) >> 6);
+            const int l = (valid ? j : 0) & 63;
+            double cv[KB_DMAX - 1];
+#pragma unroll
+            for (int q = 0; q < KB_DMAX - 1; ++q) cv[q] = q < d - 1 ? P[q * KB_CH + l] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) b2[h][t] = (t < ntc && valid) ? Q[((size_t)(ct0 + t) * capr + j) * 16 + li] : 0.0;
+            double d0 = 0.0;
+#pragma unroll
+            for (int q = 0; q < KB_DMAX - 1; ++q) {
+                if (q < d - 1) {
+                    const double u = cv[q] - sx[q];
+                    d0 += u * u;
+                }
+            }
+            E2[h] = valid ? rs_exp_nonpos(-D.gamma * d0) : 0.0;
+            emax = E2[h] > emax ? E2[h] : emax;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t < ntc) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(E2[h], b2[h][t], acc[t], 0, 0, 0);
+    }
+    // the lane holds F[replica 16 rt + kq + 4 v][candidate 16 (ct0 + t) + li]
+    double* F = K.workF + ((size_t)s * KB_GEMM_KS + kp) * N * 256;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        if (t < ntc) {
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int rr = 16 * rt + kq + 4 * v;
+                if (rr < N) F[(size_t)rr * 256 + 16 * (ct0 + t) + li] = acc[t][v];
+            }
+        }
+    }
+    if (ch == 0) {  // the largest E of replica r over this part of the landmarks (lanes li, li + 16, li + 32, li + 48)
+        double e2 = __shfl_xor(emax, 16);
+        emax = e2 > emax ? e2 : emax;
+        e2 = __shfl_xor(emax, 32);
+        emax = e2 > emax ? e2 : emax;
+        if (lane < 16 && r < N) K.workE[((size_t)s * KB_GEMM_KS + kp) * N + r] = emax;
+    }
+}
+
 __global__ __launch_bounds__(64) void shared_scan_kernel(ScanArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
@@ -1401,7 +1519,28 @@ __global__ __launch_bounds__(64) void shared_scan_kernel(ScanArgs A) {
     __syncthreads();
     const Win w = window_of(y == 1 ? a_i : 0, c_to);
     double f[4];
-    score<4, 2>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    bool from_gemm = gemm_applies(D, K, dict, m);
+    if (from_gemm) {
+        const double* E = K.workE + (size_t)s * KB_GEMM_KS * D.n_envs + env;
+        double emax = 0.0;
+        for (int kp = 0; kp < KB_GEMM_KS; ++kp) emax = E[(size_t)kp * D.n_envs] > emax ? E[(size_t)kp * D.n_envs] : emax;
+        from_gemm = emax >= 1e-250;
+    }
+    if (from_gemm) {
+        const double* F = K.workF + (size_t)s * KB_GEMM_KS * D.n_envs * 256 + (size_t)env * 256;
+        const size_t part = (size_t)D.n_envs * 256;
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int c = w.base + 64 * g + lane;
+            c = c < n ? c : n;
+            f[g] = g < w.ng ? ((F[c] + F[part + c]) + (F[2 * part + c] + F[3 * part + c])) +
+                                  ((F[4 * part + c] + F[5 * part + c]) + (F[6 * part + c] + F[7 * part + c]))
+                            : 0.0;
+        }
+    } else {
+        score<4, 2>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    }
     if (A.round == 0) {
         // y_pred, accuracy table, security factor: kbrl_control.py:88-101 (as update_control_kernel)
         n_pred += 1;
