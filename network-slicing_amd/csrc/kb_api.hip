@@ -456,9 +456,11 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     a.K = k->K;
     a.state = d_state;
     a.big_par = k->D.shared ? -1 : k->big_par;
+    a.gemm = k->D.shared ? 1 : 0;
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1, 1);
     if (rc != RS_OK) return rc;
+    if (a.gemm) launch_shared_gemm(k, d_state);
     hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0)), dim3(64), 0, k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,

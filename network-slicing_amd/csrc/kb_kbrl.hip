@@ -80,6 +80,8 @@ struct KbDev {
 
 // dictionary a learner (task = env * S + s) reads and writes
 __device__ __forceinline__ int dict_of(const KbDev& D, int task) { return D.shared ? task % D.S : task; }
+struct KbState;
+__device__ __forceinline__ bool gemm_applies(const KbDev& D, const KbState& K, int s, int m);
 
 struct KbState {
     int32_t* m;        // [ND] landmarks per dictionary
@@ -125,6 +127,10 @@ struct KbState {
     double* workf;     // shared mode: [S][budget_cap] f_p^0
 };
 
+// a shared dictionary large enough (and on the candidate grid) to be scored for all replicas at once (shared_fgemm_kernel)
+__device__ __forceinline__ bool gemm_applies(const KbDev& D, const KbState& K, int s, int m) {
+    return D.shared && m >= KB_GEMM_M && K.offgrid[s] == 0;
+}
 __host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
 __host__ __device__ inline size_t kb_apply_lds_doubles(int cap, int budget) {  // shared_apply_kernel's dynamic LDS
     return (size_t)kb_capr(cap) + 4 * (size_t)budget;
@@ -1198,22 +1204,30 @@ struct SelArgs {
     KbState K;
     const float* state;  // [n_envs][nv] new state
     int32_t big_par;     // the list that orders this launch; the other one is written for the next step (-1: none)
+    int32_t gemm;        // shared mode: shared_fgemm_kernel has scored this state for the large dictionaries
 };
 
 // per-learner part of KBRL_Control.select_action (kbrl_control.py:44-63): the smallest candidate the classifier
 // accepts.  The reference scans c = 0, 1, 2, ... and stops at the first +1 (about 15 candidates in); so does this:
 // 64 candidates per pass of the landmarks, in order, until a pass contains the answer.
+// MODE 3: the scores come from shared_fgemm_kernel's partial sums (Fp: this replica's row, `part` doubles between parts)
 template <int MODE>
 __device__ __forceinline__ int select_scan(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, int task, int env,
-                                           int s, const Lds& sm, uint64_t* n_scored) {
+                                           int s, const Lds& sm, uint64_t* n_scored, const double* Fp = nullptr, size_t part = 0) {
     const int n = D.n_prbs, lane = threadIdx.x & 63;
     int found = -1;
     for (int g = 0; 64 * g <= n && found < 0; ++g) {
         double f[1];
-        if (g == 0)
-            score<1, MODE>(D, K, sh, m, d, sm, 64 * g, 1, f);
-        else
-            score<1, MODE == 0 ? 1 : MODE>(D, K, sh, m, d, sm, 64 * g, 1, f);
+        if (MODE == 3) {
+            int cc = 64 * g + lane;
+            cc = cc < n ? cc : n;
+            f[0] = ((Fp[cc] + Fp[part + cc]) + (Fp[2 * part + cc] + Fp[3 * part + cc])) +
+                   ((Fp[4 * part + cc] + Fp[5 * part + cc]) + (Fp[6 * part + cc] + Fp[7 * part + cc]));
+        } else if (g == 0) {
+            score<1, MODE == 3 ? 2 : MODE>(D, K, sh, m, d, sm, 64 * g, 1, f);
+        } else {
+            score<1, MODE == 0 ? 1 : (MODE == 3 ? 2 : MODE)>(D, K, sh, m, d, sm, 64 * g, 1, f);
+        }
         const int c = 64 * g + lane;
         const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
         *n_scored += (uint64_t)(c1 - 64 * g + 1);
@@ -1264,10 +1278,22 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
     int found = -1;
     uint64_t n_scored = 0;
     if (m > 0) {
-        if (D.shared)
-            found = select_scan<2>(D, K, sh, m, d, task, env, s, sm, &n_scored);
-        else
+        if (D.shared) {
+            bool from_gemm = A.gemm && gemm_applies(D, K, dict, m);
+            if (from_gemm) {
+                const double* E = K.workE + (size_t)s * KB_GEMM_KS * D.n_envs + env;
+                double emax = 0.0;
+                for (int kp = 0; kp < KB_GEMM_KS; ++kp) emax = E[(size_t)kp * D.n_envs] > emax ? E[(size_t)kp * D.n_envs] : emax;
+                from_gemm = emax >= 1e-250;
+            }
+            if (from_gemm)
+                found = select_scan<3>(D, K, sh, m, d, task, env, s, sm, &n_scored,
+                                       K.workF + (size_t)s * KB_GEMM_KS * D.n_envs * 256 + (size_t)env * 256, (size_t)D.n_envs * 256);
+            else
+                found = select_scan<2>(D, K, sh, m, d, task, env, s, sm, &n_scored);
+        } else {
             found = select_scan<0>(D, K, sh, m, d, task, env, s, sm, &n_scored);
+        }
     }
     if (threadIdx.x == 0) {
         const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
@@ -1390,9 +1416,6 @@ struct ScanArgs {
 // the tiles shared_q_kernel lays out.  shared_scan_kernel then only adds the KB_GEMM_KS partial sums of its window.  A
 // replica whose E_j are ALL below 1e-250 (an outlier state, see score_pass) keeps the streaming pass and its direct
 // exponentials; so does a dictionary with off-grid landmarks.
-__device__ __forceinline__ bool gemm_applies(const KbDev& D, const KbState& K, int s, int m) {
-    return D.shared && m >= KB_GEMM_M && K.offgrid[s] == 0;
-}
 
 __global__ __launch_bounds__(256) void shared_q_kernel(KbDev D, KbState K) {
     const int s = blockIdx.x;
