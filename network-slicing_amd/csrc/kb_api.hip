@@ -40,6 +40,7 @@ struct kb_handle {
     int budget_cap = 256;
     int heavy_blocks = 256;
     int heavy_rounds = 3;
+    bool gemm_fresh = false;       // shared, resident loop: workF / workE hold the scores of d_prev_state against the dictionaries as they are
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
     bool rounds_always = false;
@@ -352,6 +353,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (k->h_seen) *k->h_seen = 0;
+    k->gemm_fresh = false;
     k->big_par = 0;
     HIPCHK(k, hipMemset(k->K.big, 0, sizeof(int32_t) * 2 * (1 + KB_BIG_MAX)));
     HIPCHK(k, hipMemset(k->K.isbig, 0, sizeof(int32_t) * 2 * T));
@@ -457,6 +459,7 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     a.state = d_state;
     a.big_par = k->D.shared ? -1 : k->big_par;
     a.gemm = k->D.shared ? 1 : 0;
+    k->gemm_fresh = false;  // (kb_shared_step_resident sets it again once the state has become d_prev_state)
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1, 1);
     if (rc != RS_OK) return rc;
@@ -564,6 +567,7 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
 
 static int kb_one(kb_handle* k, int e, int s, const double* x, int y, bool update, double out[4]) {
     if (!k || !x || e < 0 || e >= k->cfg.n_envs || s < 0 || s >= k->cfg.n_slices) return RS_EINVAL;
+    k->gemm_fresh = false;
     if (!k->is_reset) {
         k->err = "kb_predict/kb_update: call kb_reset first";
         return RS_ESTATE;
@@ -820,6 +824,7 @@ extern "C" int kb_shared_scan(kb_handle* k, const float* state, const int32_t* a
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
+    k->gemm_fresh = false;
     launch_shared_gemm(k, a.state);
     hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
@@ -844,6 +849,7 @@ extern "C" int kb_shared_apply(kb_handle* k, const int32_t* counts, const double
     const size_t S = (size_t)k->cfg.n_slices;
     HIPCHK(k, hipMemcpyAsync(k->d_counts, counts, sizeof(int32_t) * S, hipMemcpyHostToDevice, k->stream));
     HIPCHK(k, hipMemcpyAsync(k->d_props, props, sizeof(double) * S * budget * KB_PROP_W, hipMemcpyHostToDevice, k->stream));
+    k->gemm_fresh = false;
     launch_shared_apply(k, k->d_props, k->d_counts, (int)budget);
     HIPCHK(k, hipGetLastError());
     return kb_check(k);
@@ -889,7 +895,9 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         hipEvent_t e1;
         int rc = kb_time_begin(k, &e1);
         if (rc != RS_OK) return rc;
-        launch_shared_gemm(k, a.state);
+        // (resident loop, round 0: select_action of the previous step scored this very state against these very dictionaries)
+        if (!(rnd == 0 && k->gemm_fresh && d_state == k->d_prev_state)) launch_shared_gemm(k, a.state);
+        k->gemm_fresh = false;
         hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
         if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
         hipLaunchKernelGGL(kb::shared_collect_block_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, d_state,
@@ -984,6 +992,7 @@ extern "C" int kb_shared_step_resident(kb_handle* k, rs_handle* env, int32_t bud
     HIPCHK(k, hipEventRecord(done, k->stream));
     HIPCHK(k, hipStreamWaitEvent(env->stream, done, 0));
     HIPCHK(k, hipGetLastError());
+    k->gemm_fresh = true;  // workF / workE now describe d_prev_state; nothing learns before the next step's first scan
     return RS_OK;
 }
 
