@@ -267,7 +267,8 @@ int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, cons
                    int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
 /* kb_step_resident for a shared-dictionary agent: the learning step above on the simulator's own device buffers (previous
  * observation, the action `env` just executed, its labels), then select_action of the new observation into the
- * simulator's action buffer.  Only the per-round "anything left" flag crosses PCIe. */
+ * simulator's action buffer.  Only the per-round "anything left" flag crosses PCIe; with rounds_out == NULL the host
+ * does not wait for the last permitted round's flag either (the whole step is enqueued and the call returns). */
 int kb_shared_step_resident(kb_handle* k, rs_handle* env, int32_t budget, int32_t max_rounds, int32_t* rounds_out);
 /* The merge of kb_shared_step on a caller-supplied gathered buffer (what ncclAllGather delivers): `world` blocks of
  * [S proposer counts][S][budget][KB_PROP_WIDTH] doubles -> merged proposals [S][budget][KB_PROP_WIDTH], their counts [S],

@@ -872,7 +872,8 @@ extern "C" int kb_shared_commit(kb_handle* k, const int32_t* n_accept) {
 //   round r:  scan -> collect into this rank's block -> ncclAllGather of the blocks (RCCL, agent stream) ->
 //             merge by global replica id (first `budget` per slice) -> apply -> commit
 // until no rank proposes anything or max_rounds is reached.  Only one 4-byte flag per round returns to the host
-// (whether any rank still had proposals).  Without kb_comm_init the handle is its own world.
+// (whether any rank still had proposals; not even that after the last permitted round when rounds_out is NULL).
+// Without kb_comm_init the handle is its own world.
 // the rounds of one shared learning step on device buffers (state / action / labels of the local replicas)
 static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d_action, const int32_t* d_labels, int32_t budget,
                             int32_t max_rounds, int32_t* hits_host, int32_t* rounds_out) {
@@ -919,6 +920,8 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         hipLaunchKernelGGL(kb::shared_commit_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, k->d_cstar, k->d_taken,
                            k->d_cursor);
         HIPCHK(k, hipGetLastError());
+        // the last permitted round decides nothing: without a caller asking for the count the host does not wait for it
+        if (rnd + 1 == max_rounds && !rounds_out) break;
         int32_t total = 0;
         HIPCHK(k, hipMemcpyAsync(&total, k->d_total, sizeof total, hipMemcpyDeviceToHost, k->stream));
         HIPCHK(k, hipStreamSynchronize(k->stream));

@@ -69,6 +69,9 @@ struct rs_handle {
     rs_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;      // the mMTC slices' kernel of a step runs here, beside the eMBB kernels (they share nothing but
+                                     // the step's inputs; finalize_kernel waits for both).  RANSLICE_MTC_STREAM=0: one stream
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     RsDev hdev;            // host copy of the device constants
     RsDev* ddev = nullptr;
     RsState st;
@@ -198,7 +201,7 @@ static int mtc_reset(rs_handle* h, rs::MtcState* m) {
     return RS_OK;
 }
 
-static int mtc_step(rs_handle* h, rs::MtcState* m) {
+static int mtc_step(rs_handle* h, rs::MtcState* m, hipStream_t stream) {
     if (m->n_tasks == 0) return RS_OK;
     rs::MtcArgs a;
     a.D = h->ddev;
@@ -211,7 +214,7 @@ static int mtc_step(rs_handle* h, rs::MtcState* m) {
     a.info = h->d_info;
     a.err = h->st.err;
     size_t lds = (size_t)4 * 2 * m->cap * sizeof(int32_t);
-    hipLaunchKernelGGL(rs::mtc_step_kernel, dim3((unsigned)((m->n_tasks + 3) / 4)), dim3(256), lds, h->stream, a);
+    hipLaunchKernelGGL(rs::mtc_step_kernel, dim3((unsigned)((m->n_tasks + 3) / 4)), dim3(256), lds, stream, a);
     return RS_OK;
 }
 
@@ -375,6 +378,14 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     }
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    {
+        const char* e = getenv("RANSLICE_MTC_STREAM");
+        if (!(e && atoi(e) == 0)) {
+            HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+        }
+    }
     h->mux = cfg->l1_multiplex != 0;
     h->n_ran = cfg->n_embb + cfg->n_mmtc;
     h->n_slices = h->mux ? (cfg->n_embb > 0) + (cfg->n_mmtc > 0) : h->n_ran;
@@ -554,6 +565,9 @@ extern "C" void rs_destroy(rs_handle* h) {
         (void)hipEventDestroy(e.first);
         (void)hipEventDestroy(e.second);
     }
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -746,6 +760,15 @@ static int launch_step(rs_handle* h) {
         h->steps += 1;
         return RS_OK;
     }
+    // the mMTC slices step beside the eMBB ones on the side stream (fork here, join before finalize_kernel; inside a
+    // stream capture the pair becomes two branches of the graph)
+    const bool forked = h->side && h->cfg.n_mmtc > 0 && h->n_tasks > 0 && h->mst.n_tasks > 0;
+    if (forked) {
+        HIPCHK(h, hipEventRecord(h->ev_fork, h->stream));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        mtc_step(h, &h->mst, h->side);
+        HIPCHK(h, hipEventRecord(h->ev_join, h->side));
+    }
     if (h->n_tasks > 0) {
         StepArgs a;
         a.D = h->ddev;
@@ -818,7 +841,8 @@ static int launch_step(rs_handle* h) {
             launch(32);
         }
     }
-    if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst);
+    if (forked) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join, 0));
+    else if (h->cfg.n_mmtc > 0) mtc_step(h, &h->mst, h->stream);
     hipLaunchKernelGGL(finalize_kernel, dim3((h->cfg.n_envs + 255) / 256), dim3(256), 0, h->stream, h->ddev,
                        h->d_actions, h->d_viol, h->d_reward, h->d_run);
     HIPCHK(h, hipGetLastError());

@@ -244,4 +244,4 @@ __global__ __launch_bounds__(256) void mtc_step_kernel(MtcArgs A) {
 // host helpers used by rs_api.hip (defined there after rs_handle is complete)
 static int mtc_alloc(rs_handle* h, rs::MtcState* m, size_t n_tasks, const RsDev& d);
 static int mtc_reset(rs_handle* h, rs::MtcState* m);
-static int mtc_step(rs_handle* h, rs::MtcState* m);
+static int mtc_step(rs_handle* h, rs::MtcState* m, hipStream_t stream);

@@ -255,12 +255,17 @@ class SharedVecKBRL(VecKBRL):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(self.L.kb_comm_init(self.h, buf, int(rank), int(world)))
 
-    def step_resident(self, env):
+    def step_resident(self, env, count_rounds=False):
         """one closed-loop agent step on the device: the shared learning step on the simulator's buffers, then
-        select_action into them (kb_shared_step_resident)"""
-        rounds = C.c_int32()
-        self._check(self.L.kb_shared_step_resident(self.h, env.h, self.budget, self.max_rounds, C.byref(rounds)))
-        self.rounds_last = rounds.value
+        select_action into them (kb_shared_step_resident).  count_rounds: wait for the number of exchange rounds
+        that had proposals (rounds_last); without it the host does not wait for the last permitted round at all"""
+        if count_rounds:
+            rounds = C.c_int32()
+            self._check(self.L.kb_shared_step_resident(self.h, env.h, self.budget, self.max_rounds, C.byref(rounds)))
+            self.rounds_last = rounds.value
+        else:
+            self._check(self.L.kb_shared_step_resident(self.h, env.h, self.budget, self.max_rounds, None))
+            self.rounds_last = None
 
     def update_control(self, state, action, labels):
         state = np.ascontiguousarray(state, dtype=np.float32).reshape(self.n_envs, self.nv)

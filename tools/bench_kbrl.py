@@ -28,6 +28,8 @@ def main():
     ap.add_argument('--capacity', type=int, default=4096)
     ap.add_argument('--pool-gb', type=float, default=64.0)
     ap.add_argument('--profile', default='sos', help='synthetic trace profile: sos | tdl')
+    ap.add_argument('--random', action='store_true',
+                    help="no agent: the on-device random script drives the same environment (the step kernel's workload beside the agent's)")
     args = ap.parse_args()
     N = args.envs
     cfg = make_config(0, n_envs=N)
@@ -42,13 +44,20 @@ def main():
     import ctypes as C
     env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
 
+    step_no = [0]
+
     def run(k):
         for _ in range(k):
-            agent.step_resident(env)
+            if args.random:
+                env.random_actions(7, step_no[0])
+                step_no[0] += 1
+            else:
+                agent.step_resident(env)
             env.step_resident()
     run(args.warmup)
     env.synchronize(); agent.synchronize()
     s0 = agent.stats()
+    c0 = env.counters()
     agent.set_kernel_timing(True)
     env.set_kernel_timing(True)
     t0 = time.perf_counter()
@@ -56,6 +65,8 @@ def main():
     env.synchronize(); agent.synchronize()
     dt = time.perf_counter() - t0
     s1 = agent.stats()
+    c1 = env.counters()
+    per = lambda i: float(c1[i] - c0[i]) / (N * args.steps)
     kb_ms, kb_n = agent.kernel_time_ms()
     env_ms, _ = env.kernel_time_ms()
     out = env.fetch()
@@ -71,6 +82,9 @@ def main():
         'dictionary_size_mean': float(sizes.mean()), 'dictionary_size_max': int(sizes.max()),
         'dictionary_size_p50_p90_p99': [float(np.percentile(sizes, q)) for q in (50, 90, 99)], 'pool': pool,
         'mean_action_sum': float(out['actions'].sum(axis=1).mean()),
+        'action_per_slice_p10_p50_p90_max': [float(np.percentile(out['actions'], q)) for q in (10, 50, 90, 100)],
+        'step_workload_per_env_step': {'fading_samples': per(0), 'pf_iterations': per(2), 'ue_slots': per(3)},
+        'driver': 'random script' if args.random else 'KBRL agents',
         'violations_per_env_step_last': float(out['violations'].sum(axis=1).mean()),
     }))
 

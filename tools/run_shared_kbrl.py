@@ -26,6 +26,8 @@ def main():
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--budget', type=int, default=256)
     ap.add_argument('--rounds', type=int, default=1)
+    ap.add_argument('--count-rounds', action='store_true',
+                    help='resident loop: wait for the per-step count of exchange rounds (one host round trip more)')
     ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--host-loop', action='store_true', help='drive the loop through host buffers (env.step / update_control)')
     ap.add_argument('--capacity', type=int, default=1024,
@@ -90,8 +92,8 @@ def main():
         def run(k):
             nonlocal rounds
             for _ in range(k):
-                agent.step_resident(env)
-                rounds += agent.rounds_last
+                agent.step_resident(env, count_rounds=args.count_rounds)
+                rounds += agent.rounds_last or 0
                 env.step_resident()
     run(args.warmup)
     rounds, viol = 0, 0.0
@@ -118,7 +120,7 @@ def main():
     if rank == 0:
         print(json.dumps({'config': 'scenario_%d, %d envs x %d GPUs, shared KBRL dictionary per slice, RCCL all_gather merge'
                                     % (args.scenario, N, world), 'env_steps_per_s': world * N * args.steps / dt,
-                          'ms_per_step': 1e3 * dt / args.steps, 'exchange_rounds_per_step': rounds / args.steps,
+                          'ms_per_step': 1e3 * dt / args.steps, 'exchange_rounds_per_step': (rounds / args.steps) if (args.host_loop or args.count_rounds) else None,
                           'loop': 'host buffers' if args.host_loop else 'device-resident (kb_shared_step_resident)',
                           'capacity': args.capacity, 'scan_kernel_ms': ph['update_ms'], 'select_kernel_ms': ph['select_ms'],
                           'dictionary_sizes': sizes, 'violations_per_env_step%s' % ('' if args.host_loop else '_last'): viol / args.steps,
