@@ -958,7 +958,10 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& 
     flush_stats(K, task, dict, m, st);
 }
 
-__global__ __launch_bounds__(256) void update_small_kernel(CtlArgs A) {
+#ifndef KB_SMALL_OCC
+#define KB_SMALL_OCC 2  // waves per SIMD update_small_kernel is built for
+#endif
+__global__ __launch_bounds__(256, KB_SMALL_OCC) void update_small_kernel(CtlArgs A) {
     const KbState& K = A.K;
     const int count = K.heavy[2];
     if ((int)blockIdx.x >= count) return;
