@@ -380,7 +380,14 @@ static int kb_check(kb_handle* k) {
 static void launch_shared_apply(kb_handle* k, const double* props, const int32_t* counts, int budget) {
     const unsigned S = (unsigned)k->cfg.n_slices;
     hipLaunchKernelGGL(kb::shared_cols_kernel, dim3(S, KB_COLS_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, props, counts, budget);
-    hipLaunchKernelGGL(kb::shared_matvec_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
+    // d* of the whole list: on the matrix cores when the capacity (the size of a full dictionary) is a multiple of 64, by
+    // the column walk otherwise -- the same sums bit for bit (KBRL_MATVEC_MFMA=0: the column walk always)
+    static const bool mfma_on = !(getenv("KBRL_MATVEC_MFMA") && atoi(getenv("KBRL_MATVEC_MFMA")) == 0);
+    const int mfma = mfma_on && k->cfg.capacity % 64 == 0 ? 1 : 0;
+    if (mfma)
+        hipLaunchKernelGGL(kb::shared_matvec_mfma_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
+    else
+        hipLaunchKernelGGL(kb::shared_matvec_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget, 0);
     hipLaunchKernelGGL(kb::shared_gram_kernel, dim3(S, 128), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
     const size_t lds = sizeof(double) * kb::kb_apply_lds_doubles(k->cfg.capacity, k->budget_cap);
     hipLaunchKernelGGL(kb::shared_apply_kernel, dim3(S), dim3(1024), lds, k->stream, k->D, k->K, props, counts, budget, k->d_gstats);

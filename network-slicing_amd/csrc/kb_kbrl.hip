@@ -1755,10 +1755,10 @@ __global__ __launch_bounds__(256) void shared_cols_kernel(KbDev D, KbState K, co
 // d* = Kinv k_f for all proposals of the full dictionaries, each output summed exactly as matvec_colsum does (column
 // walk; eight partial sums over the row classes j mod 8, fused multiply-adds in increasing j; the same tree): a lane owns
 // output i and walks the proposals four at a time
-__global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
+__global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, const int32_t* counts, int budget, int mfma) {
     const int s = blockIdx.x;
     const int m = K.m[s];
-    if (!batch_applies(D, m)) return;
+    if (!batch_applies(D, m) || (mfma && !(m & 63))) return;  // (mfma: shared_matvec_mfma_kernel takes the multiples of 64)
     const int np = counts[s] < budget ? counts[s] : budget;
     const int capr = kb_capr(D.cap);
     const uint64_t* sh = shells_of(D, K, s);
@@ -1799,6 +1799,65 @@ __global__ __launch_bounds__(256) void shared_matvec_kernel(KbDev D, KbState K, 
             for (int r = 0; r < 4; ++r)
                 if (p0 + r < np)
                     DS[(size_t)(p0 + r) * capr + i] = ((a[0][r] + a[1][r]) + (a[2][r] + a[3][r])) + ((a[4][r] + a[5][r]) + (a[6][r] + a[7][r]));
+        }
+    }
+}
+
+// The same d* = Kinv k_f for all proposals of a full dictionary as ONE dense product on the matrix cores, DS = KF Kinv
+// (n_p x m x m), and still every output bit for bit the column walk's sum.  v_mfma_f64_16x16x4 accumulates its four
+// products as a chain of fused multiply-adds in k order onto the accumulator (tools/experiments/mfma_order.hip: 51,200 of
+// 51,200 outputs equal fma(a3,b3, fma(a2,b2, fma(a1,b1, fma(a0,b0, c)))) bit for bit), which is how matvec_colsum forms
+// ONE of its eight partial sums: class c = the rows j = c (mod 8), in increasing j.  So a wave keeps eight accumulator
+// tiles, one per row class, feeds tile c the rows c + 8 (4 h + k) of every 64-row block (k = the instruction's
+// contraction index, h = 0, 1: sixteen instructions per block of rows) and adds the eight tiles in the column walk's
+// tree at the end.  A wave owns 16 proposals x 16 outputs; the four waves of a workgroup take four proposal tiles of the
+// same output tile (they read the same rows of Kinv together).  Dictionaries whose size is a multiple of 64 only (no
+// padded rows: a padding term fma(0, 0, acc) would turn an accumulator of -0.0 into +0.0).
+__global__ __launch_bounds__(256) void shared_matvec_mfma_kernel(KbDev D, KbState K, const int32_t* counts, int budget) {
+    const int s = blockIdx.x;
+    const int m = K.m[s];
+    if (!batch_applies(D, m) || (m & 63)) return;
+    const int np = counts[s] < budget ? counts[s] : budget;
+    const int capr = kb_capr(D.cap);
+    const uint64_t* sh = shells_of(D, K, s);
+    const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    const int nb = m >> 6;
+    const double* KF = K.workb + (size_t)s * 2 * budget * capr;
+    double* DS = K.workb + (size_t)s * 2 * budget * capr + (size_t)budget * capr;
+    const int npt = (np + 15) >> 4, nct = m >> 4;
+    const int nwork = npt * nct;  // (output tile, proposal tile), proposal tile fastest: a workgroup shares its rows of Kinv
+    const int wave = blockIdx.y * (blockDim.x >> 6) + (threadIdx.x >> 6), nw = gridDim.y * (blockDim.x >> 6);
+    for (int wk = wave; wk < nwork; wk += nw) {
+        const int ct = wk / npt, pt = wk - ct * npt;
+        const int p = 16 * pt + li;                 // A operand: proposal p, row class c, contraction slot kq
+        const int bi = ct >> 2, ci = 16 * (ct & 3) + li;  // B operand: output 64 bi + ci
+        const double* ar = KF + (size_t)(p < np ? p : 0) * capr + 8 * kq;
+        kb_f64x4 acc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = (kb_f64x4){0.0, 0.0, 0.0, 0.0};
+        for (int bj = 0; bj < nb; ++bj) {
+            const double* tp = kinv_tile(K, sh, bj, bi) + (size_t)(8 * kq) * 64 + ci;
+            double a[2][8], b[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    // row 64 bj + c + 8 (4 h + kq) of the block
+                    a[h][c] = p < np ? ar[64 * bj + 32 * h + c] : 0.0;
+                    b[h][c] = tp[(size_t)(32 * h + c) * 64];
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[h][c], b[h][c], acc[c], 0, 0, 0);
+        }
+        // register r of the lane: proposal 16 pt + kq + 4 r, output 64 bi + ci
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int po = 16 * pt + kq + 4 * r;
+            if (po < np)
+                DS[(size_t)po * capr + 64 * bi + ci] =
+                    ((acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r])) + ((acc[4][r] + acc[5][r]) + (acc[6][r] + acc[7][r]));
         }
     }
 }

@@ -218,11 +218,14 @@ def test_shared_loop_run_to_run_determinism():
         R['agent'].close()
 
 
-def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch):
+@pytest.mark.parametrize('capacity', [16, 64, 192])
+def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch, capacity):
     """A shared dictionary at capacity only projects, so the apply kernel computes the kernel columns and d* = Kinv k_f
     of a whole proposal list at once and runs only predict + coefficient update in order (one wave, no block
-    barriers).  With a capacity small enough to fill within a few steps (16 landmarks), that path against the
-    one-proposal-at-a-time path (KBRL_SERIAL_APPLY): same hits, sizes, coefficients (bits) and actions at every step."""
+    barriers).  With a capacity small enough to fill within a few steps, that path against the
+    one-proposal-at-a-time path (KBRL_SERIAL_APPLY): same hits, sizes, coefficients (bits) and actions at every step.
+    Capacity 16: d* by the column walk (shared_matvec_kernel); 64 and 192: d* = KF Kinv on the matrix cores, eight
+    accumulator tiles per wave standing for the column walk's eight partial sums (shared_matvec_mfma_kernel)."""
     from ranslice.config import EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
     from ranslice.fading import synth_fading
     from ranslice.kbrl_dev import SharedVecKBRL
@@ -238,7 +241,7 @@ def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch):
         else:
             monkeypatch.delenv('KBRL_SERIAL_APPLY', raising=False)
         env = VecRanSlice(n_envs=N, cfg=cfg, fading=fading)
-        agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=16)
+        agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=64, max_rounds=4, capacity=capacity)
         monkeypatch.delenv('KBRL_SERIAL_APPLY', raising=False)
         rng = np.random.default_rng(77)
         ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
@@ -264,7 +267,7 @@ def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch):
         assert a[1] == b[1], ('sizes', i, a[1], b[1])
         assert a[2] == b[2], ('coeff', i)
         assert (a[3] == b[3]).all(), ('action', i)
-        full_seen = full_seen or max(a[1]) >= 16
+        full_seen = full_seen or max(a[1]) >= capacity
     assert full_seen, 'no dictionary reached its capacity: the batched path was not exercised'
     for R in (A, B):
         R['env'].close()
