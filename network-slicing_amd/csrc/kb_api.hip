@@ -748,6 +748,10 @@ extern "C" int kb_set_kernel_timing(kb_handle* k, int enable) {
     if (!k) return RS_EINVAL;
     k->timing = enable != 0;
     k->ev_used = 0;
+    if (enable && k->D.shared && k->d_gstats && getenv("KBRL_APPLY_TIMES")) {  // (developer aid: count from here on)
+        HIPCHK(k, hipSetDevice(k->device));
+        HIPCHK(k, hipMemsetAsync(k->d_gstats + 8, 0, sizeof(uint64_t) * 24, k->stream));
+    }
     return RS_OK;
 }
 

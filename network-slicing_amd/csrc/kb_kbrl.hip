@@ -2055,57 +2055,65 @@ __global__ __launch_bounds__(1024) void shared_apply_kernel(KbDev D, KbState K, 
     double* fp = kb_dyn_lds;  // [budget] predictions of the remaining proposals
     int from = 0;
     while (from < np) {
-        __syncthreads();
-        for (int i = from + wave; i < np; i += nw) {
-            const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
-            const double t = (double)(((int)p[1]) >> 2) / (double)D.n_prbs;
-            double part[4] = {0.0, 0.0, 0.0, 0.0};
+        // The first remaining proposal, in order, that is still a mistake.  The remaining proposals are predicted in
+        // chunks that double (one proposal per wave first): while a list is being learned its next mistake is usually among
+        // the first few, and a pass over all of the rest for every applied sample was most of a long list's time.  The
+        // predictions past the one that is applied are discarded either way (the dictionary changes under them).
+        int i = 0x7fffffff;
+        for (int lo = from, span = nw; lo < np && i == 0x7fffffff; lo += span, span *= 2) {
+            const int hi = lo + span < np ? lo + span : np;
+            __syncthreads();
+            for (int ii = lo + wave; ii < hi; ii += nw) {
+                const int i = ii;
+                const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
+                const double t = (double)(((int)p[1]) >> 2) / (double)D.n_prbs;
+                double part[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                for (int j = 64 * v + lane; j < m; j += 256) {
-                    const double* P = vec_page(K, sh, j >> 6);
+                for (int v = 0; v < 4; ++v) {
+                    for (int j = 64 * v + lane; j < m; j += 256) {
+                        const double* P = vec_page(K, sh, j >> 6);
+                        double d0 = 0.0;
+                        for (int q = 0; q < d - 1; ++q) {
+                            const double u = P[q * KB_CH + lane] - p[2 + q];
+                            d0 += u * u;
+                        }
+                        const double dl = P[(d - 1) * KB_CH + lane] - t;
+                        double k = rs_exp(-D.gamma * (d0 + dl * dl));
+                        if (m == 1) k = (double)(float)k;
+                        part[v] += k * P[KB_ROW_CO * KB_CH + lane];
+                    }
+                }
+                for (int dd = 32; dd >= 1; dd >>= 1) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
+                }
+                double f = 0.0;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) f += __shfl(part[v], 0);
+                if (m == 1) {  // float32 while a single landmark is held (kernel.py:16, projectron.py:9)
+                    const double* P = vec_page(K, sh, 0);
                     double d0 = 0.0;
                     for (int q = 0; q < d - 1; ++q) {
-                        const double u = P[q * KB_CH + lane] - p[2 + q];
+                        const double u = P[q * KB_CH] - p[2 + q];
                         d0 += u * u;
                     }
-                    const double dl = P[(d - 1) * KB_CH + lane] - t;
-                    double k = rs_exp(-D.gamma * (d0 + dl * dl));
-                    if (m == 1) k = (double)(float)k;
-                    part[v] += k * P[KB_ROW_CO * KB_CH + lane];
+                    const double dl = P[(d - 1) * KB_CH] - t;
+                    f = (double)(float)((float)rs_exp(-D.gamma * (d0 + dl * dl)) * (float)P[KB_ROW_CO * KB_CH]);
                 }
+                if (m == 0) f = 0.0;
+                if (lane == 0) fp[i] = f;
+                    }
+            __syncthreads();
+            if (threadIdx.x == 0) sm.ired[5] = 0x7fffffff;
+            __syncthreads();
+            for (int q = lo + (int)threadIdx.x; q < hi; q += blockDim.x) {
+                const int y = (((int)props[((size_t)s * budget + q) * KB_PROP_W + 1]) & 1) ? 1 : -1;
+                if (fp[q] * (double)y <= 0.0) atomicMin(&sm.ired[5], q);
             }
-            for (int dd = 32; dd >= 1; dd >>= 1) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) part[v] += __shfl_xor(part[v], dd);
-            }
-            double f = 0.0;
-#pragma unroll
-            for (int v = 0; v < 4; ++v) f += __shfl(part[v], 0);
-            if (m == 1) {  // float32 while a single landmark is held (kernel.py:16, projectron.py:9)
-                const double* P = vec_page(K, sh, 0);
-                double d0 = 0.0;
-                for (int q = 0; q < d - 1; ++q) {
-                    const double u = P[q * KB_CH] - p[2 + q];
-                    d0 += u * u;
-                }
-                const double dl = P[(d - 1) * KB_CH] - t;
-                f = (double)(float)((float)rs_exp(-D.gamma * (d0 + dl * dl)) * (float)P[KB_ROW_CO * KB_CH]);
-            }
-            if (m == 0) f = 0.0;
-            if (lane == 0) fp[i] = f;
+            __syncthreads();
+            i = sm.ired[5];
+            __syncthreads();
         }
-        __syncthreads();
-        // the first remaining proposal, in order, that is still a mistake
-        if (threadIdx.x == 0) sm.ired[5] = 0x7fffffff;
-        __syncthreads();
-        for (int i = from + (int)threadIdx.x; i < np; i += blockDim.x) {
-            const int y = (((int)props[((size_t)s * budget + i) * KB_PROP_W + 1]) & 1) ? 1 : -1;
-            if (fp[i] * (double)y <= 0.0) atomicMin(&sm.ired[5], i);
-        }
-        __syncthreads();
-        const int i = sm.ired[5];
-        __syncthreads();
         if (i == 0x7fffffff) break;
         const double* p = props + ((size_t)s * budget + i) * KB_PROP_W;
         const int packed = (int)p[1];
