@@ -1519,7 +1519,10 @@ __global__ __launch_bounds__(256) void shared_fgemm_kernel(KbDev D, KbState K, c
     }
 }
 
-__global__ __launch_bounds__(64) void shared_scan_kernel(ScanArgs A) {
+#ifndef KB_SCAN_OCC
+#define KB_SCAN_OCC 3
+#endif
+__global__ __launch_bounds__(64, KB_SCAN_OCC) void shared_scan_kernel(ScanArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ Lds sm;
