@@ -47,9 +47,41 @@ __device__ double rs_log_ool(double x);
 #include "../../include/rs_philox.h"
 #include "../../include/ranslice.h"
 
+typedef double rs_d2 __attribute__((ext_vector_type(2)));
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __noinline__ double rs_exp_ool(double x) { return rs_exp(x); }
 __device__ __noinline__ double rs_log_ool(double x) { return rs_log(x); }
+// rs_exp of two independent arguments in one call: the two dependent chains (reduction, a 13-step Horner form, the
+// scaling) interleave instruction by instruction, so a wave that is waiting on its own arithmetic -- the heaviest waves of a
+// launch, which the others make way for -- gets through two exponentials in little more than the time of one.  Same
+// values as rs_exp, special cases by selection instead of branches.
+__device__ __forceinline__ double rs_exp_sel(double x, double core) {
+    double v = x < -745.2 ? 0.0 : core;
+    v = x > 709.782712893384 ? rs_inf() : v;
+    return x != x ? x : v;
+}
+__device__ __noinline__ rs_d2 rs_exp2_ool(rs_d2 x) {
+    const double a = (x.x >= -745.2 && x.x <= 709.782712893384) ? x.x : 0.0;
+    const double b = (x.y >= -745.2 && x.y <= 709.782712893384) ? x.y : 0.0;
+    const double ca = rs_exp_core(a), cb = rs_exp_core(b);
+    rs_d2 o;
+    o.x = rs_exp_sel(x.x, ca);
+    o.y = rs_exp_sel(x.y, cb);
+    return o;
+}
+// MCSCodeset's logistic curve (rs_sigmoid) of two arguments at once: same values
+__device__ __forceinline__ rs_d2 rs_sigmoid2(double x1, double x2, double x0, double k) {
+    rs_d2 t;
+    t.x = (-k) * (x1 - x0);
+    t.y = (-k) * (x2 - x0);
+    const rs_d2 e = rs_exp2_ool(t);
+    rs_d2 o;
+    o.x = 1.0 / (1.0 + e.x);
+    o.y = 1.0 / (1.0 + e.y);
+    return o;
+}
+#else
+__device__ rs_d2 rs_sigmoid2(double x1, double x2, double x0, double k);  // (host pass: device code only)
 #endif
 
 namespace rs {
@@ -341,20 +373,32 @@ __device__ __forceinline__ double lane_pairwise(int n, bool on, F ld) {
 }
 
 // one block by the 8 lanes of a TEAM: lane j owns R_j.  Every lane of the team must call it with the same (off, n).
-// f(i) may be expensive (the response evaluates a sigmoid per element), so every lane walks its own accumulator
-// serially and the team meets only for the tree and the remainder.  Loops are wave-uniform (`on` masks idle teams).
-// The result is valid in lane 0 of the team.
-template <class F>
-__device__ __forceinline__ double team_block(int off, int n, int j, bool on, F f) {
+// The elements are expensive (the response evaluates a sigmoid of a table value per element), so every lane walks its own
+// accumulator serially and the team meets only for the tree and the remainder.  f2(i1, p1, i2, p2) returns elements i1
+// and i2 together (p: the lane needs that one; the other half of the pair is garbage otherwise): a lane's elements are
+// evaluated two at a time -- the remainder element with the first of the accumulator, then the accumulator's in pairs --
+// and added one after the other in the same order as ever.  Loops are wave-uniform (`on` masks idle teams).  The result
+// is valid in lane 0 of the team.
+template <class F2>
+__device__ __forceinline__ double team_block(int off, int n, int j, bool on, F2 f2) {
     double res = 0.0;
     const int lim = n >= 8 ? n - (n & 7) : 0;
     const int rem = n - lim;
-    // the sequential remainder's operands are independent of the tree: evaluate them first
-    double v = (on && j < rem) ? f(off + lim + j) : 0.0;
+    const bool hv = on && j < rem, h0 = on && n >= 8;
+    // the sequential remainder's operands are independent of the tree: evaluated with the accumulator's first element
+    double v = 0.0, r = 0.0;
+    if (wave_any(hv || h0)) {
+        const rs_d2 s = f2(off + lim + j, hv, off + j, h0);
+        v = hv ? s.x : 0.0;
+        r = h0 ? s.y : 0.0;
+    }
     if (wave_any(on && n >= 8)) {
-        double r = (on && n >= 8) ? f(off + j) : 0.0;
-        for (int i = 8; wave_any(on && i < lim); i += 8)
-            if (on && i < lim) r += f(off + i + j);
+        for (int i = 8; wave_any(on && i < lim); i += 16) {
+            const bool p1 = on && i < lim, p2 = on && i + 8 < lim;
+            const rs_d2 s = f2(off + i + j, p1, off + i + 8 + j, p2);
+            if (p1) r += s.x;
+            if (p2) r += s.y;
+        }
         // ((R0+R1)+(R2+R3))+((R4+R5)+(R6+R7)): each pairing is commutative, so both partners agree
         r += dpp_d<DPP_XOR1>(r);
         r += dpp_d<DPP_XOR2>(r);
@@ -372,14 +416,14 @@ __device__ __forceinline__ double team_block(int off, int n, int j, bool on, F f
     return res;
 }
 
-template <class F>
-__device__ __forceinline__ double team_pairwise(int n, int j, bool on, F f) {
+template <class F2>
+__device__ __forceinline__ double team_pairwise(int n, int j, bool on, F2 f2) {
     const PwSplit s(n);
-    double a = team_block(0, s.n0, j, on, f);
+    double a = team_block(0, s.n0, j, on, f2);
     if (wave_any(on && s.n1 > 0)) {
-        double b = team_block(s.n0, s.n1, j, on && s.n1 > 0, f);
+        double b = team_block(s.n0, s.n1, j, on && s.n1 > 0, f2);
         if (wave_any(on && s.n2 > 0)) {
-            const double c = team_block(s.n0 + s.n1, s.n2, j, on && s.n2 > 0, f);
+            const double c = team_block(s.n0 + s.n1, s.n2, j, on && s.n2 > 0, f2);
             b = s.n2 > 0 ? b + c : b;
         }
         a = s.n1 > 0 ? a + b : a;
@@ -520,9 +564,12 @@ __device__ __forceinline__ double team_response(const RsDev* D, const double* fa
         const double* __restrict__ sp = fad + (on ? c0 : 0);
         // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
         const bool single = n == 1;
-        const double sv = team_pairwise(n, j, on, [&](int i) {
-            const double x = sp[i] + nom;
-            return single ? x : rs_sigmoid(x, x0, kk);
+        const double sv = team_pairwise(n, j, on, [&](int i1, bool p1, int i2, bool p2) {
+            const double x1 = (p1 ? sp[i1] : 0.0) + nom, x2 = (p2 ? sp[i2] : 0.0) + nom;  // (both fetches in flight)
+            rs_d2 o;
+            o.x = x1;
+            o.y = x2;
+            return single ? o : rs_sigmoid2(x1, x2, x0, kk);
         });
         const double got = bperm(sv, (my_sp & 7) << 3);
         if (mine && (my_sp >> 3) == round) sum_rx = got;
@@ -549,12 +596,20 @@ __device__ __noinline__ double wide_response(const RsDev* D, const double* fad, 
         const int md = __builtin_amdgcn_readlane(mod, ol);
         const double nom = nom_wave[ol];
         const double x0 = D->mi_x0[md], kk = D->mi_k[md];
-        for (int k0 = 0; k0 < n; k0 += 64) {
-            const int k = k0 + lane;
-            if (k < n) wmi[k] = rs_sigmoid(fad[c0 + k] + nom, x0, kk);
+        for (int k0 = 0; k0 < n; k0 += 128) {  // two RBs per lane and pass
+            const int k1 = k0 + lane, k2 = k0 + 64 + lane;
+            const double x1 = (k1 < n ? fad[c0 + k1] : 0.0) + nom, x2 = (k2 < n ? fad[c0 + k2] : 0.0) + nom;
+            const rs_d2 sg = rs_sigmoid2(x1, x2, x0, kk);
+            if (k1 < n) wmi[k1] = sg.x;
+            if (k2 < n) wmi[k2] = sg.y;
         }
         __builtin_amdgcn_wave_barrier();
-        const double sv = team_pairwise(n, lane & 7, lane < 8, [&](int i) { return wmi[i]; });
+        const double sv = team_pairwise(n, lane & 7, lane < 8, [&](int i1, bool p1, int i2, bool p2) {
+            rs_d2 o;
+            o.x = p1 ? wmi[i1] : 0.0;
+            o.y = p2 ? wmi[i2] : 0.0;
+            return o;
+        });
         const double got = bperm(sv, 0);
         if (lane == ol) out = got;
         __builtin_amdgcn_wave_barrier();
