@@ -535,11 +535,11 @@ __device__ __forceinline__ void walker_advance(int& findex, int& fstep, int Tn, 
 // whole wave are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator R_j: it evaluates the
 // sigmoid of its elements one after the other and adds them in numpy's order, the team meets for the tree and the
 // remainder.  No per-RB values are stored anywhere.  Returns the lane's own sum (or `keep` if it has no span).
-__device__ __forceinline__ double team_response(const RsDev* D, const double* fad, const double* nom_wave, bool mine,
+// mi: the logistic curves' (x0, k) per modulation in LDS, mi[md] and mi[4 + md] (six doubles held in registers across the
+// response were what pushed five loop-long values out to scratch in every slot)
+__device__ __forceinline__ double team_response(const double* mi, const double* fad, const double* nom_wave, bool mine,
                                                 int rbs, int span_col, int mod, double keep) {
     const int lane = (int)(threadIdx.x & 63u);
-    const double x0_0 = D->mi_x0[0], x0_1 = D->mi_x0[1], x0_2 = D->mi_x0[2];
-    const double kk_0 = D->mi_k[0], kk_1 = D->mi_k[1], kk_2 = D->mi_k[2];
     double sum_rx = keep;
     const unsigned long long wmask = __builtin_amdgcn_ballot_w64(mine);
     const int n_sp = __popcll(wmask);
@@ -560,7 +560,7 @@ __device__ __forceinline__ double team_response(const RsDev* D, const double* fa
         const int n = bperm(rbs, owner);
         const int md = bperm(mod, owner);
         const double nom = nom_wave[owner];
-        const double x0 = sel3(md, x0_0, x0_1, x0_2), kk = sel3(md, kk_0, kk_1, kk_2);
+        const double x0 = mi[md], kk = mi[4 + md];
         const double* __restrict__ sp = fad + (on ? c0 : 0);
         // a UE holding a single RB skips the MI average (channel_models.py:305): keep x itself
         const bool single = n == 1;
@@ -583,7 +583,7 @@ __device__ __forceinline__ double team_response(const RsDev* D, const double* fa
 // purpose: random-action batches never come here, and in line its registers cost the hot loop spills.
 #define RS_WIDE_SPAN 64
 #define RS_WIDE_MAX 192   // wider spans (193..256 RBs) take the team path
-__device__ __noinline__ double wide_response(const RsDev* D, const double* fad, double* wmi, const double* nom_wave,
+__device__ __noinline__ double wide_response(const double* mi, const double* fad, double* wmi, const double* nom_wave,
                                              bool mine, int rbs, int span_col, int mod) {
     const int lane = (int)(threadIdx.x & 63u);
     double out = 0.0;
@@ -595,7 +595,7 @@ __device__ __noinline__ double wide_response(const RsDev* D, const double* fad, 
         const int c0 = __builtin_amdgcn_readlane(span_col, ol);
         const int md = __builtin_amdgcn_readlane(mod, ol);
         const double nom = nom_wave[ol];
-        const double x0 = D->mi_x0[md], kk = D->mi_k[md];
+        const double x0 = mi[md], kk = mi[4 + md];
         for (int k0 = 0; k0 < n; k0 += 128) {  // two RBs per lane and pass
             const int k1 = k0 + lane, k2 = k0 + 64 + lane;
             const double x1 = (k1 < n ? fad[c0 + k1] : 0.0) + nom, x2 = (k2 < n ? fad[c0 + k2] : 0.0) + nom;
@@ -639,6 +639,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     __shared__ short T_esnr[256][CH];        // round(mean(snr)) of the UE in the CH slots of the current chunk
     __shared__ int L_lut[RS_LUT_MAX];        // e_snr -> modulation << 24 | mcs << 16 | rate (mcs_rate_vs_error)
     __shared__ double L_ref[32];             // MCS reference SNR (estimate_rx_prob)
+    __shared__ double L_mi[8];               // logistic MI curves: x0 of the three modulations, pad, k of the three, pad
     __shared__ int L_task[TPB][4];           // per task: cbr_at, vbr_at, slice draw counter, next UE serial
     __shared__ double W_mi[4][RS_WIDE_MAX];  // per wave: MI values of one WIDE span (response of 65..192 RBs); sized so
                                              // that a block stays within 25 LDS granules of 1280 B: 5 blocks per CU
@@ -646,6 +647,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const int tid = (int)threadIdx.x;
     if (tid < RS_LUT_MAX) L_lut[tid] = tid < D->lut_n ? ((D->mcs_mod[D->lut_mcs[tid]] << 24) | (D->lut_mcs[tid] << 16) | D->lut_rate[tid]) : 0;
     if (tid >= 64 && tid < 96) L_ref[tid - 64] = D->mcs_ref[tid - 64];
+    if (tid >= 96 && tid < 104) L_mi[tid - 96] = (tid & 3) == 3 ? 0.0 : (tid < 100 ? D->mi_x0[tid - 96] : D->mi_k[tid - 100]);
     __syncthreads();
     const RsState& S = *A.S;
     const int clock0 = (int)A.run[0];
@@ -1424,8 +1426,6 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             // anything: those that sent bits.  (A UE holding RBs without data still consumes its Bernoulli draw
             // below; the allocation trace wants every probability, so the tracing instances evaluate them all.)
             const bool needed = sched && active && rbs > 0 && (TRACE || bits > 0);
-            const double x0_0 = D->mi_x0[0], x0_1 = D->mi_x0[1], x0_2 = D->mi_x0[2];
-            const double kk_0 = D->mi_k[0], kk_1 = D->mi_k[1], kk_2 = D->mi_k[2];
             // R1 + R2 fused: np.mean's pairwise sum of the mutual information over a UE's RBs.  The spans to evaluate
             // (all tasks of the wave) are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator
             // R_j: it evaluates the sigmoid of its elements one after the other and adds them in numpy's order, the
@@ -1434,12 +1434,12 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             const int span_col = col + prb_lo + prb_i;  // first element of my span in the fading table
             constexpr int WIDE = RS_WIDE_SPAN;
             const bool wide_sp = needed && rbs > WIDE && rbs <= RS_WIDE_MAX;
-            if (wave_any(wide_sp)) sum_rx = wide_response(D, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
-            sum_rx = team_response(D, A.fad, &L_nom[wb], needed && !wide_sp, rbs, span_col, mod, sum_rx);
+            if (wave_any(wide_sp)) sum_rx = wide_response(L_mi, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
+            sum_rx = team_response(L_mi, A.fad, &L_nom[wb], needed && !wide_sp, rbs, span_col, mod, sum_rx);
             SEC_MARK(10)
             // R3: effective SNR and reception probability, every evaluated UE in its own lane
             if (needed) {
-                const double x0 = sel3(mod, x0_0, x0_1, x0_2), kk = sel3(mod, kk_0, kk_1, kk_2);
+                const double x0 = L_mi[mod], kk = L_mi[4 + mod];
                 double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
                 if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
                 const double x = D->mcsA * (s_eff - L_ref[mcs]) - D->mcsB;

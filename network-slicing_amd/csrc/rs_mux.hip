@@ -70,6 +70,7 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
     __shared__ double W_mi[RS_MAX_PRBS];
     __shared__ int L_lut[RS_LUT_MAX];
     __shared__ double L_ref[32];
+    __shared__ double L_mi[8];  // logistic MI curves (x0 x 3, pad, k x 3, pad): team_response / wide_response
     const RsDev* __restrict__ D = A.D;
     const RsState& S = *A.S;
     const int lane = (int)threadIdx.x;
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
     const int cap = M * RS_GROUP < RS_MUX_UE ? M * RS_GROUP : RS_MUX_UE;
     L_lut[lane] = lane < D->lut_n ? ((D->mcs_mod[D->lut_mcs[lane]] << 24) | (D->lut_mcs[lane] << 16) | D->lut_rate[lane]) : 0;
     if (lane < 32) L_ref[lane] = D->mcs_ref[lane];
+    if (lane >= 32 && lane < 40) L_mi[lane - 32] = (lane & 3) == 3 ? 0.0 : (lane < 36 ? D->mi_x0[lane - 32] : D->mi_k[lane - 36]);
     for (int i = lane; i < M * 10; i += 64) L_info[i / 10][i % 10] = 0.0;
     if (lane < M) {
         const int task = rep * M + lane;
@@ -455,8 +457,8 @@ __global__ __launch_bounds__(64) void embb_mux_step_kernel(StepArgs A) {
             const int span_col = col + prb_lo + prb_i;
             double sum_rx = 0.0;
             const bool wide_sp = needed && rbs > RS_WIDE_SPAN;
-            if (wave_any(wide_sp)) sum_rx = wide_response(D, A.fad, W_mi, L_nom, wide_sp, rbs, span_col, mod);
-            sum_rx = team_response(D, A.fad, L_nom, needed && !wide_sp, rbs, span_col, mod, sum_rx);
+            if (wave_any(wide_sp)) sum_rx = wide_response(L_mi, A.fad, W_mi, L_nom, wide_sp, rbs, span_col, mod);
+            sum_rx = team_response(L_mi, A.fad, L_nom, needed && !wide_sp, rbs, span_col, mod, sum_rx);
             if (needed) {
                 const double x0 = D->mi_x0[mod], kk = D->mi_k[mod];
                 double s_eff = sum_rx;
