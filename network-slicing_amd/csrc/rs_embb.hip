@@ -839,6 +839,12 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         pace_ref = __builtin_amdgcn_readfirstlane((unsigned)pace_ref);  // < 2^32 cycles per slot
     }
     for (int t = 0; t < slots; ++t) {
+        // (the slot's own copy of the thread index, opaque to the optimiser: the addresses of this thread's entries in the
+        // dozen LDS arrays are then formed where they are used -- one base register and the array's offset in the
+        // instruction -- instead of being hoisted out of the loop, one register each, and spilled: the hottest spill slots
+        // of the kernel held nothing but such addresses)
+        int lt = tid;
+        asm volatile("" : "+v"(lt));
         if (RS_DYN_PRIO && pace_ref != 0ull && t >= 2) {
             const unsigned long long el = (__builtin_amdgcn_s_memtime() - pace_t0) * 32ull;
             const unsigned long long due = (unsigned long long)t * pace_ref;
@@ -917,9 +923,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                 const unsigned userial = next_serial + (uint32_t)k;
                 rs_stream st = {key0, key1, (uint32_t)sl, userial, 0u};
                 queue = 0.0; th = 0.0; e_snr = 0; ue_bits = 0; ue_prbs = 0;
-                L_acc_traf[tid] = 0; L_acc_bits[tid] = 0; L_acc_prbs[tid] = 0;
+                L_acc_traf[lt] = 0; L_acc_bits[lt] = 0; L_acc_prbs[lt] = 0;
 #pragma unroll
-                for (int q = 0; q < RS_BURSTS; ++q) L_burst[q][tid] = 0;
+                for (int q = 0; q < RS_BURSTS; ++q) L_burst[q][lt] = 0;
                 n_act = 0;
                 int uvbr_at = RS_NEVER;
                 if (type == 1) {  // VbrSource.__init__ (traffic_generators.py:62-68)
@@ -941,11 +947,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                     nominal = mc.x;
                     st.ctr = (uint32_t)mc.y;
                 }
-                L_hold[tid] = hold_at;
-                L_uvbr[tid] = uvbr_at;
-                L_serial[tid] = userial;
-                L_ctr[tid] = st.ctr;
-                L_nom[tid] = nominal;
+                L_hold[lt] = hold_at;
+                L_uvbr[lt] = uvbr_at;
+                L_serial[lt] = userial;
+                L_ctr[lt] = st.ctr;
+                L_nom[lt] = nominal;
                 evt_at = hold_at < uvbr_at ? hold_at : uvbr_at;
                 flags = type | (ftype << 1) | ((fstep > 0 ? 1 : 0) << 3);
                 active = true;
@@ -1026,7 +1032,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         int n_cur = n_act;  // bursts that emit in THIS slot (an arrival of this slot starts emitting next slot)
         if (wave_any(active && evt_at == now)) {
             // ---- departures (slice_ran.py:251-261) + extract_users (slice_l1.py:187-191)
-            const bool depart = active && evt_at == now && L_hold[tid] == now;
+            const bool depart = active && evt_at == now && L_hold[lt] == now;
             if (wave_any(depart)) {
                 flush();
                 const unsigned keep = group_ballot<G>(active && !depart, gbase);
@@ -1056,15 +1062,15 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                 __builtin_amdgcn_wave_barrier();
                 n_ue = n_keep;
                 active = gl < n_ue;
-                L_hold[tid] = active ? m_hold : RS_NEVER;
-                L_uvbr[tid] = active ? m_uvbr : RS_NEVER;
-                L_serial[tid] = active ? m_ser : 0u;
-                L_ctr[tid] = m_ctr;
-                L_nom[tid] = m_nom;
+                L_hold[lt] = active ? m_hold : RS_NEVER;
+                L_uvbr[lt] = active ? m_uvbr : RS_NEVER;
+                L_serial[lt] = active ? m_ser : 0u;
+                L_ctr[lt] = m_ctr;
+                L_nom[lt] = m_nom;
 #pragma unroll
-                for (int k = 0; k < RS_BURSTS; ++k) L_burst[k][tid] = m_b[k];
+                for (int k = 0; k < RS_BURSTS; ++k) L_burst[k][lt] = m_b[k];
 #pragma unroll
-                for (int k = 0; k < CH / 2; ++k) ((int*)T_esnr[tid])[k] = m_e[k];
+                for (int k = 0; k < CH / 2; ++k) ((int*)T_esnr[lt])[k] = m_e[k];
                 if (!active) { evt_at = RS_NEVER; n_act = 0; }
                 n_cur = n_act;
             }
@@ -1074,9 +1080,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                 unsigned freek = RS_BURSTS;                      // a free entry for a burst that may start now
 #pragma unroll
                 for (int k = 0; k < RS_BURSTS; ++k) {
-                    const unsigned e = L_burst[k][tid];
+                    const unsigned e = L_burst[k][lt];
                     const int rel = e != 0u ? rs_burst_rel(e, now) : 0;
-                    if (e != 0u && rel <= 0) L_burst[k][tid] = 0;  // ends exactly now: dropped without emitting
+                    if (e != 0u && rel <= 0) L_burst[k][lt] = 0;  // ends exactly now: dropped without emitting
                     if (rel > 0) {
                         cnt += 1;
                         nxt = now + rel < nxt ? now + rel : nxt;
@@ -1085,12 +1091,12 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                     }
                 }
                 n_cur = cnt;
-                int uvbr_at = L_uvbr[tid];
+                int uvbr_at = L_uvbr[lt];
                 if (uvbr_at == now) {
-                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], L_ctr[tid]};
+                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], L_ctr[lt]};
                     const int d = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_b_size));
                     const int v = (int)RS_RINT(rs_stream_exponential(&st, D->vbr_inter));
-                    L_ctr[tid] = st.ctr;
+                    L_ctr[lt] = st.ctr;
                     if (d < 1) {  // Q5: a duration that rounds to 0 never counts down to 0: the burst emits for ever
                         if (((flags >> 8) & 0xff) == 0xff) err |= 2;
                         else flags += 1 << 8;
@@ -1100,15 +1106,15 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                     } else {
 #pragma unroll
                         for (int k = 0; k < RS_BURSTS; ++k)
-                            if ((unsigned)k == freek) L_burst[k][tid] = (unsigned short)rs_burst_code(now + d);
+                            if ((unsigned)k == freek) L_burst[k][lt] = (unsigned short)rs_burst_code(now + d);
                         cnt += 1;
                         nxt = now + d < nxt ? now + d : nxt;
                     }
                     uvbr_at = v >= 1 ? now + v : RS_NEVER;
-                    L_uvbr[tid] = uvbr_at;
+                    L_uvbr[lt] = uvbr_at;
                 }
                 n_act = cnt;
-                const int h = L_hold[tid];
+                const int h = L_hold[lt];
                 int e = h < uvbr_at ? h : uvbr_at;
                 evt_at = e < nxt ? e : nxt;
             }
@@ -1121,7 +1127,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         if (active) {
             const double new_bits = is_vbr ? (double)n_cur * D->vbr_p_size : D->cbr_bits;
             queue += new_bits;
-            atomicAdd(&L_acc_traf[tid], (int)new_bits);
+            atomicAdd(&L_acc_traf[lt], (int)new_bits);
         }
         const bool any_queue = group_ballot<G>(active && queue > 0.0, gbase) != 0u;
 
@@ -1133,10 +1139,10 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         if (n_prb > 0 && active) {
             int fstep = (flags & 8) ? 1 : -1;
             walker_advance(findex, fstep, sel3(ftype, T0, T1, T2), has_nan, A.fad_valid + sel3(ftype, vo0, vo1, vo2), key0,
-                           key1, (uint32_t)sl, L_serial[tid], (uint32_t)now);
+                           key1, (uint32_t)sl, L_serial[lt], (uint32_t)now);
             flags = (flags & ~8) | ((fstep > 0 ? 1 : 0) << 3);
             col = sel3(ftype, fo0, fo1, fo2) + findex * P;
-            e_snr = T_esnr[tid][tt0];
+            e_snr = T_esnr[lt][tt0];
         }
         stat += (unsigned)n_ue;
 
@@ -1450,12 +1456,12 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             if (sched && active) {
                 bool received = false;
                 if (rbs > 0) {  // the draw is consumed whether or not anything rides on it
-                    const unsigned c = L_ctr[tid];
+                    const unsigned c = L_ctr[lt];
                     if (needed) {
-                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[tid], c};
+                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], c};
                         received = rs_stream_uniform(&st) < p_rx;
                     }
-                    L_ctr[tid] = c + 1u;
+                    L_ctr[lt] = c + 1u;
                 }
                 if (!received) bits = 0;
                 double nq = queue - (double)bits;
@@ -1470,8 +1476,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         SEC_MARK(5)
         // ================= SliceRANeMBB.update_info (slice_ran.py:278-305); Q2: stale bits/prbs count
         if (active) {
-            atomicAdd(&L_acc_bits[tid], ue_bits);
-            atomicAdd(&L_acc_prbs[tid], ue_prbs);
+            atomicAdd(&L_acc_bits[lt], ue_bits);
+            atomicAdd(&L_acc_prbs[lt], ue_prbs);
         }
         {
             const unsigned m_c = group_ballot<G>(active && !is_vbr, gbase);
@@ -1516,7 +1522,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         if (TRACE) {
             if (valid) {
                 rs_alloc_rec rec;
-                rec.serial = active ? (int32_t)L_serial[tid] : 0;
+                rec.serial = active ? (int32_t)L_serial[lt] : 0;
                 rec.type = active ? (flags & 1) : 0;
                 rec.e_snr = active ? e_snr : 0;
                 rec.prbs = active ? ue_prbs : 0;
