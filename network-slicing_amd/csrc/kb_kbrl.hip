@@ -729,7 +729,8 @@ __device__ __forceinline__ int learner_of_block(const KbState& K, int T, int par
     return t < T && !K.isbig[(size_t)par * T + t] ? t : -1;
 }
 
-// y_pred of update_control's first predict, the accuracy table and the security factor (kbrl_control.py:88-101)
+// y_pred of update_control's first predict, the accuracy table and the security factor (kbrl_control.py:88-101).
+// Called by one-wave kernels only (64 threads).
 __device__ __forceinline__ int control_bookkeeping(const KbDev& D, const KbState& K, int task, int env, int s, int m, double f0, int y,
                                                    int32_t* hits, Lds& sm) {
     const int n = D.n_prbs;
@@ -747,25 +748,40 @@ __device__ __forceinline__ int control_bookkeeping(const KbDev& D, const KbState
     int margin = K.margins[env * D.S + s];
     margin = margin > 0 ? margin : 0;
     double* acc = K.acc + ((size_t)env * D.S + s) * n;
-    if (y_pred == 1) {
-        for (int c = threadIdx.x; c < n; c += blockDim.x) {
-            if (!hit) {
-                if (c < margin + 1) acc[c] = (1 - D.alfa) * acc[c];
-            } else {
-                if (c >= margin) acc[c] = (1 - D.alfa) * acc[c] + D.alfa;
+    // (one wave: a lane holds the table entries c = lane, lane + 64, ... -- one fetch for the update and for the search of
+    // the first entry above the threshold, no barrier and no second trip through memory between them)
+    const bool adj = K.adjusted[env] != 0;
+    if (y_pred == 1 || !adj) {
+        const int lane = threadIdx.x & 63;
+        double a[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = lane + 64 * k < n ? acc[lane + 64 * k] : 0.0;
+        if (y_pred == 1) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = lane + 64 * k;
+                if (c < n) {
+                    if (!hit) {
+                        if (c < margin + 1) {
+                            a[k] = (1 - D.alfa) * a[k];
+                            acc[c] = a[k];
+                        }
+                    } else if (c >= margin) {
+                        a[k] = (1 - D.alfa) * a[k] + D.alfa;
+                        acc[c] = a[k];
+                    }
+                }
             }
         }
-    }
-    __syncthreads();
-    if (!K.adjusted[env]) {
-        if (threadIdx.x == 0) sm.ired[1] = 0x7fffffff;
-        __syncthreads();
-        int first = 0x7fffffff;
-        for (int c = threadIdx.x; c < n; c += blockDim.x)
-            if (acc[c] > D.lo) { first = c; break; }
-        if (first != 0x7fffffff) atomicMin(&sm.ired[1], first);
-        __syncthreads();
-        if (threadIdx.x == 0) K.security[env * D.S + s] = sm.ired[1] == 0x7fffffff ? 0 : sm.ired[1];
+        if (!adj) {
+            int first = 0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned long long above = __ballot(lane + 64 * k < n && a[k] > D.lo);
+                if (first == 0x7fffffff && above) first = 64 * k + __builtin_ctzll(above);
+            }
+            if (threadIdx.x == 0) K.security[env * D.S + s] = first == 0x7fffffff ? 0 : first;
+        }
     }
     if (threadIdx.x == 0) hits[env * D.S + s] = hit;
     return hit;
