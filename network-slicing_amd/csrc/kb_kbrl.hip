@@ -811,10 +811,33 @@ __device__ __forceinline__ void share_scores(double (&f)[4], Lds& sm) {
     for (int g = 0; g < 4; ++g) f[g] = sm.fbuf[g * 64 + (threadIdx.x & 63)];
 }
 
+// the scores of the window again (same state: the E row is reused).  A candidate's score does not depend on which other
+// candidates are computed with it, so a workgroup of four waves or more gives each of the window's (up to four) groups of
+// 64 candidates to a wave of its own -- a quarter of the scoring chain per wave -- and the groups meet in LDS; a single
+// wave does all of them.  Same sums either way.
 __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, Win w,
                                         double (&f)[4]) {
-    if (threadIdx.x < 64) score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
-    share_scores(f, sm);
+    if (blockDim.x == 64) {
+        score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
+        return;
+    }
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double f1[1] = {0.0};
+    if (blockDim.x >= 256) {
+        if (g < w.ng) score<1, 1>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);  // (w.ng <= 4: waves beyond it idle)
+    } else if (threadIdx.x < 64) {
+        score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    }
+    __syncthreads();
+    if (blockDim.x >= 256) {
+        if (g < 4) sm.fbuf[g * 64 + lane] = g < w.ng ? f1[0] : 0.0;
+    } else if (threadIdx.x < 64) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sm.fbuf[q * 64 + lane] = f[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) f[q] = sm.fbuf[q * 64 + lane];
 }
 
 __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, int task, int env, int dict, int m, int d, int y,
