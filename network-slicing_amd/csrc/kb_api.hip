@@ -40,6 +40,8 @@ struct kb_handle {
     int budget_cap = 256;
     int heavy_blocks = 256;
     int heavy_rounds = 3;
+    int rounds_gate = 200;         // tiles of Kinv queued per step from which the rounds are enqueued (eight learners of 320 landmarks;
+                                   // KBRL_ROUNDS_GATE)
     bool gemm_fresh = false;       // shared, resident loop: workF / workE hold the scores of d_prev_state against the dictionaries as they are
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
@@ -203,6 +205,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         k->heavy_rounds = atoi(getenv("KBRL_ROUNDS"));
         k->rounds_always = true;
     }
+    if (getenv("KBRL_ROUNDS_GATE")) k->rounds_gate = atoi(getenv("KBRL_ROUNDS_GATE"));
     if (hipHostMalloc((void**)&k->h_seen, sizeof(int32_t), hipHostMallocMapped) != hipSuccess) k->h_seen = nullptr;
     if (k->h_seen) *k->h_seen = 0;
     D.serial_apply = getenv("KBRL_SERIAL_APPLY") ? 1 : 0;  // test knob: the batched apply of full dictionaries off
@@ -444,7 +447,7 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         // enqueued only once a recent step has queued a few large learners.  The host reads that count from pinned memory
         // without waiting for the device, so it lags by the depth of the launch queue; until it catches up the clean-up
         // kernel below, which is always launched, repairs them one workgroup each.  Results do not depend on it.
-        const bool rounds = k->rounds_always || (k->h_seen && *(volatile int32_t*)k->h_seen >= 8);
+        const bool rounds = k->rounds_always || (k->h_seen && *(volatile int32_t*)k->h_seen >= k->rounds_gate);
         if (rounds && k->heavy_rounds > 0) hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
         for (int r = 0; rounds && r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
             hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);

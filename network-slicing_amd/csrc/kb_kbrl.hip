@@ -940,7 +940,11 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
             if (m >= KB_SMALL_M || INLINE) {
                 // the first repair is prepared here: scores, range, the mistake and its kernel column
                 int slot = 0;
-                if (threadIdx.x == 0) slot = atomicAdd(&K.heavy[0], 1);
+                if (threadIdx.x == 0) {
+                    slot = atomicAdd(&K.heavy[0], 1);
+                    const int nbq = (m + 63) >> 6;
+                    atomicAdd(&K.heavy[3], nbq * nbq);  // tiles of Kinv a repair of this learner walks (the rounds' gate)
+                }
                 slot = __builtin_amdgcn_readfirstlane(slot);
                 const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -2294,8 +2298,11 @@ __global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K,
 
 // end of the update phase: the queues are emptied for the next step; how many large learners were queued goes to a word of
 // host memory the launcher reads WITHOUT synchronising (it decides whether the next steps enqueue the repair rounds at all)
+// (seen: the work queued for the large learners' repairs in this step, in tiles of Kinv per repair pass: what the host goes
+// by when it decides whether the next steps enqueue the chip-wide rounds -- a handful of dictionaries of 300 landmarks
+// are repaired by a workgroup each in less time than nine idle launches take, ONE of 1,500 is not)
 __global__ void heavy_reset_kernel(KbState K, volatile int32_t* seen) {
-    if (seen) *seen = K.heavy[0];
+    if (seen) *seen = K.heavy[3];
     K.heavy[0] = K.heavy[1] = K.heavy[2] = K.heavy[3] = 0;
 }
 
