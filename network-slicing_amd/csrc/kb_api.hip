@@ -42,6 +42,7 @@ struct kb_handle {
     int heavy_rounds = 3;
     int rounds_gate = 200;         // tiles of Kinv queued per step from which the rounds are enqueued (eight learners of 320 landmarks;
                                    // KBRL_ROUNDS_GATE)
+    double* d_bigf = nullptr;      // [KB_BIG_MAX][256] detect_big_kernel's window scores of the listed learners
     bool gemm_fresh = false;       // shared, resident loop: workF / workE hold the scores of d_prev_state against the dictionaries as they are
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
@@ -153,6 +154,7 @@ extern "C" int kb_comm_init(kb_handle* k, const void* id128, int rank, int world
     k->comm_rank = rank;
     k->comm_world = world;
     if (k->d_gather) (void)hipFree(k->d_gather);
+    if (k->d_bigf) (void)hipFree(k->d_bigf);
     k->d_gather = nullptr;
     return RS_OK;
 }
@@ -206,8 +208,8 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         k->rounds_always = true;
     }
     if (getenv("KBRL_ROUNDS_GATE")) k->rounds_gate = atoi(getenv("KBRL_ROUNDS_GATE"));
-    if (hipHostMalloc((void**)&k->h_seen, sizeof(int32_t), hipHostMallocMapped) != hipSuccess) k->h_seen = nullptr;
-    if (k->h_seen) *k->h_seen = 0;
+    if (hipHostMalloc((void**)&k->h_seen, 2 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess) k->h_seen = nullptr;
+    if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
     D.serial_apply = getenv("KBRL_SERIAL_APPLY") ? 1 : 0;  // test knob: the batched apply of full dictionaries off
     D.first_env = cfg->first_env;
     k->nv = o;
@@ -355,7 +357,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
-    if (k->h_seen) *k->h_seen = 0;
+    if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
     k->gemm_fresh = false;
     k->big_par = 0;
     HIPCHK(k, hipMemset(k->K.big, 0, sizeof(int32_t) * 2 * (1 + KB_BIG_MAX)));
@@ -430,10 +432,20 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
     a.labels = d_labels;
     a.hits = k->d_hits;
     a.big_par = k->D.shared ? -1 : k->big_par;
+    a.bigf = nullptr;
     const unsigned grid1 = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
+    // most learners are large (the pinned count of listed learners, a step or two old): their scoring pass by a workgroup
+    // each, a wave per group of candidates, ahead of the one-wave kernel (same scores; KBRL_BIG_DETECT=0 never, =1 always)
+    static const int big_detect = getenv("KBRL_BIG_DETECT") ? atoi(getenv("KBRL_BIG_DETECT")) : -1;
+    const bool mostly_large = k->h_seen && 2 * (long long)*(volatile int32_t*)(k->h_seen + 1) >= (long long)k->T;
+    if (big_detect != 0 && (mostly_large || big_detect > 0) && a.big_par >= 0 && k->D.heavy_m == 0) {
+        if (!k->d_bigf) HIPCHK(k, hipMalloc((void**)&k->d_bigf, sizeof(double) * (size_t)KB_BIG_MAX * 256));
+        hipLaunchKernelGGL(kb::detect_big_kernel, dim3(KB_BIG_MAX), dim3(256), 0, k->stream, a, k->d_bigf);
+        a.bigf = k->d_bigf;
+    }
     if (k->D.heavy_m > 0)
         hipLaunchKernelGGL(kb::update_control_kernel<true>, dim3(grid1), dim3(64), 0, k->stream, a);
     else

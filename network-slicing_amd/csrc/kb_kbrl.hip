@@ -714,6 +714,7 @@ struct CtlArgs {
     const int32_t* labels;  // [n_envs][S]
     int32_t* hits;          // [n_envs][S]
     int32_t big_par;        // which of the two large-learner lists orders this launch (-1: none, block index = learner)
+    const double* bigf;     // [KB_BIG_MAX][256] window scores of the listed (large) learners by detect_big_kernel, or null
 };
 
 // The learner of a workgroup of the one-wave kernels.  With a list: the first KB_BIG_MAX workgroups take the listed (large)
@@ -928,7 +929,13 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     const int c_to = y == 1 ? n : a_i;
     const Win w = window_of(c_from, c_to);
     double f[4];
-    score<4, 0>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    if (A.bigf && A.big_par >= 0 && (int)blockIdx.x < KB_BIG_MAX) {  // a listed learner: detect_big_kernel scored its window
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = A.bigf[(size_t)blockIdx.x * 256 + 64 * g + lane];
+    } else {
+        score<4, 0>(D, K, sh, m, d, sm, w.base, w.ng, f);
+    }
     control_bookkeeping(D, K, task, env, s, m, f_of(f, w, a_i), y, A.hits, sm);
 
     // ---- sample augmentation (kbrl_control.py:102-112), in the reference's order
@@ -976,6 +983,39 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
         if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
     }
     flush_stats(K, task, dict, m, st);
+}
+
+// The scoring pass of update_control_kernel for the LISTED learners (dictionaries of KB_BIG_M landmarks and more, the first
+// KB_BIG_MAX workgroups of the launch order): a workgroup of four waves per learner, one wave per group of 64 candidates
+// of the window -- a candidate's score does not depend on which others are computed with it, so these are the sums
+// score<4, 0> forms, at a quarter of the chain per wave.  Wave 0 leaves the D0 / E rows of the state as the one-wave
+// pass does.  update_control_kernel picks the scores up from bigf and goes on as ever.  Enqueued when most learners are
+// large (a 30-replica evaluation late in learning: 0.44 -> 0.2 ms per step); among 20,480 learners of which a fifth are
+// large it only delays the one-wave kernel (3.99 against 3.92 ms per step), and is not.
+__global__ __launch_bounds__(256) void detect_big_kernel(CtlArgs A, double* bigf) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    __shared__ Lds sm;
+    const int task = learner_of_block(K, D.n_envs * D.S, A.big_par);  // (grid = KB_BIG_MAX: listed learners only)
+    if (task < 0) return;
+    const int env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1, n = D.n_prbs;
+    const int dict = dict_of(D, task);
+    const uint64_t* sh = shells_of(D, K, dict);
+    const int m = K.m[dict];
+    load_gtab(K, sm);
+    stage_state(D, A.state, env, s, d, sm);
+    __syncthreads();
+    const int a_i = A.action[env * D.S + s];
+    const int y = A.labels[env * D.S + s];
+    const Win w = window_of(y == 1 ? a_i : 0, y == 1 ? n : a_i);
+    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    double f1[1] = {0.0};
+    if (g < w.ng) {
+        if (g == 0) score<1, 0>(D, K, sh, m, d, sm, w.base, 1, f1);
+        else score<1, 2>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);
+    }
+    bigf[(size_t)blockIdx.x * 256 + 64 * g + lane] = g < w.ng ? f1[0] : 0.0;
 }
 
 // the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: a workgroup of four waves each, all at
@@ -2303,6 +2343,7 @@ __global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K,
 // are repaired by a workgroup each in less time than nine idle launches take, ONE of 1,500 is not)
 __global__ void heavy_reset_kernel(KbState K, volatile int32_t* seen) {
     if (seen) *seen = K.heavy[3];
+    if (seen) seen[1] = K.big[0] > K.big[1 + KB_BIG_MAX] ? K.big[0] : K.big[1 + KB_BIG_MAX];  // listed (large) learners
     K.heavy[0] = K.heavy[1] = K.heavy[2] = K.heavy[3] = 0;
 }
 
