@@ -52,6 +52,9 @@ namespace kb {
 #define KB_VEC_ROWS 30
 #define KB_VEC (KB_VEC_ROWS * KB_CH)
 #ifndef KB_OCC
+#ifndef KB_SCORE_UNROLL1
+#define KB_SCORE_UNROLL1 8  // landmarks per unrolled block of the scoring loop when one group of candidates is scored
+#endif
 #define KB_OCC 4        // waves per SIMD the one-wave kernels are built for
 #endif
 #define KB_SMALL_M 192     // dictionaries below this repair their mistakes on one wave, larger ones on a workgroup
@@ -339,10 +342,12 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
         const bool table = lane < cnt && !direct && R.a >= 0;
         const double w = table ? R.co * E : 0.0;
         const int a8 = table ? R.a * 8 : 0;
-        // lanes without a table term carry w = 0: the loop may run to the next multiple of four
-        for (int jj0 = 0; jj0 < cnt; jj0 += 4) {
+        // lanes without a table term carry w = 0: the loop may run to the next multiple of the unroll factor (a single group
+        // of candidates has one table read per landmark: more of them in flight)
+        constexpr int UNR = NG == 1 ? KB_SCORE_UNROLL1 : 4;
+        for (int jj0 = 0; jj0 < cnt; jj0 += UNR) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < UNR; ++u) {
                 const int jj = jj0 + u;
                 const double ws = readlane_f64(w, jj);
                 const int as8 = __builtin_amdgcn_readlane(a8, jj);
