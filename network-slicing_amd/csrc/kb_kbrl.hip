@@ -183,7 +183,7 @@ __device__ __forceinline__ int grid_index(double t, int n) {
 
 // small per-block staging area (static LDS; nothing in these kernels scales with the capacity)
 struct Lds {
-    double G[KB_GTAB];
+    double G2[512];  // the kernel's last-coordinate factor, two-sided: G2[256 + k] = G[|k|], |k| <= 255 (no abs in the hot loop)
     double x[KB_DMAX];
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
@@ -191,7 +191,7 @@ struct Lds {
 };
 
 __device__ __forceinline__ void load_gtab(const KbState& K, Lds& sm) {
-    for (int k = threadIdx.x; k < KB_GTAB; k += blockDim.x) sm.G[k] = K.gtab[k];
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) sm.G2[k] = K.gtab[k < 256 ? 256 - k : k - 256];
 }
 
 // sum over the block, any block size that is a multiple of 64: butterfly per wave, wave totals in order
@@ -298,15 +298,16 @@ template <int NG, int MODE>
 __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const Lds& sm,
                                            int c_base, int ng, double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
-    int cb[NG];
+    int cb[NG], cs[NG];  // candidate x 8; (256 - candidate) x 8: the byte offset of G2[256 + a - c] is a8 + cs
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int c = c_base + 64 * g + lane;
         cb[g] = (c < D.n_prbs ? c : D.n_prbs) * 8;  // lanes past the last candidate are never looked at
+        cs[g] = (256 - (c < D.n_prbs ? c : D.n_prbs)) * 8;
         f[g] = 0.0;
     }
     const int nch = (m + 63) >> 6;
-    const char* Gb = (const char*)sm.G;
+    const char* Gb = (const char*)sm.G2;
     ChunkRows<MODE> R, Rn;
     load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
     for (int b = 0; b < nch; ++b) {
@@ -354,9 +355,7 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     if (g < ng) {  // (wave-uniform: only the groups the window reaches)
-                        int o = as8 - cb[g];
-                        o = o < 0 ? -o : o;
-                        f[g] = __builtin_fma(ws, *(const double*)(Gb + o), f[g]);
+                        f[g] = __builtin_fma(ws, *(const double*)(Gb + (as8 + cs[g])), f[g]);
                     }
                 }
             }
@@ -880,7 +879,7 @@ __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, in
             for (int g = 0; g < 4; ++g) {
                 int o = cstar - (w.base + 64 * g + lane);
                 o = o < 0 ? -o : o;
-                f[g] = __builtin_fma((double)y, sm.G[o < 255 ? o : 255], f[g]);
+                f[g] = __builtin_fma((double)y, sm.G2[256 + (o < 255 ? o : 255)], f[g]);
             }
             st.n_eval += left;
         } else {  // projection (every coefficient moved), or the first two landmarks
@@ -1222,7 +1221,7 @@ __global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
                 for (int g = 0; g < 4; ++g) {  // one more term, E = 1 (augment_loop)
                     int o = cstar - (w.base + 64 * g + lane);
                     o = o < 0 ? -o : o;
-                    f[g] = __builtin_fma((double)y, sm.G[o < 255 ? o : 255], f[g]);
+                    f[g] = __builtin_fma((double)y, sm.G2[256 + (o < 255 ? o : 255)], f[g]);
                 }
                 st.n_eval += left;
             } else {
