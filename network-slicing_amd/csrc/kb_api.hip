@@ -42,7 +42,6 @@ struct kb_handle {
     int heavy_rounds = 3;
     int rounds_gate = 200;         // tiles of Kinv queued per step from which the rounds are enqueued (eight learners of 320 landmarks;
                                    // KBRL_ROUNDS_GATE)
-    double* d_bigf = nullptr;      // [KB_BIG_MAX][256] detect_big_kernel's window scores of the listed learners
     bool gemm_fresh = false;       // shared, resident loop: workF / workE hold the scores of d_prev_state against the dictionaries as they are
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
@@ -153,8 +152,7 @@ extern "C" int kb_comm_init(kb_handle* k, const void* id128, int rank, int world
     }
     k->comm_rank = rank;
     k->comm_world = world;
-    if (k->d_gather) (void)hipFree(k->d_gather);
-    if (k->d_bigf) (void)hipFree(k->d_bigf);
+    if (k->d_gather) (void)hipFree(k->d_gather);  // (sized by the world: allocated again on the first exchange)
     k->d_gather = nullptr;
     return RS_OK;
 }
@@ -202,6 +200,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     D.gamma = cfg->gamma;
     D.eta = cfg->eta;
     D.shared = cfg->shared_dictionary ? 1 : 0;
+    D.tri = D.shared ? 0 : 1;  // one agent per replica: the lower block triangle of Kinv only (kb_kbrl.hip, "Storage")
     D.heavy_m = getenv("KBRL_HEAVY_M") ? atoi(getenv("KBRL_HEAVY_M")) : 0;  // developer knob; results do not depend on it
     if (getenv("KBRL_ROUNDS")) {  // developer knob (tests): that many rounds, always enqueued; results do not depend on it
         k->heavy_rounds = atoi(getenv("KBRL_ROUNDS"));
@@ -235,7 +234,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         // The pool every dictionary of the handle grows in (kb_kbrl.hip, "Storage").  Upper bound on what can ever be
         // asked for: every dictionary at its capacity.  kb_config.pool_bytes == 0 picks a default below it.
         unsigned long long need_all = 64;
-        for (int b = 0; b < D.max_shells; ++b) need_all += (unsigned long long)ND * kb::kb_shell_doubles(b);
+        for (int b = 0; b < D.max_shells; ++b) need_all += (unsigned long long)ND * kb::kb_shell_doubles(b, D.tri);
         unsigned long long want = cfg->pool_bytes > 0 ? (unsigned long long)cfg->pool_bytes / 8 : need_all;
         if (want > need_all) want = need_all;
         if (cfg->pool_bytes <= 0) {
@@ -248,9 +247,9 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
             if (want > modest) want = modest;
             if (want > avail) want = avail;
         }
-        const unsigned long long least = 64 + (unsigned long long)ND * kb::kb_shell_doubles(0);
+        const unsigned long long least = 64 + (unsigned long long)ND * kb::kb_shell_doubles(0, D.tri);
         if (want < least) {
-            k->err = "kb_create: the dictionary pool cannot hold even one shell (43 KB) per dictionary";
+            k->err = "kb_create: the dictionary pool cannot hold even one shell (51 KB) per dictionary";
             return RS_EINVAL;
         }
         D.pool_doubles = want;
@@ -277,6 +276,10 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_cstar, T, true);
     KA(K.workb, D.shared ? (size_t)cfg->n_slices * 2 * k->budget_cap * kb::kb_capr(cfg->capacity) : 1, true);
     KA(K.offgrid, ND, true);
+    KA(K.F, D.shared ? 1 : T * 256, true);
+    KA(K.fstate, D.shared ? 1 : T * 16, true);
+    KA(K.fver, T, true);
+    KA(K.ver, ND, true);
     KA(K.workq, D.shared ? (size_t)cfg->n_slices * 16 * kb::kb_capr(cfg->capacity) * 16 : 1, true);
     KA(K.workF, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N * 256 : 1, true);
     KA(K.workE, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N : 1, true);
@@ -354,6 +357,8 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.shell, 0, sizeof(uint64_t) * (size_t)k->n_dict * k->D.max_shells, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.head, 0xFF, sizeof(int32_t) * (size_t)k->n_dict * KB_HEAD, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.offgrid, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.ver, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.fver, 0xFF, sizeof(int32_t) * T, k->stream));  // -1: no stored scores
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
@@ -432,20 +437,10 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
     a.labels = d_labels;
     a.hits = k->d_hits;
     a.big_par = k->D.shared ? -1 : k->big_par;
-    a.bigf = nullptr;
     const unsigned grid1 = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;
-    // most learners are large (the pinned count of listed learners, a step or two old): their scoring pass by a workgroup
-    // each, a wave per group of candidates, ahead of the one-wave kernel (same scores; KBRL_BIG_DETECT=0 never, =1 always)
-    static const int big_detect = getenv("KBRL_BIG_DETECT") ? atoi(getenv("KBRL_BIG_DETECT")) : -1;
-    const bool mostly_large = k->h_seen && 2 * (long long)*(volatile int32_t*)(k->h_seen + 1) >= (long long)k->T;
-    if (big_detect != 0 && (mostly_large || big_detect > 0) && a.big_par >= 0 && k->D.heavy_m == 0) {
-        if (!k->d_bigf) HIPCHK(k, hipMalloc((void**)&k->d_bigf, sizeof(double) * (size_t)KB_BIG_MAX * 256));
-        hipLaunchKernelGGL(kb::detect_big_kernel, dim3(KB_BIG_MAX), dim3(256), 0, k->stream, a, k->d_bigf);
-        a.bigf = k->d_bigf;
-    }
     if (k->D.heavy_m > 0)
         hipLaunchKernelGGL(kb::update_control_kernel<true>, dim3(grid1), dim3(64), 0, k->stream, a);
     else
@@ -486,7 +481,13 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     int rc = kb_time_begin(k, &e1, 1);
     if (rc != RS_OK) return rc;
     if (a.gemm) launch_shared_gemm(k, d_state);
-    hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0)), dim3(64), 0, k->stream, a);
+    if (k->D.shared) {
+        hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
+    } else {  // one agent per replica: sixteen learners per workgroup, their scores as one product on the matrix cores
+        const unsigned slots = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
+        hipLaunchKernelGGL(kb::select_gemm_kernel, dim3((slots + KB_SEL_WAVES - 1) / KB_SEL_WAVES), dim3(64 * KB_SEL_WAVES), 0,
+                           k->stream, a);
+    }
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,
                        k->K, d_action_out, a.big_par);
@@ -545,6 +546,10 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
         env->device != k->device) {
         k->err = "kb_step_resident: agent and environment do not match (or kb_reset missing)";
         return RS_EINVAL;
+    }
+    if (k->D.shared) {  // (update_control's repair kernels are not launched for shared dictionaries: nothing would learn)
+        k->err = "kb_step_resident: shared-dictionary handles step through kb_shared_step_resident";
+        return RS_ESTATE;
     }
     HIPCHK(k, hipSetDevice(k->device));
     if (env->hint_auto && !env->block_hint) {  // the next steps take agent-made allocations

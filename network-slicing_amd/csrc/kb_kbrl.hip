@@ -9,11 +9,14 @@
 // a POOL shared by all dictionaries of the handle and grows 64 landmarks at a time, like the reference's np.vstack /
 // np.append / np.column_stack do one landmark at a time (projectron.py:17-21,52-57): when landmark 64 b arrives the
 // learner's own workgroup takes "shell" b from a bump allocator --
-//     [ vector page: 30 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
-//     [ 2 b + 1 tiles of 64 x 64 doubles  ]  Kinv tiles (b,0) .. (b,b), then (0,b) .. (b-1,b)
-// and records its pool offset in the dictionary's shell table.  Nothing is ever moved or freed before kb_reset, so
+//     [ vector page: 38 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
+//     [ b + 1 tiles of 64 x 64 doubles    ]  Kinv tiles (b,0) .. (b,b): the LOWER block triangle (round 4)
+// and records its pool offset in the dictionary's shell table.  Kinv is symmetric bit for bit (it only ever receives
+// (d_i d_j) / delta), so the upper block triangle is never stored: the rank-1 update streams half of what it did and
+// the pool holds twice the landmarks.  (Shared dictionaries -- five per handle -- keep both triangles, 2 b + 1 tiles per
+// shell, and the round-3 kernels that walk them: KbDev.tri = 0.)  Nothing is ever moved or freed before kb_reset, so
 // the capacity is bounded by the pool (device memory), not by a per-learner reservation: a handle of 4096 x 5
-// learners costs what its dictionaries hold (43 KB each while below 64 landmarks; round 2 reserved 8 MB each).
+// learners costs what its dictionaries hold (51 KB each while below 64 landmarks; round 2 reserved 8 MB each).
 //
 // Scoring.  Both hot loops of the agent -- the augmentation loop of update_control and the scan of select_action --
 // evaluate the classifier on candidates x_c = (state, c / n_prbs) that differ only in the last coordinate, and the
@@ -49,7 +52,8 @@ namespace kb {
 #define KB_ROW_DS 20      //   d* = Kinv K_f
 #define KB_ROW_IDX 21     //   64 x int32 grid index a_j of the last coordinate (-1: off the grid), 64 x int32 chain link
 #define KB_ROW_PART 22    //   8 rows: the partial sums of d* over the row classes j mod 8 (matvec_colsum)
-#define KB_VEC_ROWS 30
+#define KB_ROW_PARTT 30   //   8 rows: the same over the rows whose tiles are stored transposed (triangle storage: matvec_tri_unit)
+#define KB_VEC_ROWS 38
 #define KB_VEC (KB_VEC_ROWS * KB_CH)
 #ifndef KB_OCC
 #ifndef KB_SCORE_UNROLL1
@@ -65,6 +69,8 @@ namespace kb {
 #define KB_GEMM_KS 8       // the landmarks are split in this many parts (one wave each per 16 replicas)
 #define KB_E_TINY 1e-280   // below this E_j G[.] would leave the normal range: direct evaluation (score_pass)
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
+#define KB_BIN_M 128      // a repair rescoring a dictionary of this many landmarks or more uses the binned form (score_binned)
+#define KB_SEL_WAVES 16   // learners per workgroup of select_gemm_kernel: the N dimension of its v_mfma_f64_16x16x4 tiles
 
 typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
 
@@ -78,6 +84,7 @@ struct KbDev {
     int32_t first_env; // global id of local replica 0 (shared mode proposals carry global ids)
     int32_t serial_apply; // shared mode: apply a full dictionary's proposals one by one as well (KBRL_SERIAL_APPLY, tests)
     int32_t heavy_m;      // dictionaries of this many landmarks repair their mistakes in update_heavy_kernel
+    int32_t tri;          // 1: only the lower block triangle of Kinv is stored (one agent per replica); 0: both (shared dictionaries)
     uint64_t pool_doubles;
 };
 
@@ -123,6 +130,12 @@ struct KbState {
     int32_t* isbig;    // [2][T] membership of that list
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
     int32_t* offgrid;  // [ND] landmarks whose last coordinate is off the candidate grid (inserted through kb_update)
+    // the scores select_action formed for every candidate of its state (select_gemm_kernel): update_control of the SAME
+    // state against the SAME dictionary (the next call of KBRL_Control.run's loop, kbrl_control.py:129-134) starts from them
+    double* F;         // [T][256]
+    float* fstate;     // [T][16] the state F was computed for
+    int32_t* fver;     // [T] K.ver[dict] when F was computed (-1: none)
+    int32_t* ver;      // [ND] bumped by every Projectron.update that changed the dictionary (finish_update)
     double* workq;     // shared mode: [S][16][capr][16] Q[j][c] = coeff_j G[|a_j - c|] in MFMA B-operand tiles (shared_q_kernel)
     double* workF;     // shared mode: [S][KB_GEMM_KS][n_envs][256] partial scores F = E Q (shared_fgemm_kernel)
     double* workE;     // shared mode: [S][KB_GEMM_KS][n_envs] largest E_j a replica met in its part of the landmarks
@@ -138,13 +151,19 @@ __host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
 __host__ __device__ inline size_t kb_apply_lds_doubles(int cap, int budget) {  // shared_apply_kernel's dynamic LDS
     return (size_t)kb_capr(cap) + 4 * (size_t)budget;
 }
-__host__ __device__ inline uint64_t kb_shell_doubles(int b) { return (uint64_t)KB_VEC + (uint64_t)(2 * b + 1) * KB_TILE; }
+__host__ __device__ inline uint64_t kb_shell_doubles(int b, int tri) {
+    return (uint64_t)KB_VEC + (uint64_t)((tri ? b : 2 * b) + 1) * KB_TILE;
+}
 
 __device__ __forceinline__ const uint64_t* shells_of(const KbDev& D, const KbState& K, int dict) {
     return K.shell + (size_t)dict * D.max_shells;
 }
 __device__ __forceinline__ double* vec_page(const KbState& K, const uint64_t* sh, int b) { return K.pool + sh[b]; }
-// tile holding Kinv[i][j] for i in row block bi, j in column block bj (row-major 64 x 64)
+// tile holding Kinv[i][j] for i in row block bi, j in column block bj (row-major 64 x 64).  kinv_tile_lo: bj <= bi, the
+// tiles every dictionary stores; kinv_tile: any (bi, bj) of a dictionary that stores both triangles (KbDev.tri == 0).
+__device__ __forceinline__ double* kinv_tile_lo(const KbState& K, const uint64_t* sh, int bi, int bj) {
+    return K.pool + sh[bi] + KB_VEC + (size_t)bj * KB_TILE;
+}
 __device__ __forceinline__ double* kinv_tile(const KbState& K, const uint64_t* sh, int bi, int bj) {
     return bj <= bi ? K.pool + sh[bi] + KB_VEC + (size_t)bj * KB_TILE
                     : K.pool + sh[bj] + KB_VEC + (size_t)(bj + 1 + bi) * KB_TILE;
@@ -187,6 +206,8 @@ struct Lds {
     double x[KB_DMAX];
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
+    double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned)
+    int tag[256];      //   and its per-bin claim tags (bin_pass)
     int ired[8];
 };
 
@@ -380,13 +401,13 @@ __device__ __forceinline__ void score_pass(const KbDev& D, const KbState& K, con
 
 // the single-landmark dictionary: numpy keeps k and coeff in float32 (kernel.py:16, projectron.py:9)
 template <int NG, int MODE>
-__device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, const uint64_t* sh, int d, const Lds& sm, int c_base,
+__device__ __forceinline__ void score_single(const KbDev& D, const KbState& K, const uint64_t* sh, int d, const double* x, int c_base,
                                              double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     double* P = vec_page(K, sh, 0);
     double d0 = 0.0;
     for (int q = 0; q < d - 1; ++q) {
-        const double t = P[q * KB_CH] - sm.x[q];
+        const double t = P[q * KB_CH] - x[q];
         d0 += t * t;
     }
     if (MODE == 0 && lane == 0) {
@@ -412,9 +433,165 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 #pragma unroll
         for (int g = 0; g < NG; ++g) f[g] = 0.0;
     } else if (m == 1) {
-        score_single<NG, MODE>(D, K, sh, d, sm, c_base, f);
+        score_single<NG, MODE>(D, K, sh, d, sm.x, c_base, f);
     } else {
         score_pass<NG, MODE>(D, K, sh, m, d, sm, c_base, ng, f);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------ binned scoring (round 4)
+// f(c) = sum_j (coeff_j E_j) G[|a_j - c|] only depends on the landmarks through the sums per grid index,
+//     W[a] = sum_{j : a_j = a} coeff_j E_j          (one pass over the landmarks: the exp, nothing per candidate)
+//     f(c) = sum_a G[|a - c|] W[a]                   (a Toeplitz matrix times a vector: no trace of m left)
+// so the cost of scoring EVERY candidate of a state stops depending on the dictionary's size, and the second line is a
+// dense product T W, T[c][a] = G[|a - c|] the same for every learner of the handle: select_gemm_kernel forms it for
+// sixteen learners at a time on the matrix cores (v_mfma_f64_16x16x4, N = learners).  The order of both sums is fixed so
+// that every kernel produces the same bits:
+//   * W[a] takes its landmarks in increasing j (bin_pass: a chunk's lanes that share a bin claim it in lane order
+//     through an integer ds_min tag -- no floating-point atomic whose order the hardware would choose);
+//   * f(c) is ONE chain of fused multiply-adds over a = 0, 1, ..., KA - 1 (KA = n_prbs + 1 rounded up to four) starting
+//     from zero -- which is what consecutive v_mfma_f64_16x16x4 on one accumulator compute (tools/experiments/mfma_order.hip)
+//     and what chain_scores spells out on the vector ALU;
+//   * landmarks that cannot be binned (off the candidate grid, or E_j below KB_E_TINY: see score_pass) add their exact
+//     exponentials afterwards, in increasing j (add_direct_terms).
+// The reference's k @ coeff is a BLAS dot in no particular order (kernel.py:24); like score_pass's table form these
+// sums agree with it to a few ulp of sum |coeff_j k_j| (tests: f within 1e-9 (1 + sum |w|), every decision exact).
+
+// W[a * wstride] += coeff_j E_j over the dictionary, by ONE wave, for the state x.  MODE 0: D0 / E are computed and left in
+// the dictionary's rows; MODE 1: the E row is reused.  W zeroed and tag[] = 64 on entry (tag[] = 64 again on return).
+// Returns whether any landmark takes the direct evaluation.
+template <int MODE>
+__device__ __forceinline__ bool bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
+                                         volatile double* W, int wstride, volatile int* tag) {
+    const int lane = threadIdx.x & 63;
+    const int nch = (m + 63) >> 6;
+    bool any_direct = false;
+    ChunkRows<MODE> R, Rn;
+    load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
+    for (int b = 0; b < nch; ++b) {
+        double* P = vec_page(K, sh, b);
+        R = Rn;
+        if (b + 1 < nch) load_chunk<MODE>(vec_page(K, sh, b + 1), lane, d, Rn);
+        const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
+        double E, d0 = 0.0;
+        if (MODE == 1) {
+            E = R.v[0];
+        } else {
+            if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82)
+#pragma unroll
+                for (int q = 0; q < 10; ++q) {
+                    const double t = R.v[q] - x[q];
+                    d0 += t * t;
+                }
+            } else {
+                d0 = dist0(P, lane, d, x);
+            }
+            E = rs_exp_nonpos(-D.gamma * d0);
+            P[KB_ROW_D0 * KB_CH + lane] = d0;
+            P[KB_ROW_E * KB_CH + lane] = E;
+        }
+        const bool direct = lane < cnt && (R.a < 0 || (!(E >= KB_E_TINY) && E > 0.0));
+        any_direct = any_direct || __ballot(direct) != 0ull;
+        const double w = R.co * E;
+        const int a = R.a;
+        // every lane with a term claims its bin with its lane number; the lowest lane of a bin adds, releases the bin and
+        // leaves; the others come round again: landmarks enter W[a] in increasing j whatever the chunk looks like
+        bool pend = lane < cnt && !direct && a >= 0 && w != 0.0;
+        while (__ballot(pend)) {
+            if (pend) atomicMin((int*)tag + a, lane);
+            const int t = pend ? tag[a] : -1;
+            if (pend && t == lane) {
+                W[a * wstride] = W[a * wstride] + w;
+                tag[a] = 64;
+                pend = false;
+            }
+        }
+    }
+    return any_direct;
+}
+
+// f[g] = sum_a G[|a - c|] W[a], c = c_base + 64 g + lane: one chain of fused multiply-adds over a = 0 .. KA - 1 per candidate
+template <int NG>
+__device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, const volatile double* W, int wstride, int c_base,
+                                             int ng, double (&f)[NG]) {
+    const int lane = threadIdx.x & 63;
+    const int KA = (D.n_prbs + 4) & ~3;
+    int cs[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = c_base + 64 * g + lane;
+        cs[g] = 256 - (c < D.n_prbs ? c : D.n_prbs);
+        f[g] = 0.0;
+    }
+    for (int a0 = 0; a0 < KA; a0 += 4) {
+        double wv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) wv[u] = W[(a0 + u) * wstride];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                if (g < ng) f[g] = __builtin_fma(G2[a0 + u + cs[g]], wv[u], f[g]);
+        }
+    }
+}
+
+// the landmarks bin_pass left out (off the grid, or E_j below KB_E_TINY) add coeff_j exp(-gamma (D0_j + (l_j - c/n)^2)), in
+// increasing j (D0 / E are in the dictionary's rows)
+template <int NG>
+__device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, int c_base, int ng,
+                                                 double (&f)[NG]) {
+    const int lane = threadIdx.x & 63;
+    const int nch = (m + 63) >> 6;
+    double tc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int c = c_base + 64 * g + lane;
+        tc[g] = (double)(c < D.n_prbs ? c : D.n_prbs) / (double)D.n_prbs;
+    }
+    for (int b = 0; b < nch; ++b) {
+        const double* P = vec_page(K, sh, b);
+        const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
+        const double E = P[KB_ROW_E * KB_CH + lane];
+        const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
+        unsigned long long dm = __ballot(lane < cnt && (a < 0 || (!(E >= KB_E_TINY) && E > 0.0)));
+        if (!dm) continue;
+        const double d0 = P[KB_ROW_D0 * KB_CH + lane], lam = P[(d - 1) * KB_CH + lane], co = P[KB_ROW_CO * KB_CH + lane];
+        while (dm) {
+            const int jj = __builtin_ctzll(dm);
+            dm &= dm - 1ull;
+            const double cs = readlane_f64(co, jj), ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g < ng) {
+                    const double dl = ls - tc[g];
+                    f[g] = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
+                }
+            }
+        }
+    }
+}
+
+// the binned scores of the first ng (<= NG) groups of 64 candidates from c_base on, by ONE wave using the block's sm.W / sm.tag
+template <int NG, int MODE>
+__device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, int c_base,
+                                             int ng, double (&f)[NG]) {
+    if (m == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) f[g] = 0.0;
+    } else if (m == 1) {
+        score_single<NG, MODE>(D, K, sh, d, sm.x, c_base, f);
+    } else {
+        const int lane = threadIdx.x & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            sm.W[lane + 64 * k] = 0.0;
+            sm.tag[lane + 64 * k] = 64;
+        }
+        const bool any_direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, 1, sm.tag);
+        chain_scores<NG>(D, sm.G2, sm.W, 1, c_base, ng, f);
+        if (any_direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, f);
     }
 }
 
@@ -557,20 +734,117 @@ __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* 
     matvec_combine(K, sh, m);
 }
 
+// ---- triangle storage (KbDev.tri): d* = Kinv K_f when only the tiles (b_i, b_j), b_j <= b_i, exist.
+// Output i = 64 bo + c sums Kinv[j][i] K_f[j] over all rows j.  Rows in the blocks br >= bo come from tile (br, bo), walked
+// down column c as ever (lane = column, coalesced rows).  Rows in the blocks br < bo are Kinv[i][j] by symmetry: row c of
+// tile (bo, br), walked ALONG the row.  A lane-per-column walk of that would touch 64 cache lines per load instruction,
+// so the wave is dealt differently there: lane = (column c = 8 x + (lane >> 3), row class sg = lane & 7) reads
+// T[c][sg + 8 k] -- the eight lanes of a column read 64 consecutive bytes, one load instruction covers eight 64-byte
+// segments, and the eight units of a column block still fetch each tile once between them.  The sum keeps ONE shape in
+// every kernel: per output sixteen partial sums, eight over the rows j = sg (mod 8) of the blocks br >= bo (increasing j,
+// fused multiply-adds: PART rows) and eight over those of the blocks br < bo (PARTT rows), then
+// ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) of each eight and the sum of the two.
+// A work unit (bo, x), x = 0..7, is the direct part of row class x plus the transposed part of the columns 8 x .. 8 x + 7:
+// (nb - bo) + bo = nb tile passes of eight loads whatever bo is (heavy_plan_kernel's work line counts on that).
+__device__ __forceinline__ void matvec_tri_units(const KbState& K, const uint64_t* sh, int m, int u0, int ustride,
+                                                 int u_end = 0x7fffffff) {
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
+    for (int u = u0; u < nb * 8 && u < u_end; u += ustride) {
+        const int bo = u >> 3, x = u & 7;
+        {  // rows of the blocks br >= bo: down the columns of tile (br, bo)
+            double acc = 0.0;
+            for (int br = bo; br < nb; ++br) {
+                const double kfv = vec_page(K, sh, br)[KB_ROW_KF * KB_CH + lane];
+                const double* tp = kinv_tile_lo(K, sh, br, bo) + lane;
+                const int rows = m - 64 * br < 64 ? m - 64 * br : 64;
+                double v[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = x + 8 * k;
+                    v[k] = r < rows ? tp[r * 64] : 0.0;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int r = x + 8 * k;
+                    if (r < rows) acc = __builtin_fma(v[k], readlane_f64(kfv, r), acc);
+                }
+            }
+            vec_page(K, sh, bo)[(KB_ROW_PART + x) * KB_CH + lane] = acc;
+        }
+        {  // rows of the blocks br < bo: along the rows of tile (bo, br)
+            const int cl = lane >> 3, sg = lane & 7, c = 8 * x + cl;
+            double acc = 0.0;
+            for (int br = 0; br < bo; ++br) {
+                const double* kfp = vec_page(K, sh, br) + KB_ROW_KF * KB_CH + sg;
+                const double* tp = kinv_tile_lo(K, sh, bo, br) + c * 64 + sg;
+                double v[8], kv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    v[k] = tp[8 * k];
+                    kv[k] = kfp[8 * k];
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = __builtin_fma(v[k], kv[k], acc);
+            }
+            vec_page(K, sh, bo)[(KB_ROW_PARTT + sg) * KB_CH + c] = acc;
+        }
+    }
+}
+
+__device__ __forceinline__ void matvec_tri_combine(const KbState& K, const uint64_t* sh, int m) {
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        double* P = vec_page(K, sh, i >> 6) + (i & 63);
+        double p[8], q[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            p[k] = P[(KB_ROW_PART + k) * KB_CH];
+            q[k] = P[(KB_ROW_PARTT + k) * KB_CH];
+        }
+        const double a = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
+        const double b = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+        P[KB_ROW_DS * KB_CH] = a + b;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void matvec_tri_colsum(const KbState& K, const uint64_t* sh, int m) {
+    matvec_tri_units(K, sh, m, threadIdx.x >> 6, blockDim.x >> 6);
+    __syncthreads();
+    matvec_tri_combine(K, sh, m);
+}
+
+// tile t of the lower block triangle in the order (0,0) (1,0) (1,1) (2,0) ...
+__device__ __forceinline__ void tri_tile_of(int t, int* bi, int* bj) {
+    int b = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((b + 1) * (b + 2) / 2 <= t) ++b;
+    while (b * (b + 1) / 2 > t) --b;
+    *bi = b;
+    *bj = t - b * (b + 1) / 2;
+}
+
 // Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta (projectron.py:54-58) over the m1 = m + 1 landmarks, d* (with
 // its -1) in the DS row.  A work unit is 16 rows of a tile: all 16 loads of a lane are in flight before the first store
-// (d_i broadcast from the row block's lanes, d_j in this lane).  Every entry is formed as old + (d_i d_j) (1 / delta).
-__device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh, int m, double delta, int u0, int ustride,
+// (d_i broadcast from the row block's lanes, d_j in this lane).  Every entry is formed as old + (d_i d_j) / delta, the
+// reference's own expression (a true division: the kernel is bound by the tiles it streams, not by the divide), and
+// d_i d_j = d_j d_i keeps Kinv symmetric bit for bit.  tri: only the tiles (b_i, b_j), b_j <= b_i, exist (units count
+// along the lower block triangle); diagonal tiles hold both of their halves.
+__device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh, int m, double delta, int tri, int u0, int ustride,
                                             int u_end = 0x7fffffff) {
     const int m1 = m + 1, nb = (m1 + 63) >> 6, lane = threadIdx.x & 63;
-    const double inv = 1.0 / delta;
-    for (int u = u0; u < nb * nb * 4 && u < u_end; u += ustride) {
+    const int ntile = tri ? nb * (nb + 1) / 2 : nb * nb;
+    for (int u = u0; u < ntile * 4 && u < u_end; u += ustride) {
         const int tb = u >> 2, r0 = (u & 3) * 16;
-        const int bi = tb / nb, bj = tb - bi * nb;
+        int bi, bj;
+        if (tri) {
+            tri_tile_of(tb, &bi, &bj);
+        } else {
+            bi = tb / nb;
+            bj = tb - bi * nb;
+        }
         const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
         const int j = 64 * bj + lane;
         if (r0 >= rows) continue;  // (wave-uniform)
-        double* T = kinv_tile(K, sh, bi, bj) + lane;
+        double* T = (tri ? kinv_tile_lo(K, sh, bi, bj) : kinv_tile(K, sh, bi, bj)) + lane;
         const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
         const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
         double old[16];
@@ -583,21 +857,28 @@ __device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh
         for (int k = 0; k < 16; ++k) {
             const int r = r0 + k;
             const double dsi = readlane_f64(dsi_v, r);
-            if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) * inv;
+            if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) / delta;
         }
     }
 }
 
-// take shell b for the dictionary (thread 0; everybody learns the outcome).  false: capacity or pool exhausted.
+// take shell b for the dictionary (thread 0; everybody learns the outcome).  false: capacity or pool exhausted.  The top
+// only moves when the request fits (compare-and-swap): a large shell that does not fit leaves the space to the smaller
+// ones of other dictionaries instead of pushing the top past the end for everybody.
 __device__ __forceinline__ bool take_shell(const KbDev& D, const KbState& K, int dict, int b, Lds& sm) {
     if (threadIdx.x == 0) {
         int ok = 0;
         if (b < D.max_shells) {
-            const unsigned long long need = kb_shell_doubles(b);
-            const unsigned long long at = atomicAdd(K.pool_top, need);
-            if (at + need <= D.pool_doubles) {
-                K.shell[(size_t)dict * D.max_shells + b] = at;
-                ok = 1;
+            const unsigned long long need = kb_shell_doubles(b, D.tri);
+            unsigned long long at = *(volatile unsigned long long*)K.pool_top;
+            while (at + need <= D.pool_doubles) {
+                const unsigned long long seen = atomicCAS(K.pool_top, at, at + need);
+                if (seen == at) {
+                    K.shell[(size_t)dict * D.max_shells + b] = at;
+                    ok = 1;
+                    break;
+                }
+                at = seen;
             }
         }
         sm.ired[6] = ok;
@@ -631,6 +912,7 @@ __device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
     delta = delta > 0.0 ? delta : 0.0;
     *delta_out = delta;
+    if (threadIdx.x == 0) K.ver[dict] += 1;  // the dictionary changes (projection or insertion): stored scores are stale
     // A dictionary that cannot grow (capacity reached, or the pool has no shell left) projects every further sample
     // onto its span -- the fixed-budget reading of Projectron -- instead of growing as the reference's unbounded
     // SVvariable would: learning goes on, nothing is dropped, and the replica is flagged (err bit 8 "saturated", bit 16
@@ -682,9 +964,9 @@ __device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err
     }
     __syncthreads();
     if (m == 0) {
-        if (threadIdx.x == 0) kinv_tile(K, sh, 0, 0)[0] = 1.0;
+        if (threadIdx.x == 0) kinv_tile_lo(K, sh, 0, 0)[0] = 1.0;
     } else if (!defer_rank1) {
-        rank1_units(K, sh, m, delta, threadIdx.x >> 6, blockDim.x >> 6);
+        rank1_units(K, sh, m, delta, D.tri, threadIdx.x >> 6, blockDim.x >> 6);
     }
     __syncthreads();
     return m + 1;
@@ -702,7 +984,9 @@ __device__ int apply_update(const KbDev& D, const KbState& K, int dict, int err_
         if (threadIdx.x == 0) *vec_at(K, sh, KB_ROW_DS, 0) = (double)(1.0f * (float)*vec_at(K, sh, KB_ROW_KF, 0));
         __syncthreads();
     } else if (m >= 2) {
-        if (blockDim.x >= 256)
+        if (D.tri)
+            matvec_tri_colsum(K, sh, m);
+        else if (blockDim.x >= 256)
             matvec_colsum<4>(K, sh, m);
         else
             matvec_colsum<2>(K, sh, m);
@@ -718,21 +1002,22 @@ struct CtlArgs {
     const int32_t* labels;  // [n_envs][S]
     int32_t* hits;          // [n_envs][S]
     int32_t big_par;        // which of the two large-learner lists orders this launch (-1: none, block index = learner)
-    const double* bigf;     // [KB_BIG_MAX][256] window scores of the listed (large) learners by detect_big_kernel, or null
 };
 
-// The learner of a workgroup of the one-wave kernels.  With a list: the first KB_BIG_MAX workgroups take the listed (large)
-// learners, the others their own index unless it is listed; -1: nothing to do.  The list is the one select_kernel wrote
-// at the end of the previous step (dictionaries only grow, and not between that select and these launches).
-__device__ __forceinline__ int learner_of_block(const KbState& K, int T, int par) {
-    if (par < 0) return (int)blockIdx.x;
-    if ((int)blockIdx.x < KB_BIG_MAX) {
+// The learner of launch slot `slot` (one-wave kernels: slot = workgroup; select_gemm_kernel: a wave).  With a list: the
+// first KB_BIG_MAX slots take the listed (large) learners, the others their own index unless it is listed; -1: nothing to
+// do.  The list is the one the select kernel wrote at the end of the previous step (dictionaries only grow, and not between
+// that select and these launches).
+__device__ __forceinline__ int learner_of_slot(const KbState& K, int T, int par, int slot) {
+    if (par < 0) return slot < T ? slot : -1;
+    if (slot < KB_BIG_MAX) {
         const int32_t* L = K.big + (size_t)par * (1 + KB_BIG_MAX);
-        return (int)blockIdx.x < L[0] ? L[1 + blockIdx.x] : -1;
+        return slot < L[0] ? L[1 + slot] : -1;
     }
-    const int t = (int)blockIdx.x - KB_BIG_MAX;
+    const int t = slot - KB_BIG_MAX;
     return t < T && !K.isbig[(size_t)par * T + t] ? t : -1;
 }
+__device__ __forceinline__ int learner_of_block(const KbState& K, int T, int par) { return learner_of_slot(K, T, par, (int)blockIdx.x); }
 
 // y_pred of update_control's first predict, the accuracy table and the security factor (kbrl_control.py:88-101).
 // Called by one-wave kernels only (64 threads).
@@ -819,16 +1104,44 @@ __device__ __forceinline__ void share_scores(double (&f)[4], Lds& sm) {
 // the scores of the window again (same state: the E row is reused).  A candidate's score does not depend on which other
 // candidates are computed with it, so a workgroup of four waves or more gives each of the window's (up to four) groups of
 // 64 candidates to a wave of its own -- a quarter of the scoring chain per wave -- and the groups meet in LDS; a single
-// wave does all of them.  Same sums either way.
+// wave does all of them.  Same sums either way.  Dictionaries of KB_BIN_M landmarks and more are scored in the binned
+// form (wave 0 forms W, every wave chains its group), smaller ones landmark by landmark (score_pass): which of the two
+// depends on m alone, never on the kernel that asks.
 __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, Lds& sm, Win w,
                                         double (&f)[4]) {
+    const bool binned = m >= KB_BIN_M;
     if (blockDim.x == 64) {
-        score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
+        if (binned)
+            score_binned<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
+        else
+            score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
         return;
     }
     const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
     double f1[1] = {0.0};
-    if (blockDim.x >= 256) {
+    if (binned) {
+        __syncthreads();
+        if (threadIdx.x < 64) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                sm.W[lane + 64 * k] = 0.0;
+                sm.tag[lane + 64 * k] = 64;
+            }
+            const bool any = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, 1, sm.tag);
+            if (lane == 0) sm.ired[4] = any ? 1 : 0;
+        }
+        __syncthreads();
+        const bool any_direct = sm.ired[4] != 0;
+        if (blockDim.x >= 256) {
+            if (g < w.ng) {
+                chain_scores<1>(D, sm.G2, sm.W, 1, w.base + 64 * g, 1, f1);
+                if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, f1);
+            }
+        } else if (threadIdx.x < 64) {
+            chain_scores<4>(D, sm.G2, sm.W, 1, w.base, w.ng, f);
+            if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, f);
+        }
+    } else if (blockDim.x >= 256) {
         if (g < w.ng) score<1, 1>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);  // (w.ng <= 4: waves beyond it idle)
     } else if (threadIdx.x < 64) {
         score<4, 1>(D, K, sh, m, d, sm, w.base, w.ng, f);
@@ -933,12 +1246,26 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     const int c_to = y == 1 ? n : a_i;
     const Win w = window_of(c_from, c_to);
     double f[4];
-    if (A.bigf && A.big_par >= 0 && (int)blockIdx.x < KB_BIG_MAX) {  // a listed learner: detect_big_kernel scored its window
+    {
+        // select_action scored every candidate of the state it selected for (select_gemm_kernel) and left the D0 / E rows of
+        // that state in the dictionary.  KBRL_Control.run hands the same state back (kbrl_control.py:129-134) and nothing
+        // learns in between, so those scores ARE update_control's first predictions; otherwise (another state, or the
+        // dictionary changed since: kb_update, another update_control) they are formed here, by the same sums.
         const int lane = threadIdx.x & 63;
+        const float* st = A.state + (size_t)env * D.nv + D.off[s];
+        const bool differs = lane < d - 1 && __float_as_uint(st[lane]) != __float_as_uint(K.fstate[(size_t)task * 16 + lane]);
+        const bool stored = K.fver[task] == K.ver[dict] && __ballot(differs) == 0ull;
+        if (stored) {
+            const double* F = K.F + (size_t)task * 256;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) f[g] = A.bigf[(size_t)blockIdx.x * 256 + 64 * g + lane];
-    } else {
-        score<4, 0>(D, K, sh, m, d, sm, w.base, w.ng, f);
+            for (int g = 0; g < 4; ++g) {
+                const int c = w.base + 64 * g + lane;
+                f[g] = g < w.ng ? F[c < 255 ? c : 255] : 0.0;
+            }
+        } else {
+            score_binned<4, 0>(D, K, sh, m, d, sm, w.base, w.ng, f);
+            if (threadIdx.x == 0) K.fver[task] = -1;  // (the D0 / E rows now belong to this state, not to the stored scores')
+        }
     }
     control_bookkeeping(D, K, task, env, s, m, f_of(f, w, a_i), y, A.hits, sm);
 
@@ -948,18 +1275,26 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
         int zeros;
         const int cst = first_mistake(f, w, y, c_from, c_to, &zeros);
         if (cst >= 0) {
-            if (m >= KB_SMALL_M || INLINE) {
-                // the first repair is prepared here: scores, range, the mistake and its kernel column
-                int slot = 0;
-                if (threadIdx.x == 0) {
+            // queued with its scores: large dictionaries from the front of the queue array (the repair rounds), small ones
+            // from its far end (update_small_kernel)
+            const bool large = m >= KB_SMALL_M || INLINE;
+            const int T = D.n_envs * D.S;
+            int slot = 0;
+            if (threadIdx.x == 0) {
+                if (large) {
                     slot = atomicAdd(&K.heavy[0], 1);
                     const int nbq = (m + 63) >> 6;
                     atomicAdd(&K.heavy[3], nbq * nbq);  // tiles of Kinv a repair of this learner walks (the rounds' gate)
+                } else {
+                    slot = T - 1 - atomicAdd(&K.heavy[2], 1);
                 }
-                slot = __builtin_amdgcn_readfirstlane(slot);
-                const int lane = threadIdx.x & 63;
+            }
+            slot = __builtin_amdgcn_readfirstlane(slot);
+            const int lane = threadIdx.x & 63;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) K.hv_f[(size_t)slot * 256 + 64 * g + lane] = f[g];
+            for (int g = 0; g < 4; ++g) K.hv_f[(size_t)slot * 256 + 64 * g + lane] = f[g];
+            if (large) {
+                // the first repair is prepared here: range, the mistake and its kernel column
                 kernel_column_from_d0(D, K, sh, m, d, (double)cst / (double)n);
                 if (threadIdx.x == 0) {
                     K.heavy[4 + slot] = task;
@@ -970,9 +1305,8 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
                     K.hv_grew[slot] = 0;
                     K.hv_state[slot] = 1;
                 }
-            } else if (threadIdx.x == 0) {  // small dictionaries: from the far end of the same array
-                const int slot = atomicAdd(&K.heavy[2], 1);
-                K.heavy[4 + D.n_envs * D.S - 1 - slot] = task;
+            } else if (threadIdx.x == 0) {
+                K.heavy[4 + slot] = task;
             }
             flush_stats(K, task, dict, m, st);
             return;
@@ -989,48 +1323,15 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
     flush_stats(K, task, dict, m, st);
 }
 
-// The scoring pass of update_control_kernel for the LISTED learners (dictionaries of KB_BIG_M landmarks and more, the first
-// KB_BIG_MAX workgroups of the launch order): a workgroup of four waves per learner, one wave per group of 64 candidates
-// of the window -- a candidate's score does not depend on which others are computed with it, so these are the sums
-// score<4, 0> forms, at a quarter of the chain per wave.  Wave 0 leaves the D0 / E rows of the state as the one-wave
-// pass does.  update_control_kernel picks the scores up from bigf and goes on as ever.  Enqueued when most learners are
-// large (a 30-replica evaluation late in learning: 0.44 -> 0.2 ms per step); among 20,480 learners of which a fifth are
-// large it only delays the one-wave kernel (3.99 against 3.92 ms per step), and is not.
-__global__ __launch_bounds__(256) void detect_big_kernel(CtlArgs A, double* bigf) {
-    const KbDev& D = A.D;
-    const KbState& K = A.K;
-    __shared__ Lds sm;
-    const int task = learner_of_block(K, D.n_envs * D.S, A.big_par);  // (grid = KB_BIG_MAX: listed learners only)
-    if (task < 0) return;
-    const int env = task / D.S, s = task - env * D.S;
-    const int d = D.dims[s] + 1, n = D.n_prbs;
-    const int dict = dict_of(D, task);
-    const uint64_t* sh = shells_of(D, K, dict);
-    const int m = K.m[dict];
-    load_gtab(K, sm);
-    stage_state(D, A.state, env, s, d, sm);
-    __syncthreads();
-    const int a_i = A.action[env * D.S + s];
-    const int y = A.labels[env * D.S + s];
-    const Win w = window_of(y == 1 ? a_i : 0, y == 1 ? n : a_i);
-    const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double f1[1] = {0.0};
-    if (g < w.ng) {
-        if (g == 0) score<1, 0>(D, K, sh, m, d, sm, w.base, 1, f1);
-        else score<1, 2>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);
-    }
-    bigf[(size_t)blockIdx.x * 256 + 64 * g + lane] = g < w.ng ? f1[0] : 0.0;
-}
-
 // the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: a workgroup of four waves each, all at
 // once (update_small_kernel; workgroups beyond the queue leave at once); larger ones: the repair rounds below.
-__device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& sm) {
+__device__ __forceinline__ void repair_learner(const CtlArgs& A, int qslot, Lds& sm) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
+    const int task = K.heavy[4 + qslot];
     const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1, n = D.n_prbs;
     const int dict = dict_of(D, task);
-    const uint64_t* sh = shells_of(D, K, dict);
     int m = K.m[dict];
     stage_state(D, A.state, env, s, d, sm);
     __syncthreads();
@@ -1039,8 +1340,10 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int task, Lds& 
     LoopStats st = {0, 0, 0, 0};
     const int c_from = y == 1 ? a_i : 0, c_to = y == 1 ? n : a_i;
     const Win w = window_of(c_from, c_to);
-    double f[4];
-    rescore(D, K, sh, m, d, sm, w, f);  // the E row is the one update_control_kernel left for this state
+    double f[4];  // the window's scores as update_control_kernel had them (the D0 / E rows are this state's too)
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) f[g] = K.hv_f[(size_t)qslot * 256 + 64 * g + lane];
     m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, w, f, sm, st);
     flush_stats(K, task, dict, m, st);
 }
@@ -1056,7 +1359,7 @@ __global__ __launch_bounds__(256, KB_SMALL_OCC) void update_small_kernel(CtlArgs
     load_gtab(K, sm);
     for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
         __syncthreads();
-        repair_learner(A, K.heavy[4 + A.D.n_envs * A.D.S - 1 - slot], sm);
+        repair_learner(A, A.D.n_envs * A.D.S - 1 - slot, sm);
     }
 }
 
@@ -1088,7 +1391,7 @@ __global__ __launch_bounds__(1024) void heavy_plan_kernel(KbDev D, KbState K) {
             }
             if (K.hv_grew[slot] == 1) {
                 const long long nb1 = (K.hv_m[slot] + 1 + 63) >> 6;
-                wr1 = nb1 * nb1 * 4;
+                wr1 = (D.tri ? nb1 * (nb1 + 1) / 2 : nb1 * nb1) * 4;
             }
         }
         __syncthreads();
@@ -1148,7 +1451,12 @@ __global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
         // units whose first pass lies in [lo, hi)
         const long long a = lo > sb ? lo - sb : 0, b = (hi < se ? hi : se) - sb;
         const int u0 = (int)((a + nb - 1) / nb), u1 = (int)((b + nb - 1) / nb);
-        if (u0 < u1) matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
+        if (u0 < u1) {
+            if (D.tri)
+                matvec_tri_units(K, shells_of(D, K, dict), m, u0, 1, u1);
+            else
+                matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
+        }
         lo = se;
     }
 }
@@ -1164,7 +1472,7 @@ __global__ __launch_bounds__(256) void heavy_rank1_kernel(KbDev D, KbState K) {
         if (se <= lo) continue;
         const int dict = dict_of(D, K.heavy[4 + slot]);
         const int u0 = (int)(lo > sb ? lo - sb : 0), u1 = (int)((hi < se ? hi : se) - sb);
-        if (u0 < u1) rank1_units(K, shells_of(D, K, dict), K.hv_m[slot], K.hv_delta[slot], u0, 1, u1);
+        if (u0 < u1) rank1_units(K, shells_of(D, K, dict), K.hv_m[slot], K.hv_delta[slot], D.tri, u0, 1, u1);
         lo = se;
     }
 }
@@ -1195,7 +1503,10 @@ __global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
         const int cstar = K.hv_cstar[slot];
         LoopStats st = {(uint64_t)K.hv_pend[2 * slot], 1, 0, 0};
         if (threadIdx.x == 0 && K.hv_pend[2 * slot + 1] > 0) K.tie_ctr[task] += (uint32_t)K.hv_pend[2 * slot + 1];  // Q11
-        matvec_combine(K, sh, m);
+        if (D.tri)
+            matvec_tri_combine(K, sh, m);
+        else
+            matvec_combine(K, sh, m);
         int branch;
         double delta;
         bool saturated;
@@ -1386,6 +1697,147 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
         }
     }
     if (threadIdx.x == 0) {
+        const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
+        const int offset = K.security[env * D.S + s];
+        int act, margin = 0;
+        if (found >= 0) {
+            int a = n < found + offset ? n : found + offset;
+            margin = a - found;
+            act = a;
+        } else {
+            act = n;
+        }
+        K.action[env * D.S + s] = act;
+        K.margins[env * D.S + s] = margin;
+        uint64_t* st = K.stats + (size_t)task * 4;
+        st[0] += n_pred;
+        st[3] += n_scored * (uint64_t)m;
+    }
+}
+
+// ---- KBRL_Control.select_action for one agent per replica (kbrl_control.py:44-63), round 4: the scores of EVERY candidate
+// of sixteen learners at a time as one dense product on the matrix cores.  A workgroup is sixteen waves, a wave per learner:
+//   1. bin_pass      the wave walks its learner's landmarks once (the exp, the D0 / E rows of the state) and sums
+//                    coeff_j E_j per grid index into column `wave` of Wt[a][16] (LDS)
+//   2. F = T Wt      T[c][a] = G[|a - c|] (candidates x grid indices, the same Toeplitz matrix for every learner of the
+//                    handle: its 16 x 4 operand tiles are read straight out of the G table), Wt (grid indices x 16 learners):
+//                    wave ct forms the 16 candidates x 16 learners tile ct with (n_prbs + 4) / 4 v_mfma_f64_16x16x4 on one
+//                    accumulator -- per output the chain of fused multiply-adds over a = 0, 1, ... that chain_scores spells out
+//   3. the wave takes its learner's row of F back, adds the exact exponentials of the landmarks that could not be binned,
+//      leaves the row in K.F (update_control of this state starts from it) and scans it for the first accepted candidate,
+//      in order, exact ties drawing (kernel.py:26-27).
+// Per learner the cost is one pass over the landmarks plus 256 x 204 multiply-adds on the matrix pipe whatever m is; round 3
+// walked every landmark for every group of 64 candidates, here and again in update_control.
+struct SelLds {
+    double G2[512];
+    double Wt[256 * KB_SEL_WAVES];  // W[a][learner]
+    union {
+        int tag[KB_SEL_WAVES][256];         // bin_pass's claim tags, dead once W is complete
+        double Fs[KB_SEL_WAVES][256];       // F[learner][candidate]
+    };
+    double x[KB_SEL_WAVES][KB_DMAX];
+};
+
+__global__ __launch_bounds__(64 * KB_SEL_WAVES) void select_gemm_kernel(SelArgs A) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    __shared__ SelLds sm;
+    const int T = D.n_envs * D.S, n = D.n_prbs;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int task = learner_of_slot(K, T, A.big_par, (int)blockIdx.x * KB_SEL_WAVES + wv);
+    const int env = task >= 0 ? task / D.S : 0, s = task >= 0 ? task - env * D.S : 0;
+    const int d = D.dims[s] + 1;
+    const int dict = task >= 0 ? dict_of(D, task) : 0;
+    const uint64_t* sh = shells_of(D, K, dict);
+    const int m = task >= 0 ? K.m[dict] : 0;
+    if (task >= 0 && A.big_par >= 0 && lane == 0) {  // the next step's list (the other of the two)
+        const int pw = 1 - A.big_par;
+        int listed = 0;
+        if (m >= KB_BIG_M) {
+            int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
+            const int slot = atomicAdd(&L[0], 1);
+            if (slot < KB_BIG_MAX) {
+                L[1 + slot] = task;
+                listed = 1;
+            }
+        }
+        K.isbig[(size_t)pw * T + task] = listed;
+    }
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) sm.G2[k] = K.gtab[k < 256 ? 256 - k : k - 256];
+    for (int k = threadIdx.x; k < 256 * KB_SEL_WAVES; k += blockDim.x) sm.Wt[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sm.tag[wv][lane + 64 * k] = 64;
+    if (task >= 0 && lane < d - 1) sm.x[wv][lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
+    __syncthreads();
+    bool any_direct = false;
+    if (task >= 0 && m >= 2) any_direct = bin_pass<0>(D, K, sh, m, d, sm.x[wv], sm.Wt + wv, KB_SEL_WAVES, sm.tag[wv]);
+    __syncthreads();
+    // ---- F = T Wt: wave ct owns the candidates 16 ct .. 16 ct + 15 of all sixteen learners
+    const int nt = n / 16 + 1, KA = (n + 4) & ~3;
+    const int li = lane & 15, kq = lane >> 4;
+    kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+    if (wv < nt) {
+        const double* Ga = sm.G2 + 256 + kq - (16 * wv + li);  // A operand: T[16 ct + li][a0 + kq] = G2[256 + a - c]
+        const double* Wb = sm.Wt + kq * KB_SEL_WAVES + li;     // B operand: Wt[a0 + kq][learner li]
+        for (int a0 = 0; a0 < KA; a0 += 8) {
+            const double ta0 = Ga[a0], tb0 = Wb[(size_t)a0 * KB_SEL_WAVES];
+            const bool two = a0 + 4 < KA;
+            const double ta1 = two ? Ga[a0 + 4] : 0.0, tb1 = two ? Wb[(size_t)(a0 + 4) * KB_SEL_WAVES] : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, tb0, acc, 0, 0, 0);
+            if (two) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, tb1, acc, 0, 0, 0);
+        }
+    }
+    __syncthreads();  // (every wave is done with its tags: Fs takes their place)
+    if (wv < nt) {
+        // the lane holds F[candidate 16 ct + kq + 4 v][learner li]
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sm.Fs[li][16 * wv + kq + 4 * v] = acc[v];
+    }
+    __syncthreads();
+    if (task < 0) return;
+    double f[4];
+    if (m >= 2) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = 64 * g <= n ? sm.Fs[wv][64 * g + lane] : 0.0;
+        if (any_direct) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, f);
+    } else if (m == 1) {
+        score_single<4, 0>(D, K, sh, d, sm.x[wv], 0, f);
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = 0.0;
+    }
+    {
+        double* F = K.F + (size_t)task * 256;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) F[64 * g + lane] = f[g];
+        if (lane < d - 1) K.fstate[(size_t)task * 16 + lane] = A.state[(size_t)env * D.nv + D.off[s] + lane];
+        if (lane == 0) K.fver[task] = K.ver[dict];
+    }
+    // ---- the smallest candidate the classifier accepts, in order (kbrl_control.py:54-61)
+    int found = -1;
+    uint64_t n_scored = 0;
+    if (m > 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (64 * g <= n && found < 0) {
+                const int c = 64 * g + lane;
+                const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
+                n_scored += (uint64_t)(c1 - 64 * g + 1);
+                unsigned long long cand = __ballot(c <= n && f[g] >= 0.0);  // positive, or a tie to be drawn
+                while (cand) {  // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
+                    const int l = __builtin_ctzll(cand);
+                    const double fl = readlane_f64(f[g], l);
+                    if (fl > 0.0) { found = 64 * g + l; break; }
+                    int dr = 0;
+                    if (lane == 0) dr = tie_draw(K, task, env, s);
+                    dr = __builtin_amdgcn_readfirstlane(dr);
+                    if (dr == 1) { found = 64 * g + l; break; }
+                    cand &= cand - 1;
+                }
+            }
+        }
+    }
+    if (lane == 0) {
         const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
         const int offset = K.security[env * D.S + s];
         int act, margin = 0;
@@ -2336,7 +2788,9 @@ __global__ __launch_bounds__(256) void gather_learner_kernel(KbDev D, KbState K,
     if (kinv)
         for (size_t e = tid; e < (size_t)m * m; e += nt) {
             const int i = (int)(e / m), j = (int)(e - (size_t)i * m);
-            kinv[e] = kinv_tile(K, sh, i >> 6, j >> 6)[(i & 63) * 64 + (j & 63)];
+            // (triangle storage: the upper block triangle is the lower one transposed)
+            kinv[e] = (D.tri && (j >> 6) > (i >> 6)) ? kinv_tile_lo(K, sh, j >> 6, i >> 6)[(j & 63) * 64 + (i & 63)]
+                                                     : kinv_tile(K, sh, i >> 6, j >> 6)[(i & 63) * 64 + (j & 63)];
         }
 }
 
