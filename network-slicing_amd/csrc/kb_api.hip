@@ -279,6 +279,8 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.F, D.shared ? 1 : T * 256, true);
     KA(K.fstate, D.shared ? 1 : T * 16, true);
     KA(K.fver, T, true);
+    KA(K.Wg, D.shared ? 1 : T * 256, true);
+    KA(K.fdirect, T, true);
     KA(K.ver, ND, true);
     KA(K.workq, D.shared ? (size_t)cfg->n_slices * 16 * kb::kb_capr(cfg->capacity) * 16 : 1, true);
     KA(K.workF, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N * 256 : 1, true);
@@ -483,10 +485,11 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     if (a.gemm) launch_shared_gemm(k, d_state);
     if (k->D.shared) {
         hipLaunchKernelGGL(kb::select_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
-    } else {  // one agent per replica: sixteen learners per workgroup, their scores as one product on the matrix cores
+    } else {  // one agent per replica: a wave per learner bins its landmarks, then sixteen learners per workgroup are scored
+              // as one product on the matrix cores
         const unsigned slots = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
-        hipLaunchKernelGGL(kb::select_gemm_kernel, dim3((slots + KB_SEL_WAVES - 1) / KB_SEL_WAVES), dim3(64 * KB_SEL_WAVES), 0,
-                           k->stream, a);
+        hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a);
+        hipLaunchKernelGGL(kb::select_gemm_kernel, dim3((slots + KB_SEL_WAVES - 1) / KB_SEL_WAVES), dim3(256), 0, k->stream, a);
     }
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,

@@ -136,6 +136,8 @@ struct KbState {
     float* fstate;     // [T][16] the state F was computed for
     int32_t* fver;     // [T] K.ver[dict] when F was computed (-1: none)
     int32_t* ver;      // [ND] bumped by every Projectron.update that changed the dictionary (finish_update)
+    double* Wg;        // [T][256] W[a] of select_action's state, from select_bin_kernel to select_gemm_kernel
+    int32_t* fdirect;  // [T] the learner has landmarks that take the direct evaluation for that state
     double* workq;     // shared mode: [S][16][capr][16] Q[j][c] = coeff_j G[|a_j - c|] in MFMA B-operand tiles (shared_q_kernel)
     double* workF;     // shared mode: [S][KB_GEMM_KS][n_envs][256] partial scores F = E Q (shared_fgemm_kernel)
     double* workE;     // shared mode: [S][KB_GEMM_KS][n_envs] largest E_j a replica met in its part of the landmarks
@@ -207,7 +209,6 @@ struct Lds {
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
     double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned)
-    int tag[256];      //   and its per-bin claim tags (bin_pass)
     int ired[8];
 };
 
@@ -448,8 +449,8 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // dense product T W, T[c][a] = G[|a - c|] the same for every learner of the handle: select_gemm_kernel forms it for
 // sixteen learners at a time on the matrix cores (v_mfma_f64_16x16x4, N = learners).  The order of both sums is fixed so
 // that every kernel produces the same bits:
-//   * W[a] takes its landmarks in increasing j (bin_pass: a chunk's lanes that share a bin claim it in lane order
-//     through an integer ds_min tag -- no floating-point atomic whose order the hardware would choose);
+//   * W[a] takes its landmarks in increasing j (bin_pass: one wave, chunk after chunk, a chunk's lanes with one ds_add_f64
+//     that the LDS resolves in lane order -- measured, see bin_pass);
 //   * f(c) is ONE chain of fused multiply-adds over a = 0, 1, ..., KA - 1 (KA = n_prbs + 1 rounded up to four) starting
 //     from zero -- which is what consecutive v_mfma_f64_16x16x4 on one accumulator compute (tools/experiments/mfma_order.hip)
 //     and what chain_scores spells out on the vector ALU;
@@ -458,12 +459,16 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // The reference's k @ coeff is a BLAS dot in no particular order (kernel.py:24); like score_pass's table form these
 // sums agree with it to a few ulp of sum |coeff_j k_j| (tests: f within 1e-9 (1 + sum |w|), every decision exact).
 
-// W[a * wstride] += coeff_j E_j over the dictionary, by ONE wave, for the state x.  MODE 0: D0 / E are computed and left in
-// the dictionary's rows; MODE 1: the E row is reused.  W zeroed and tag[] = 64 on entry (tag[] = 64 again on return).
+// W[a] += coeff_j E_j over the dictionary, by ONE wave, for the state x.  MODE 0: D0 / E are computed and left in the
+// dictionary's rows; MODE 1: the E row is reused.  W (LDS, 256 doubles) zeroed on entry.  The lanes of a chunk add their
+// terms with ONE ds_add_f64: the LDS resolves the lanes of an instruction that hit the same address in increasing lane
+// order (tools/experiments/lds_add_order.hip, profiles/r04_lds_add_order.txt: 4,194,304 of 4,194,304 bins bit for bit the
+// lane-ordered sum, sixteen waves of a CU at it together, three launches identical), and the LDS executes a wave's
+// instructions in order -- so every W[a] is the sum over its landmarks in increasing j, on every run and in every kernel.
 // Returns whether any landmark takes the direct evaluation.
 template <int MODE>
 __device__ __forceinline__ bool bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
-                                         volatile double* W, int wstride, volatile int* tag) {
+                                         double* W) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
     bool any_direct = false;
@@ -494,27 +499,15 @@ __device__ __forceinline__ bool bin_pass(const KbDev& D, const KbState& K, const
         const bool direct = lane < cnt && (R.a < 0 || (!(E >= KB_E_TINY) && E > 0.0));
         any_direct = any_direct || __ballot(direct) != 0ull;
         const double w = R.co * E;
-        const int a = R.a;
-        // every lane with a term claims its bin with its lane number; the lowest lane of a bin adds, releases the bin and
-        // leaves; the others come round again: landmarks enter W[a] in increasing j whatever the chunk looks like
-        bool pend = lane < cnt && !direct && a >= 0 && w != 0.0;
-        while (__ballot(pend)) {
-            if (pend) atomicMin((int*)tag + a, lane);
-            const int t = pend ? tag[a] : -1;
-            if (pend && t == lane) {
-                W[a * wstride] = W[a * wstride] + w;
-                tag[a] = 64;
-                pend = false;
-            }
-        }
+        if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(W + R.a, w);  // ds_add_f64
     }
     return any_direct;
 }
 
 // f[g] = sum_a G[|a - c|] W[a], c = c_base + 64 g + lane: one chain of fused multiply-adds over a = 0 .. KA - 1 per candidate
 template <int NG>
-__device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, const volatile double* W, int wstride, int c_base,
-                                             int ng, double (&f)[NG]) {
+__device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, const volatile double* W, int c_base, int ng,
+                                             double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     const int KA = (D.n_prbs + 4) & ~3;
     int cs[NG];
@@ -527,7 +520,7 @@ __device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, c
     for (int a0 = 0; a0 < KA; a0 += 4) {
         double wv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) wv[u] = W[(a0 + u) * wstride];
+        for (int u = 0; u < 4; ++u) wv[u] = W[a0 + u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
@@ -585,12 +578,9 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
     } else {
         const int lane = threadIdx.x & 63;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            sm.W[lane + 64 * k] = 0.0;
-            sm.tag[lane + 64 * k] = 64;
-        }
-        const bool any_direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, 1, sm.tag);
-        chain_scores<NG>(D, sm.G2, sm.W, 1, c_base, ng, f);
+        for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
+        const bool any_direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W);
+        chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
         if (any_direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, f);
     }
 }
@@ -1123,22 +1113,19 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         __syncthreads();
         if (threadIdx.x < 64) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                sm.W[lane + 64 * k] = 0.0;
-                sm.tag[lane + 64 * k] = 64;
-            }
-            const bool any = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, 1, sm.tag);
+            for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
+            const bool any = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W);
             if (lane == 0) sm.ired[4] = any ? 1 : 0;
         }
         __syncthreads();
         const bool any_direct = sm.ired[4] != 0;
         if (blockDim.x >= 256) {
             if (g < w.ng) {
-                chain_scores<1>(D, sm.G2, sm.W, 1, w.base + 64 * g, 1, f1);
+                chain_scores<1>(D, sm.G2, sm.W, w.base + 64 * g, 1, f1);
                 if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, f1);
             }
         } else if (threadIdx.x < 64) {
-            chain_scores<4>(D, sm.G2, sm.W, 1, w.base, w.ng, f);
+            chain_scores<4>(D, sm.G2, sm.W, w.base, w.ng, f);
             if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, f);
         }
     } else if (blockDim.x >= 256) {
@@ -1716,41 +1703,33 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 }
 
 // ---- KBRL_Control.select_action for one agent per replica (kbrl_control.py:44-63), round 4: the scores of EVERY candidate
-// of sixteen learners at a time as one dense product on the matrix cores.  A workgroup is sixteen waves, a wave per learner:
-//   1. bin_pass      the wave walks its learner's landmarks once (the exp, the D0 / E rows of the state) and sums
-//                    coeff_j E_j per grid index into column `wave` of Wt[a][16] (LDS)
-//   2. F = T Wt      T[c][a] = G[|a - c|] (candidates x grid indices, the same Toeplitz matrix for every learner of the
-//                    handle: its 16 x 4 operand tiles are read straight out of the G table), Wt (grid indices x 16 learners):
-//                    wave ct forms the 16 candidates x 16 learners tile ct with (n_prbs + 4) / 4 v_mfma_f64_16x16x4 on one
-//                    accumulator -- per output the chain of fused multiply-adds over a = 0, 1, ... that chain_scores spells out
-//   3. the wave takes its learner's row of F back, adds the exact exponentials of the landmarks that could not be binned,
-//      leaves the row in K.F (update_control of this state starts from it) and scans it for the first accepted candidate,
-//      in order, exact ties drawing (kernel.py:26-27).
-// Per learner the cost is one pass over the landmarks plus 256 x 204 multiply-adds on the matrix pipe whatever m is; round 3
-// walked every landmark for every group of 64 candidates, here and again in update_control.
-struct SelLds {
-    double G2[512];
-    double Wt[256 * KB_SEL_WAVES];  // W[a][learner]
-    union {
-        int tag[KB_SEL_WAVES][256];         // bin_pass's claim tags, dead once W is complete
-        double Fs[KB_SEL_WAVES][256];       // F[learner][candidate]
-    };
-    double x[KB_SEL_WAVES][KB_DMAX];
-};
-
-__global__ __launch_bounds__(64 * KB_SEL_WAVES) void select_gemm_kernel(SelArgs A) {
+// as a dense product on the matrix cores, sixteen learners at a time.
+//   select_bin_kernel   a wave per learner walks its landmarks once (the exp, the D0 / E rows of the state) and sums
+//                       coeff_j E_j per grid index: W[learner][a] (bin_pass)
+//   select_gemm_kernel  F = T W^T for sixteen learners per workgroup: T[c][a] = G[|a - c|] (candidates x grid indices) is the
+//                       same Toeplitz matrix for every learner of the handle -- its 16 x 4 operand tiles are read straight
+//                       out of the G table --, W^T (grid indices x 16 learners) comes through LDS.  A wave owns up to four
+//                       16-candidate tiles (four independent accumulators, one B operand read for four v_mfma_f64_16x16x4);
+//                       per output this is the chain of fused multiply-adds over a = 0, 1, ... that chain_scores spells
+//                       out.  Then every learner's row of F gets the exact exponentials of the landmarks that could not be
+//                       binned, is left in K.F (update_control of this state starts from it) and is scanned for the first
+//                       accepted candidate, in order, exact ties drawing (kernel.py:26-27).
+// Per learner: one pass over the landmarks plus 208 x 204 multiply-adds on the matrix pipe, whatever m is.  Round 3 walked
+// every landmark for every group of 64 candidates, here and again in update_control.
+__global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    __shared__ SelLds sm;
-    const int T = D.n_envs * D.S, n = D.n_prbs;
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int task = learner_of_slot(K, T, A.big_par, (int)blockIdx.x * KB_SEL_WAVES + wv);
-    const int env = task >= 0 ? task / D.S : 0, s = task >= 0 ? task - env * D.S : 0;
+    __shared__ double W[256];
+    __shared__ double x[KB_DMAX];
+    const int T = D.n_envs * D.S;
+    const int task = learner_of_block(K, T, A.big_par);
+    if (task < 0) return;
+    const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1;
-    const int dict = task >= 0 ? dict_of(D, task) : 0;
-    const uint64_t* sh = shells_of(D, K, dict);
-    const int m = task >= 0 ? K.m[dict] : 0;
-    if (task >= 0 && A.big_par >= 0 && lane == 0) {  // the next step's list (the other of the two)
+    const int dict = dict_of(D, task);
+    const int m = K.m[dict];
+    const int lane = threadIdx.x;
+    if (A.big_par >= 0 && lane == 0) {  // the next step's list (the other of the two)
         const int pw = 1 - A.big_par;
         int listed = 0;
         if (m >= KB_BIG_M) {
@@ -1763,96 +1742,161 @@ __global__ __launch_bounds__(64 * KB_SEL_WAVES) void select_gemm_kernel(SelArgs 
         }
         K.isbig[(size_t)pw * T + task] = listed;
     }
-    for (int k = threadIdx.x; k < 512; k += blockDim.x) sm.G2[k] = K.gtab[k < 256 ? 256 - k : k - 256];
-    for (int k = threadIdx.x; k < 256 * KB_SEL_WAVES; k += blockDim.x) sm.Wt[k] = 0.0;
+    if (m < 2) {  // (nothing to bin: select_gemm_kernel scores the single landmark in float32, kernel.py:16)
+        if (lane == 0) K.fdirect[task] = 0;
+        return;
+    }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sm.tag[wv][lane + 64 * k] = 64;
-    if (task >= 0 && lane < d - 1) sm.x[wv][lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
+    for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
+    if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    bool any_direct = false;
-    if (task >= 0 && m >= 2) any_direct = bin_pass<0>(D, K, sh, m, d, sm.x[wv], sm.Wt + wv, KB_SEL_WAVES, sm.tag[wv]);
+    const bool any_direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W);
     __syncthreads();
-    // ---- F = T Wt: wave ct owns the candidates 16 ct .. 16 ct + 15 of all sixteen learners
+    double* Wg = K.Wg + (size_t)task * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Wg[lane + 64 * k] = W[lane + 64 * k];
+    if (lane == 0) K.fdirect[task] = any_direct ? 1 : 0;
+}
+
+#define KB_WT_LD 17  // doubles between the rows of W^T in LDS (16 learners + 1: the transposing stores spread over the banks)
+struct GemmLds {
+    double G2[512];
+    union {
+        double Wt[256 * KB_WT_LD];          // W^T[a][learner]
+        double Fs[KB_SEL_WAVES][256];       // F[learner][candidate], once every wave is done with W^T
+    };
+    int task[KB_SEL_WAVES], m[KB_SEL_WAVES];
+};
+
+__global__ __launch_bounds__(256) void select_gemm_kernel(SelArgs A) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    __shared__ GemmLds sm;
+    const int T = D.n_envs * D.S, n = D.n_prbs;
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (threadIdx.x < KB_SEL_WAVES) {
+        const int t = learner_of_slot(K, T, A.big_par, (int)blockIdx.x * KB_SEL_WAVES + (int)threadIdx.x);
+        sm.task[threadIdx.x] = t;
+        sm.m[threadIdx.x] = t >= 0 ? K.m[dict_of(D, t)] : 0;
+    }
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) sm.G2[k] = K.gtab[k < 256 ? 256 - k : k - 256];
+    __syncthreads();
+    // ---- W^T of the block's sixteen learners (wave w brings learners 4 w .. 4 w + 3; a learner without a W is a zero column)
+    {
+        double v[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = 4 * wv + q;
+            const bool on = sm.task[l] >= 0 && sm.m[l] >= 2;
+            const double* Wg = K.Wg + (size_t)(on ? sm.task[l] : 0) * 256;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[q][k] = on ? Wg[lane + 64 * k] : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sm.Wt[(lane + 64 * k) * KB_WT_LD + 4 * wv + q] = v[q][k];
+    }
+    __syncthreads();
+    // ---- F = T W^T: wave w owns the candidate tiles w, w + 4, w + 8, w + 12 (16 candidates each) of all sixteen learners
     const int nt = n / 16 + 1, KA = (n + 4) & ~3;
     const int li = lane & 15, kq = lane >> 4;
-    kb_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-    if (wv < nt) {
-        const double* Ga = sm.G2 + 256 + kq - (16 * wv + li);  // A operand: T[16 ct + li][a0 + kq] = G2[256 + a - c]
-        const double* Wb = sm.Wt + kq * KB_SEL_WAVES + li;     // B operand: Wt[a0 + kq][learner li]
-        for (int a0 = 0; a0 < KA; a0 += 8) {
-            const double ta0 = Ga[a0], tb0 = Wb[(size_t)a0 * KB_SEL_WAVES];
-            const bool two = a0 + 4 < KA;
-            const double ta1 = two ? Ga[a0 + 4] : 0.0, tb1 = two ? Wb[(size_t)(a0 + 4) * KB_SEL_WAVES] : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta0, tb0, acc, 0, 0, 0);
-            if (two) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ta1, tb1, acc, 0, 0, 0);
+    kb_f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (kb_f64x4){0.0, 0.0, 0.0, 0.0};
+    {
+        const double* Wb = sm.Wt + kq * KB_WT_LD + li;      // B operand: W^T[a0 + kq][learner li]
+        const double* Ga = sm.G2 + 256 + kq - (16 * wv + li);  // A operand of tile t: T[16 (w + 4 t) + li][a0 + kq] = G2[256 + a - c]
+        for (int a0 = 0; a0 < KA; a0 += 4) {
+            const double b = Wb[a0 * KB_WT_LD];
+            double ta[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) ta[t] = wv + 4 * t < nt ? Ga[a0 - 64 * t] : 0.0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                if (wv + 4 * t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], b, acc[t], 0, 0, 0);
         }
     }
-    __syncthreads();  // (every wave is done with its tags: Fs takes their place)
-    if (wv < nt) {
-        // the lane holds F[candidate 16 ct + kq + 4 v][learner li]
+    __syncthreads();  // (every wave is done with W^T: F takes its place)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) sm.Fs[li][16 * wv + kq + 4 * v] = acc[v];
+    for (int t = 0; t < 4; ++t) {
+        if (wv + 4 * t < nt) {
+            // the lane holds F[candidate 16 (w + 4 t) + kq + 4 v][learner li]
+#pragma unroll
+            for (int v = 0; v < 4; ++v) sm.Fs[li][16 * (wv + 4 * t) + kq + 4 * v] = acc[t][v];
+        }
     }
     __syncthreads();
-    if (task < 0) return;
-    double f[4];
-    if (m >= 2) {
+    // ---- per learner: the row of F, the first accepted candidate (kbrl_control.py:54-61); wave w takes learners w, w + 4, ...
+    for (int l = wv; l < KB_SEL_WAVES; l += 4) {
+        const int task = sm.task[l];
+        if (task < 0) continue;
+        const int m = sm.m[l];
+        const int env = task / D.S, s = task - env * D.S;
+        const int d = D.dims[s] + 1;
+        const int dict = dict_of(D, task);
+        const uint64_t* sh = shells_of(D, K, dict);
+        const int offset = K.security[env * D.S + s];  // (needed at the very end: in flight meanwhile)
+        double f[4];
+        if (m >= 2) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) f[g] = 64 * g <= n ? sm.Fs[wv][64 * g + lane] : 0.0;
-        if (any_direct) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, f);
-    } else if (m == 1) {
-        score_single<4, 0>(D, K, sh, d, sm.x[wv], 0, f);
-    } else {
+            for (int g = 0; g < 4; ++g) f[g] = 64 * g <= n ? sm.Fs[l][64 * g + lane] : 0.0;
+            if (K.fdirect[task]) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, f);
+        } else if (m == 1) {
+            double x[KB_DMAX];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) f[g] = 0.0;
-    }
-    {
-        double* F = K.F + (size_t)task * 256;
+            for (int q = 0; q < KB_DMAX - 1; ++q) x[q] = q < d - 1 ? (double)A.state[(size_t)env * D.nv + D.off[s] + q] : 0.0;
+            score_single<4, 0>(D, K, sh, d, x, 0, f);
+        } else {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) F[64 * g + lane] = f[g];
-        if (lane < d - 1) K.fstate[(size_t)task * 16 + lane] = A.state[(size_t)env * D.nv + D.off[s] + lane];
-        if (lane == 0) K.fver[task] = K.ver[dict];
-    }
-    // ---- the smallest candidate the classifier accepts, in order (kbrl_control.py:54-61)
-    int found = -1;
-    uint64_t n_scored = 0;
-    if (m > 0) {
+            for (int g = 0; g < 4; ++g) f[g] = 0.0;
+        }
+        {
+            double* F = K.F + (size_t)task * 256;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (64 * g <= n && found < 0) {
-                const int c = 64 * g + lane;
-                const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
-                n_scored += (uint64_t)(c1 - 64 * g + 1);
-                unsigned long long cand = __ballot(c <= n && f[g] >= 0.0);  // positive, or a tie to be drawn
-                while (cand) {  // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
-                    const int l = __builtin_ctzll(cand);
-                    const double fl = readlane_f64(f[g], l);
-                    if (fl > 0.0) { found = 64 * g + l; break; }
-                    int dr = 0;
-                    if (lane == 0) dr = tie_draw(K, task, env, s);
-                    dr = __builtin_amdgcn_readfirstlane(dr);
-                    if (dr == 1) { found = 64 * g + l; break; }
-                    cand &= cand - 1;
+            for (int g = 0; g < 4; ++g) F[64 * g + lane] = f[g];
+            if (lane < d - 1) K.fstate[(size_t)task * 16 + lane] = A.state[(size_t)env * D.nv + D.off[s] + lane];
+            if (lane == 0) K.fver[task] = K.ver[dict];
+        }
+        int found = -1;
+        uint64_t n_scored = 0;
+        if (m > 0) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (64 * g <= n && found < 0) {
+                    const int c = 64 * g + lane;
+                    const int c1 = 64 * g + 63 < n ? 64 * g + 63 : n;
+                    n_scored += (uint64_t)(c1 - 64 * g + 1);
+                    unsigned long long cand = __ballot(c <= n && f[g] >= 0.0);  // positive, or a tie to be drawn
+                    while (cand) {  // walk the (rare) exact ties in order; each consumes one draw (kernel.py:26-27)
+                        const int ll = __builtin_ctzll(cand);
+                        const double fl = readlane_f64(f[g], ll);
+                        if (fl > 0.0) { found = 64 * g + ll; break; }
+                        int dr = 0;
+                        if (lane == 0) dr = tie_draw(K, task, env, s);
+                        dr = __builtin_amdgcn_readfirstlane(dr);
+                        if (dr == 1) { found = 64 * g + ll; break; }
+                        cand &= cand - 1;
+                    }
                 }
             }
         }
-    }
-    if (lane == 0) {
-        const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
-        const int offset = K.security[env * D.S + s];
-        int act, margin = 0;
-        if (found >= 0) {
-            int a = n < found + offset ? n : found + offset;
-            margin = a - found;
-            act = a;
-        } else {
-            act = n;
+        if (lane == 0) {
+            const uint64_t n_pred = found >= 0 ? (uint64_t)found + 1 : (uint64_t)n + 1;
+            int act, margin = 0;
+            if (found >= 0) {
+                int a = n < found + offset ? n : found + offset;
+                margin = a - found;
+                act = a;
+            } else {
+                act = n;
+            }
+            K.action[env * D.S + s] = act;
+            K.margins[env * D.S + s] = margin;
+            unsigned long long* st = (unsigned long long*)(K.stats + (size_t)task * 4);
+            atomicAdd(&st[0], (unsigned long long)n_pred);  // (no return value: nothing waits for it)
+            atomicAdd(&st[3], (unsigned long long)(n_scored * (uint64_t)m));
         }
-        K.action[env * D.S + s] = act;
-        K.margins[env * D.S + s] = margin;
-        uint64_t* st = K.stats + (size_t)task * 4;
-        st[0] += n_pred;
-        st[3] += n_scored * (uint64_t)m;
     }
 }
 

@@ -602,8 +602,10 @@ def test_pool_grows_on_demand_and_reports_exhaustion():
     big = VecKBRL(4096, [10] * 5, 200, capacity=4096, pool_bytes=4 << 30)
     assert big.pool()['total_bytes'] <= 4 << 30
     big.close()
-    shell0 = (22 * 64 + 4096) * 8
-    ag = VecKBRL(2, [10], 200, capacity=65536, pool_bytes=2 * shell0 + 3 * (22 * 64 + 3 * 4096) * 8 // 2 + 4096)
+    def shell(b):   # bytes of shell b: the vector page (38 rows x 64) + the tiles (b, 0) .. (b, b) of Kinv's lower triangle
+        return (38 * 64 + (b + 1) * 4096) * 8
+    # room for shells 0, 1, 2 of one dictionary and 0, 1 of the other; shell 3 (147 KB) is larger than what two shells leave
+    ag = VecKBRL(2, [10], 200, capacity=65536, pool_bytes=64 * 8 + 2 * shell(0) + 2 * shell(1) + shell(2) + 4096)
     ag.reset([[10], [10]], [[3], [3]])
     assert ag.pool()['used_bytes'] == 64 * 8
     for i in range(len(xs)):
@@ -611,7 +613,16 @@ def test_pool_grows_on_demand_and_reports_exhaustion():
         ag.update(0, 0, xs[i], int(ys[i]))
     p = ag.pool()
     m = ag.dictionary_sizes()[0, 0]
-    assert m == 128 and p['pool_full'] == 1 and p['saturated'] == 1, (m, p)   # shells 0 and 1 fit, shell 2 does not
+    assert m == 192 and p['pool_full'] == 1 and p['saturated'] == 1, (m, p)   # shells 0, 1, 2 fit, shell 3 does not
+    # the request that did not fit left the pool as it was (the top only moves when a shell is granted): the
+    # other dictionary still finds room for its shells 0 and 1
+    assert p['used_bytes'] == 64 * 8 + shell(0) + shell(1) + shell(2), p
+    for i in range(len(xs)):
+        ag.predict(1, 0, xs[i])
+        ag.update(1, 0, xs[i], int(ys[i]))
+    p = ag.pool()
+    assert ag.dictionary_sizes()[1, 0] == 128 and p['used_bytes'] == 64 * 8 + 2 * shell(0) + 2 * shell(1) + shell(2), p
+    assert p['pool_full'] == 2
     ag.synchronize()
     with pytest.raises(_lib.RanSliceError):
         VecKBRL(64, [10] * 5, 200, capacity=1024, pool_bytes=1 << 20)     # not even one shell per dictionary

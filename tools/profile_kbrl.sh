@@ -13,8 +13,8 @@ for W in 100 3000; do
   DB=$(find /tmp/kt_${TAG}_$W -name '*.db' | head -1)
   { echo "# rocprofv3 --kernel-trace --stats of: $CMD   (the summary covers the warm-up as well; see the last-200 lines)"
     echo "# the run's own line: $(cat /tmp/kt_${TAG}_$W.json)"
-    python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 200
-    for KN in 'void kb::update_control_kernel<false>' 'kb::update_small_kernel' 'kb::heavy_matvec_kernel' 'kb::heavy_finish_kernel' 'kb::heavy_rank1_kernel' 'kb::update_heavy_kernel' 'kb::select_kernel'; do
+    python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 200 --steps 200 --anchor kb::adjust_kernel
+    for KN in 'void kb::update_control_kernel<false>' 'kb::update_small_kernel' 'kb::heavy_matvec_kernel' 'kb::heavy_finish_kernel' 'kb::heavy_rank1_kernel' 'kb::update_heavy_kernel' 'kb::select_bin_kernel' 'kb::select_gemm_kernel'; do
       python - "$DB" "$KN" <<'PY'
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1])
@@ -23,8 +23,9 @@ if d:
     print('# last %d launches of %s (= the last 200 steps): mean %.0f ns (min %d, max %d)' % (len(d), sys.argv[2], sum(d) / len(d), min(d), max(d)))
 PY
     done; } > $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
-  head -12 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt; tail -4 $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt
+  grep -A30 'the last 200 steps' $OUT/${TAG}_kbrl_w${W}_kernel_trace.txt | head -34
 done
+[ -n "$KONLY" ] && exit 0   # KONLY=1: the kernel traces only
 PCMD="python tools/bench_kbrl.py --warmup 150 --steps 20"
 echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch over the last 20 launches of each kb:: kernel (steps 150-170 of learning: dictionaries of ~40 landmarks on average; counter collection costs ~20 ms per dispatch, so the late phase is not replayed under PMC)" > $OUT/${TAG}_kbrl_pmc.txt
 i=0
