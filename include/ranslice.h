@@ -292,11 +292,18 @@ int kb_get_sizes(kb_handle* k, int32_t* m);
 /* the dictionary pool: bytes in use / in total, replicas with a dictionary at its capacity, replicas that found the pool
  * exhausted (both keep learning by projection -- build-defined, the reference's SVvariable is unbounded; any may be NULL) */
 int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_bytes, int32_t* n_saturated, int32_t* n_pool_full);
+/* bytes behind the repair rounds of the large dictionaries since kb_reset (projectron.py:42 Kinv @ K_f, :54-58 the rank-1
+ * update), as their kernels count them: work[0] tile passes of the mat-vec kernel (4,096 bytes read each), work[1] units of
+ * the rank-1 kernel (8,192 bytes read + 8,192 written each), work[2] / work[3] launches of either that had work */
+int kb_get_repair_work(kb_handle* k, uint64_t work[4]);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
 /* the same per phase: ms[0] / n[0] the update phase (update_control_kernel and its repair kernels; shared mode: the scan
  * kernels), ms[1] / n[1] select_kernel */
 int kb_phase_times_ms(kb_handle* k, double ms[2], int64_t n[2]);
 int kb_set_kernel_timing(kb_handle* k, int enable);
+/* mean duration of one launch of the two kernels that stream Kinv in the repair rounds -- ms[0] / n[0] the mat-vec, ms[1] /
+ * n[1] the rank-1 update -- over the span the last kb_phase_times_ms call covered (for their HBM roofline) */
+int kb_repair_times_ms(kb_handle* k, double ms[2], int64_t n[2]);
 /* waits for the agent's stream and reports an internal error flag raised by any kernel since kb_reset (the
  * device-resident loop kb_step_resident does not check on its own); dictionaries at capacity are not errors (kb_get_pool) */
 int kb_synchronize(kb_handle* k);

@@ -51,8 +51,10 @@ struct kb_handle {
     bool is_reset = false;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    std::vector<int> ev_kind;  // 0 update phase, 1 select
+    std::vector<int> ev_kind;  // 0 update phase, 1 select, 2 one launch of heavy_matvec_kernel, 3 one of heavy_rank1_kernel
     size_t ev_used = 0;
+    double repair_ms[2] = {0.0, 0.0};  // mean launch of the two (kb_phase_times_ms computes them, kb_repair_times_ms hands them out)
+    int64_t repair_n[2] = {0, 0};
     std::string err;
 };
 
@@ -228,7 +230,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.heavy, T + 4, true);
     KA(K.hv_cfrom, T, true); KA(K.hv_cstar, T, true); KA(K.hv_state, T, true); KA(K.hv_grew, T, true); KA(K.hv_m, T, true);
     KA(K.hv_pend, 2 * T, true); KA(K.hv_delta, T, true); KA(K.hv_f, 256 * T, true);
-    KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true);
+    KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true); KA(K.hv_work, 4, true);
     KA(K.big, 2 * (1 + KB_BIG_MAX), true); KA(K.isbig, 2 * T, true);
     {
         // The pool every dictionary of the handle grows in (kb_kbrl.hip, "Storage").  Upper bound on what can ever be
@@ -362,6 +364,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.ver, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.fver, 0xFF, sizeof(int32_t) * T, k->stream));  // -1: no stored scores
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.hv_work, 0, sizeof(unsigned long long) * 4, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
@@ -459,10 +462,15 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         const bool rounds = k->rounds_always || (k->h_seen && *(volatile int32_t*)k->h_seen >= k->rounds_gate);
         if (rounds && k->heavy_rounds > 0) hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
         for (int r = 0; rounds && r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
+            hipEvent_t em, er;  // (with kb_set_kernel_timing: each launch of the two streaming kernels on its own, for their roofline)
+            if ((rc = kb_time_begin(k, &em, 2)) != RS_OK) return rc;
             hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
+            if (em) HIPCHK(k, hipEventRecord(em, k->stream));
             hipLaunchKernelGGL(kb::heavy_finish_kernel, dim3(1024), dim3(256), 0, k->stream, a);
             hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
+            if ((rc = kb_time_begin(k, &er, 3)) != RS_OK) return rc;
             hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
+            if (er) HIPCHK(k, hipEventRecord(er, k->stream));
         }
         hipLaunchKernelGGL(kb::update_heavy_kernel, dim3(blocks), dim3(KB_HEAVY_THREADS), 0, k->stream, a);
         hipLaunchKernelGGL(kb::heavy_reset_kernel, dim3(1), dim3(1), 0, k->stream, k->K, (volatile int32_t*)k->h_seen);
@@ -767,6 +775,18 @@ extern "C" int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_b
     return RS_OK;
 }
 
+// What the chip-wide repair rounds have streamed since kb_reset, counted by the kernels from their own work plan:
+// work[0] tile passes of heavy_matvec_kernel (eight rows of a 64 x 64 tile of Kinv: 4,096 bytes read each), work[1] units
+// of heavy_rank1_kernel (sixteen rows: 8,192 bytes read and 8,192 written each), work[2] / work[3] launches of the two
+// that had anything to do.  The algorithmic bytes of projectron.py:42 (Kinv @ K_f) and :54-58 (the rank-1 update).
+extern "C" int kb_get_repair_work(kb_handle* k, uint64_t work[4]) {
+    if (!k || !work) return RS_EINVAL;
+    HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipMemcpyAsync(work, k->K.hv_work, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    return RS_OK;
+}
+
 extern "C" int kb_set_kernel_timing(kb_handle* k, int enable) {
     if (!k) return RS_EINVAL;
     k->timing = enable != 0;
@@ -784,16 +804,32 @@ extern "C" int kb_phase_times_ms(kb_handle* k, double ms[2], int64_t n[2]) {
     if (!k || !ms || !n) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));
-    double tot[2] = {0.0, 0.0};
-    n[0] = n[1] = 0;
+    double tot[4] = {0.0, 0.0, 0.0, 0.0};
+    int64_t cnt[4] = {0, 0, 0, 0};
     for (size_t i = 0; i < k->ev_used; ++i) {
         float t = 0.f;
         HIPCHK(k, hipEventElapsedTime(&t, k->ev[i].first, k->ev[i].second));
         tot[k->ev_kind[i]] += t;
-        n[k->ev_kind[i]] += 1;
+        cnt[k->ev_kind[i]] += 1;
     }
-    for (int q = 0; q < 2; ++q) ms[q] = n[q] ? tot[q] / (double)n[q] : 0.0;
+    for (int q = 0; q < 2; ++q) {
+        n[q] = cnt[q];
+        ms[q] = cnt[q] ? tot[q] / (double)cnt[q] : 0.0;
+        k->repair_n[q] = cnt[2 + q];
+        k->repair_ms[q] = cnt[2 + q] ? tot[2 + q] / (double)cnt[2 + q] : 0.0;
+    }
     k->ev_used = 0;
+    return RS_OK;
+}
+
+// mean duration of ONE launch of heavy_matvec_kernel (ms[0], n[0] launches) and of heavy_rank1_kernel (ms[1], n[1]) over the
+// span the last kb_phase_times_ms / kb_kernel_time_ms call summed up (HIP events on the agent's stream, kb_set_kernel_timing)
+extern "C" int kb_repair_times_ms(kb_handle* k, double ms[2], int64_t n[2]) {
+    if (!k || !ms || !n) return RS_EINVAL;
+    for (int q = 0; q < 2; ++q) {
+        ms[q] = k->repair_ms[q];
+        n[q] = k->repair_n[q];
+    }
     return RS_OK;
 }
 

@@ -124,6 +124,8 @@ struct KbState {
     double* hv_delta;   // [T]
     long long* hv_mvbase;  // [T + 1] prefix sums of the mat-vec work of the pending learners (heavy_plan_kernel)
     long long* hv_r1base;  // [T + 1] prefix sums of the rank-1 work of the learners that inserted
+    unsigned long long* hv_work;  // [4] since kb_reset: tile passes of the chip-wide mat-vec kernel (8 rows x 512 B each), 16-row units of
+                                  // the rank-1 kernel (8 KB read + 8 KB written each), launches of either that had work
     double* hv_f;       // [T][256] the scores of the candidates
     // launch order of the one-wave kernels: learners with large dictionaries first (their waves are the long ones)
     int32_t* big;      // [2][1 + KB_BIG_MAX]: count, then the learners select_kernel found at KB_BIG_M landmarks or more
@@ -1426,6 +1428,10 @@ __device__ __forceinline__ int stretch_of(const long long* base, int count, long
 __global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
     const int count = K.heavy[0];
     if (count == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && K.hv_mvbase[count] > 0) {  // (the roofline's byte count: kb_get_repair_work)
+        K.hv_work[0] += (unsigned long long)K.hv_mvbase[count];
+        K.hv_work[2] += 1;
+    }
     long long lo, hi;
     int slot = stretch_of(K.hv_mvbase, count, &lo, &hi);
     if (slot < 0) return;
@@ -1451,6 +1457,10 @@ __global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
 __global__ __launch_bounds__(256) void heavy_rank1_kernel(KbDev D, KbState K) {
     const int count = K.heavy[0];
     if (count == 0) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && K.hv_r1base[count] > 0) {
+        K.hv_work[1] += (unsigned long long)K.hv_r1base[count];
+        K.hv_work[3] += 1;
+    }
     long long lo, hi;
     int slot = stretch_of(K.hv_r1base, count, &lo, &hi);
     if (slot < 0) return;

@@ -172,6 +172,14 @@ class VecKBRL:
         self._check(self.L.kb_get_pool(self.h, C.byref(u), C.byref(t), C.byref(ns), C.byref(nf)))
         return dict(used_bytes=u.value, total_bytes=t.value, saturated=ns.value, pool_full=nf.value)
 
+    def repair_work(self):
+        """bytes the chip-wide repair rounds streamed since reset: dict(matvec_bytes read, rank1_bytes read + written,
+        matvec_launches, rank1_launches) -- counted by the kernels from their work plan (kb_get_repair_work)"""
+        w = (C.c_uint64 * 4)()
+        self._check(self.L.kb_get_repair_work(self.h, w))
+        return dict(matvec_bytes=int(w[0]) * 4096, rank1_bytes=int(w[1]) * 16384, matvec_launches=int(w[2]),
+                    rank1_launches=int(w[3]))
+
     def set_kernel_timing(self, enable=True):
         self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))
 
@@ -186,7 +194,11 @@ class VecKBRL:
         ms = (C.c_double * 2)()
         n = (C.c_int64 * 2)()
         self._check(self.L.kb_phase_times_ms(self.h, ms, n))
-        return dict(update_ms=ms[0], select_ms=ms[1], n_update=n[0], n_select=n[1])
+        rm = (C.c_double * 2)()
+        rn = (C.c_int64 * 2)()
+        self._check(self.L.kb_repair_times_ms(self.h, rm, rn))
+        return dict(update_ms=ms[0], select_ms=ms[1], n_update=n[0], n_select=n[1],
+                    matvec_launch_ms=rm[0], rank1_launch_ms=rm[1], n_matvec=rn[0], n_rank1=rn[1])
 
     def synchronize(self):
         self._check(self.L.kb_synchronize(self.h))

@@ -478,19 +478,19 @@ def test_kbrl_control_long_golden(golden_dir, monkeypatch, name, min_m, heavy_m,
     ag.close()
 
 
-def _fast_growing_samples(n, seed=141):
-    """a stream on which the dictionary grows by about one landmark every five samples (states spread over [0, 1.6]^10,
+def _fast_growing_samples(n, seed=141, spread=1.6, revisit=0.5):
+    """a stream on which the dictionary grows by about one landmark every five samples (states spread over [0, spread]^10,
     noisy labels); every second sample revisits an earlier state with a new action, as sample augmentation does"""
     rng = np.random.default_rng(seed)
     xs, ys, states = [], [], []
     for i in range(n):
-        if states and rng.random() < 0.5:
+        if states and rng.random() < revisit:
             s = states[rng.integers(len(states))]
         else:
-            s = (rng.random(10) * 1.6).astype(np.float32)
+            s = (rng.random(10) * spread).astype(np.float32)
         states.append(s)
         x = np.append(s, rng.integers(0, 201) / 200)
-        score = x[:-1].mean() * 0.5 + 0.35 - x[-1]
+        score = x[:-1].mean() * 0.5 * 1.6 / spread + 0.35 - x[-1]
         ys.append(-1 if score + rng.normal(0, 0.15) > 0 else 1)
         xs.append(x)
     return np.asarray(xs), np.asarray(ys)
@@ -526,6 +526,96 @@ def test_projectron_through_saturation_at_capacity_1024():
     p = ag.pool()
     assert p['saturated'] == 1 and p['pool_full'] == 0
     ag.synchronize()          # a dictionary at its capacity is reported, not an error
+    ag.close()
+
+
+def test_projectron_to_3000_landmarks_vs_oracle():
+    """device vs oracle where long runs live.  One stream takes Projectron.predict / update to more than
+    3,000 landmarks at capacity 4,096 (shell indices up to 47, a Kinv of 9.4 M entries in 1,176 tiles of the lower block
+    triangle, 1 / delta conditioning of a dictionary that size): f within 1e-8, predicted sign / branch / dictionary size
+    exact at every sample, delta within 1e-6 relative (it is 1 - k.Kinv k: a difference of two numbers near one whose
+    Kinv entries have been through thousands of rank-1 updates in two different summation orders); final coefficients
+    1e-6, Kinv probes 1e-6 of its scale"""
+    from ranslice.kbrl_dev import VecKBRL
+    xs, ys = _fast_growing_samples(12400, spread=3.0, revisit=0.35)
+    cap = 4096
+    ag = VecKBRL(1, [10], 200, capacity=cap)
+    ag.reset([[10]], [[3]])
+    oa = po.OracleKBRL([10], 200, [10], [3], capacity=cap)
+    oa.set_seed(0)
+    n_proj_large = 0
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, 0, xs[i])
+        oyp, of = oa.predict(0, xs[i])
+        assert f == pytest.approx(of, rel=1e-8, abs=TOL), i
+        if abs(of) > 1e-7:
+            assert yp == oyp, i
+        br, dl = ag.update(0, 0, xs[i], int(ys[i]))
+        obr, odl = oa.update(0, xs[i], int(ys[i]))
+        assert br == obr, (i, br, obr, dl, odl)
+        if br:
+            assert dl == pytest.approx(odl, rel=1e-6, abs=1e-9), i
+            n_proj_large += int(br == 1 and oa.m(0) > 2000)
+    m = oa.m(0)
+    assert m >= 3000 and ag.dictionary_sizes()[0, 0] == m
+    assert n_proj_large > 20, 'projections onto a dictionary of more than 2,000 landmarks should be part of the stream'
+    L = ag.learner(0, 0, with_kinv=True)
+    np.testing.assert_array_equal(L['landmarks'], oa.landmarks(0))
+    np.testing.assert_allclose(L['coeff'], oa.coeff(0), rtol=1e-6, atol=1e-8)
+    ko = oa.kinv(0)
+    assert np.array_equal(L['kinv'], L['kinv'].T), 'Kinv is symmetric bit for bit (only its lower block triangle is stored)'
+    scale = np.abs(ko).max()
+    np.testing.assert_allclose(L['kinv'], ko, rtol=1e-6, atol=1e-6 * scale)
+    p = ag.pool()
+    # the triangle: shells 0 .. 47 hold 48 pages and 48 * 49 / 2 tiles
+    nb = (m + 63) // 64
+    assert p['used_bytes'] == 64 * 8 + (nb * 38 * 64 + nb * (nb + 1) // 2 * 4096) * 8, p
+    assert p['saturated'] == 0 and p['pool_full'] == 0
+    ag.close()
+
+
+@pytest.mark.parametrize('rounds', [None, 2])
+def test_control_with_dictionaries_above_1024_vs_oracle(golden_dir, monkeypatch, rounds):
+    """KBRL_Control on dictionaries of 1,300 to 1,900 landmarks: every learner of one agent (device and oracle alike) is first
+    grown through Projectron.predict / update on its own stream, then both take 120 control steps of G15's recorded
+    (state, action, labels): hits, selected actions, adjusted, margins, security factors and dictionary sizes agree at every
+    step.  rounds = 2 sends the repairs through the chip-wide rounds (heavy_matvec / heavy_finish / heavy_rank1 over the
+    triangle's tiles); None leaves them to the per-learner clean-up workgroups."""
+    from ranslice.kbrl_dev import VecKBRL
+    if rounds is not None:
+        monkeypatch.setenv('KBRL_ROUNDS', str(rounds))
+    g = _load(golden_dir, 'g15_kbrl_long_s0')
+    dims, n_prbs = _dims(0)
+    cap = 4096
+    ag = VecKBRL(1, dims, n_prbs, accuracy_range=tuple(g['a_range']), capacity=cap)
+    ag.reset(g['init_action'][None].astype(np.int32), g['init_sec'][None].astype(np.int32), seeds=np.zeros(1, dtype=np.uint64))
+    oa = po.OracleKBRL(dims, n_prbs, g['init_action'], g['init_sec'], accuracy_range=tuple(g['a_range']), capacity=cap)
+    oa.set_seed(0)
+    for s in range(len(dims)):
+        xs, ys = _fast_growing_samples(8000 + 800 * s, seed=300 + s, revisit=0.35)
+        for i in range(len(xs)):
+            ag.predict(0, s, xs[i])
+            ag.update(0, s, xs[i], int(ys[i]))
+            oa.predict(s, xs[i])
+            oa.update(s, xs[i], int(ys[i]))
+        assert ag.dictionary_sizes()[0, s] == oa.m(s) >= 1300, (s, oa.m(s))
+    steps, grown = 120, 0
+    m0 = [oa.m(s) for s in range(len(dims))]
+    for i in range(steps):
+        hits = ag.update_control(g['state'][i][None], g['action_in'][i][None], g['labels'][i][None])
+        oh = oa.update_control(g['state'][i], g['action_in'][i], g['labels'][i])
+        assert (hits[0] == oh).all(), i
+        act, adj = ag.select_action(g['state'][i + 1][None])
+        oact, oadj = oa.select_action(g['state'][i + 1])
+        oa.adjusted = oadj
+        assert (act[0] == oact).all() and adj[0] == oadj, i
+        c = ag.control(with_accuracies=False)
+        assert (c['margins'][0] == oa.margins).all() and (c['security_factors'][0] == oa.security_factors).all(), i
+        assert (ag.dictionary_sizes()[0] == [oa.m(s) for s in range(len(dims))]).all(), i
+    grown = sum(oa.m(s) - m0[s] for s in range(len(dims)))
+    assert grown > 20, 'the control steps should keep inserting into the large dictionaries'
+    for s in range(len(dims)):
+        np.testing.assert_allclose(ag.learner(0, s)['coeff'], oa.coeff(s), rtol=1e-6, atol=1e-8)
     ag.close()
 
 

@@ -57,6 +57,7 @@ def main():
     run(args.warmup)
     env.synchronize(); agent.synchronize()
     s0 = agent.stats()
+    w0 = agent.repair_work()
     c0 = env.counters()
     agent.set_kernel_timing(True)
     env.set_kernel_timing(True)
@@ -67,7 +68,21 @@ def main():
     s1 = agent.stats()
     c1 = env.counters()
     per = lambda i: float(c1[i] - c0[i]) / (N * args.steps)
-    kb_ms, kb_n = agent.kernel_time_ms()
+    ph = agent.phase_times_ms()
+    w1 = agent.repair_work()
+    kb_n = ph['n_update'] + ph['n_select']
+    kb_ms = (ph['update_ms'] * ph['n_update'] + ph['select_ms'] * ph['n_select']) / max(1, kb_n)
+
+    def roof(kind, ms_key, n_key):
+        # bytes from the kernels' own work plan over the time of ALL their launches in the window (HIP events; the later rounds
+        # of a step often find nothing left and return at once: they are in the time and in the count), against 8 TB/s
+        nw = w1[kind + '_launches'] - w0[kind + '_launches']
+        if not nw or not ph[ms_key]:
+            return None
+        total = w1[kind + '_bytes'] - w0[kind + '_bytes']
+        gbs = total / (ph[ms_key] * ph[n_key] * 1e-3) / 1e9
+        return {'bytes_per_step': total / args.steps, 'launch_ms_mean': ph[ms_key], 'launches_timed': ph[n_key], 'launches_with_work': nw,
+                'ms_per_step': ph[ms_key] * ph[n_key] / args.steps, 'achieved_GBs': gbs, 'frac_of_8TBs': gbs / 8000.0}
     env_ms, _ = env.kernel_time_ms()
     out = env.fetch()
     evals = s1[3] - s0[3]
@@ -84,6 +99,8 @@ def main():
         'mean_action_sum': float(out['actions'].sum(axis=1).mean()),
         'action_per_slice_p10_p50_p90_max': [float(np.percentile(out['actions'], q)) for q in (10, 50, 90, 100)],
         'step_workload_per_env_step': {'fading_samples': per(0), 'pf_iterations': per(2), 'ue_slots': per(3)},
+        'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
+        'kinv_streaming': {'heavy_matvec_kernel': roof('matvec', 'matvec_launch_ms', 'n_matvec'), 'heavy_rank1_kernel': roof('rank1', 'rank1_launch_ms', 'n_rank1')},
         'driver': 'random script' if args.random else 'KBRL agents',
         'violations_per_env_step_last': float(out['violations'].sum(axis=1).mean()),
     }))
