@@ -293,7 +293,7 @@ int kb_get_sizes(kb_handle* k, int32_t* m);
  * exhausted (both keep learning by projection -- build-defined, the reference's SVvariable is unbounded; any may be NULL) */
 int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_bytes, int32_t* n_saturated, int32_t* n_pool_full);
 /* bytes behind the repair rounds of the large dictionaries since kb_reset (projectron.py:42 Kinv @ K_f, :54-58 the rank-1
- * update), as their kernels count them: work[0] tile passes of the mat-vec kernel (4,096 bytes read each), work[1] units of
+ * update), as their kernels count them: work[0] tiles of Kinv the mat-vec kernel read (32,768 bytes each), work[1] units of
  * the rank-1 kernel (8,192 bytes read + 8,192 written each), work[2] / work[3] launches of either that had work */
 int kb_get_repair_work(kb_handle* k, uint64_t work[4]);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);

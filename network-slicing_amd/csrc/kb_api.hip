@@ -39,6 +39,7 @@ struct kb_handle {
     int comm_rank = 0, comm_world = 1;
     int budget_cap = 256;
     int heavy_blocks = 256;
+    int mv_grid = 2048, r1_grid = 2048;  // one co-resident round of workgroups of the two Kinv-streaming kernels (kb_create)
     int heavy_rounds = 3;
     int rounds_gate = 200;         // tiles of Kinv queued per step from which the rounds are enqueued (eight learners of 320 landmarks;
                                    // KBRL_ROUNDS_GATE)
@@ -251,7 +252,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         }
         const unsigned long long least = 64 + (unsigned long long)ND * kb::kb_shell_doubles(0, D.tri);
         if (want < least) {
-            k->err = "kb_create: the dictionary pool cannot hold even one shell (51 KB) per dictionary";
+            k->err = "kb_create: the dictionary pool cannot hold even one shell (48 KB) per dictionary";
             return RS_EINVAL;
         }
         D.pool_doubles = want;
@@ -307,6 +308,15 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         }
         if (lds > 48 * 1024)
             HIPCHK(k, hipFuncSetAttribute((const void*)kb::shared_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    }
+    {
+        // The two kernels that stream Kinv split their work line evenly over the waves of the launch: exactly one resident
+        // round of workgroups, so that no second, partly filled round trails the first (KBRL_STREAM_GRID overrides both)
+        int cus = 256, b1 = 0, b2 = 0;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kb::heavy_matvec_kernel, 256, 0) == hipSuccess && b1 > 0) k->mv_grid = b1 * cus;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, kb::heavy_rank1_kernel, 256, 0) == hipSuccess && b2 > 0) k->r1_grid = b2 * cus;
+        if (getenv("KBRL_STREAM_GRID")) k->mv_grid = k->r1_grid = atoi(getenv("KBRL_STREAM_GRID"));
     }
     hipLaunchKernelGGL(kb::kb_gtab_kernel, dim3((KB_GTAB + 255) / 256), dim3(256), 0, k->stream, k->D, k->K);
     HIPCHK(k, hipGetLastError());
@@ -464,12 +474,12 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         for (int r = 0; rounds && r < k->heavy_rounds; ++r) {  // one repair of every pending large learner per round, chip-wide
             hipEvent_t em, er;  // (with kb_set_kernel_timing: each launch of the two streaming kernels on its own, for their roofline)
             if ((rc = kb_time_begin(k, &em, 2)) != RS_OK) return rc;
-            hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
+            hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3((unsigned)k->mv_grid), dim3(256), 0, k->stream, k->D, k->K);
             if (em) HIPCHK(k, hipEventRecord(em, k->stream));
             hipLaunchKernelGGL(kb::heavy_finish_kernel, dim3(1024), dim3(256), 0, k->stream, a);
             hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
             if ((rc = kb_time_begin(k, &er, 3)) != RS_OK) return rc;
-            hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3(2048), dim3(256), 0, k->stream, k->D, k->K);
+            hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3((unsigned)k->r1_grid), dim3(256), 0, k->stream, k->D, k->K);
             if (er) HIPCHK(k, hipEventRecord(er, k->stream));
         }
         hipLaunchKernelGGL(kb::update_heavy_kernel, dim3(blocks), dim3(KB_HEAVY_THREADS), 0, k->stream, a);
@@ -776,7 +786,7 @@ extern "C" int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_b
 }
 
 // What the chip-wide repair rounds have streamed since kb_reset, counted by the kernels from their own work plan:
-// work[0] tile passes of heavy_matvec_kernel (eight rows of a 64 x 64 tile of Kinv: 4,096 bytes read each), work[1] units
+// work[0] tiles of Kinv heavy_matvec_kernel read (32,768 bytes each; 128 partial sums written per tile), work[1] units
 // of heavy_rank1_kernel (sixteen rows: 8,192 bytes read and 8,192 written each), work[2] / work[3] launches of the two
 // that had anything to do.  The algorithmic bytes of projectron.py:42 (Kinv @ K_f) and :54-58 (the rank-1 update).
 extern "C" int kb_get_repair_work(kb_handle* k, uint64_t work[4]) {

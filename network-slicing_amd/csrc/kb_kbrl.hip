@@ -9,14 +9,15 @@
 // a POOL shared by all dictionaries of the handle and grows 64 landmarks at a time, like the reference's np.vstack /
 // np.append / np.column_stack do one landmark at a time (projectron.py:17-21,52-57): when landmark 64 b arrives the
 // learner's own workgroup takes "shell" b from a bump allocator --
-//     [ vector page: 38 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
+//     [ vector page: 30 rows x 64 doubles ]  coordinates (16 rows, coordinate-major), coefficient, scratch rows
 //     [ b + 1 tiles of 64 x 64 doubles    ]  Kinv tiles (b,0) .. (b,b): the LOWER block triangle (round 4)
+//     [ b + 1 times 128 doubles           ]  the tiles' partial sums of d* = Kinv K_f (matvec_tri_tiles)
 // and records its pool offset in the dictionary's shell table.  Kinv is symmetric bit for bit (it only ever receives
 // (d_i d_j) / delta), so the upper block triangle is never stored: the rank-1 update streams half of what it did and
 // the pool holds twice the landmarks.  (Shared dictionaries -- five per handle -- keep both triangles, 2 b + 1 tiles per
 // shell, and the round-3 kernels that walk them: KbDev.tri = 0.)  Nothing is ever moved or freed before kb_reset, so
 // the capacity is bounded by the pool (device memory), not by a per-learner reservation: a handle of 4096 x 5
-// learners costs what its dictionaries hold (51 KB each while below 64 landmarks; round 2 reserved 8 MB each).
+// learners costs what its dictionaries hold (48 KB each while below 64 landmarks; round 2 reserved 8 MB each).
 //
 // Scoring.  Both hot loops of the agent -- the augmentation loop of update_control and the scan of select_action --
 // evaluate the classifier on candidates x_c = (state, c / n_prbs) that differ only in the last coordinate, and the
@@ -52,8 +53,7 @@ namespace kb {
 #define KB_ROW_DS 20      //   d* = Kinv K_f
 #define KB_ROW_IDX 21     //   64 x int32 grid index a_j of the last coordinate (-1: off the grid), 64 x int32 chain link
 #define KB_ROW_PART 22    //   8 rows: the partial sums of d* over the row classes j mod 8 (matvec_colsum)
-#define KB_ROW_PARTT 30   //   8 rows: the same over the rows whose tiles are stored transposed (triangle storage: matvec_tri_unit)
-#define KB_VEC_ROWS 38
+#define KB_VEC_ROWS 30
 #define KB_VEC (KB_VEC_ROWS * KB_CH)
 #ifndef KB_OCC
 #ifndef KB_SCORE_UNROLL1
@@ -139,7 +139,7 @@ struct KbState {
     int32_t* fver;     // [T] K.ver[dict] when F was computed (-1: none)
     int32_t* ver;      // [ND] bumped by every Projectron.update that changed the dictionary (finish_update)
     double* Wg;        // [T][256] W[a] of select_action's state, from select_bin_kernel to select_gemm_kernel
-    int32_t* fdirect;  // [T] the learner has landmarks that take the direct evaluation for that state
+    int32_t* fdirect;  // [T] bin_pass's flags: the learner has landmarks that take the direct evaluation for that state (1) / off the grid (2)
     double* workq;     // shared mode: [S][16][capr][16] Q[j][c] = coeff_j G[|a_j - c|] in MFMA B-operand tiles (shared_q_kernel)
     double* workF;     // shared mode: [S][KB_GEMM_KS][n_envs][256] partial scores F = E Q (shared_fgemm_kernel)
     double* workE;     // shared mode: [S][KB_GEMM_KS][n_envs] largest E_j a replica met in its part of the landmarks
@@ -155,8 +155,8 @@ __host__ __device__ inline int kb_capr(int cap) { return (cap + 63) & ~63; }
 __host__ __device__ inline size_t kb_apply_lds_doubles(int cap, int budget) {  // shared_apply_kernel's dynamic LDS
     return (size_t)kb_capr(cap) + 4 * (size_t)budget;
 }
-__host__ __device__ inline uint64_t kb_shell_doubles(int b, int tri) {
-    return (uint64_t)KB_VEC + (uint64_t)((tri ? b : 2 * b) + 1) * KB_TILE;
+__host__ __device__ inline uint64_t kb_shell_doubles(int b, int tri) {  // tri: b + 1 tiles and their 128 partial sums each
+    return (uint64_t)KB_VEC + (tri ? (uint64_t)(b + 1) * (KB_TILE + 128) : (uint64_t)(2 * b + 1) * KB_TILE);
 }
 
 __device__ __forceinline__ const uint64_t* shells_of(const KbDev& D, const KbState& K, int dict) {
@@ -467,13 +467,13 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // order (tools/experiments/lds_add_order.hip, profiles/r04_lds_add_order.txt: 4,194,304 of 4,194,304 bins bit for bit the
 // lane-ordered sum, sixteen waves of a CU at it together, three launches identical), and the LDS executes a wave's
 // instructions in order -- so every W[a] is the sum over its landmarks in increasing j, on every run and in every kernel.
-// Returns whether any landmark takes the direct evaluation.
+// Returns bit 0: some landmark takes the direct evaluation; bit 1: some landmark is off the candidate grid.
 template <int MODE>
-__device__ __forceinline__ bool bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
+__device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
                                          double* W) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
-    bool any_direct = false;
+    int flags = 0;
     ChunkRows<MODE> R, Rn;
     load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
     for (int b = 0; b < nch; ++b) {
@@ -498,12 +498,13 @@ __device__ __forceinline__ bool bin_pass(const KbDev& D, const KbState& K, const
             P[KB_ROW_D0 * KB_CH + lane] = d0;
             P[KB_ROW_E * KB_CH + lane] = E;
         }
-        const bool direct = lane < cnt && (R.a < 0 || (!(E >= KB_E_TINY) && E > 0.0));
-        any_direct = any_direct || __ballot(direct) != 0ull;
+        const bool offg = lane < cnt && R.a < 0;
+        const bool direct = offg || (lane < cnt && !(E >= KB_E_TINY) && E > 0.0);
+        flags |= (__ballot(direct) != 0ull ? 1 : 0) | (__ballot(offg) != 0ull ? 2 : 0);
         const double w = R.co * E;
         if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(W + R.a, w);  // ds_add_f64
     }
-    return any_direct;
+    return flags;
 }
 
 // f[g] = sum_a G[|a - c|] W[a], c = c_base + 64 g + lane: one chain of fused multiply-adds over a = 0 .. KA - 1 per candidate
@@ -532,19 +533,29 @@ __device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, c
     }
 }
 
-// the landmarks bin_pass left out (off the grid, or E_j below KB_E_TINY) add coeff_j exp(-gamma (D0_j + (l_j - c/n)^2)), in
-// increasing j (D0 / E are in the dictionary's rows)
+// The landmarks bin_pass left out (off the grid, or E_j below KB_E_TINY) add coeff_j exp(-gamma (D0_j + (l_j - c/n)^2)), in
+// increasing j (D0 / E are in the dictionary's rows).  With off_grid == false the left-out terms are all below
+// |coeff_j| 1e-280 in magnitude, and a candidate whose binned sum already stands at 1e-240 or more keeps it: the terms could
+// not move its sign, nor its value by more than one part in 1e30 (65,536 landmarks with coefficients of a thousand sum to
+// 1e-272) -- only a candidate whose binned sum is (next to) nothing, the reference's f == 0 ties of an outlier state
+// (kernel.py:26-27), needs them, and then it needs them exactly.  The rule looks at the candidate's own binned sum only, so
+// it is the same in every kernel.
+#define KB_F_SETTLED 1e-240
 template <int NG>
 __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, int c_base, int ng,
-                                                 double (&f)[NG]) {
+                                                 bool off_grid, double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
     double tc[NG];
+    bool open_[NG], any = false;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         const int c = c_base + 64 * g + lane;
         tc[g] = (double)(c < D.n_prbs ? c : D.n_prbs) / (double)D.n_prbs;
+        open_[g] = g < ng && (off_grid || !(__builtin_fabs(f[g]) >= KB_F_SETTLED));
+        any = any || open_[g];
     }
+    if (!__ballot(any)) return;
     for (int b = 0; b < nch; ++b) {
         const double* P = vec_page(K, sh, b);
         const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
@@ -559,9 +570,10 @@ __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& 
             const double cs = readlane_f64(co, jj), ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g < ng) {
+                if (__ballot(open_[g])) {
                     const double dl = ls - tc[g];
-                    f[g] = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
+                    const double v = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
+                    f[g] = open_[g] ? v : f[g];
                 }
             }
         }
@@ -581,9 +593,9 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-        const bool any_direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W);
+        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W);
         chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
-        if (any_direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, f);
+        if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, (direct & 2) != 0, f);
     }
 }
 
@@ -726,85 +738,6 @@ __device__ __forceinline__ void matvec_colsum(const KbState& K, const uint64_t* 
     matvec_combine(K, sh, m);
 }
 
-// ---- triangle storage (KbDev.tri): d* = Kinv K_f when only the tiles (b_i, b_j), b_j <= b_i, exist.
-// Output i = 64 bo + c sums Kinv[j][i] K_f[j] over all rows j.  Rows in the blocks br >= bo come from tile (br, bo), walked
-// down column c as ever (lane = column, coalesced rows).  Rows in the blocks br < bo are Kinv[i][j] by symmetry: row c of
-// tile (bo, br), walked ALONG the row.  A lane-per-column walk of that would touch 64 cache lines per load instruction,
-// so the wave is dealt differently there: lane = (column c = 8 x + (lane >> 3), row class sg = lane & 7) reads
-// T[c][sg + 8 k] -- the eight lanes of a column read 64 consecutive bytes, one load instruction covers eight 64-byte
-// segments, and the eight units of a column block still fetch each tile once between them.  The sum keeps ONE shape in
-// every kernel: per output sixteen partial sums, eight over the rows j = sg (mod 8) of the blocks br >= bo (increasing j,
-// fused multiply-adds: PART rows) and eight over those of the blocks br < bo (PARTT rows), then
-// ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)) of each eight and the sum of the two.
-// A work unit (bo, x), x = 0..7, is the direct part of row class x plus the transposed part of the columns 8 x .. 8 x + 7:
-// (nb - bo) + bo = nb tile passes of eight loads whatever bo is (heavy_plan_kernel's work line counts on that).
-__device__ __forceinline__ void matvec_tri_units(const KbState& K, const uint64_t* sh, int m, int u0, int ustride,
-                                                 int u_end = 0x7fffffff) {
-    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
-    for (int u = u0; u < nb * 8 && u < u_end; u += ustride) {
-        const int bo = u >> 3, x = u & 7;
-        {  // rows of the blocks br >= bo: down the columns of tile (br, bo)
-            double acc = 0.0;
-            for (int br = bo; br < nb; ++br) {
-                const double kfv = vec_page(K, sh, br)[KB_ROW_KF * KB_CH + lane];
-                const double* tp = kinv_tile_lo(K, sh, br, bo) + lane;
-                const int rows = m - 64 * br < 64 ? m - 64 * br : 64;
-                double v[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = x + 8 * k;
-                    v[k] = r < rows ? tp[r * 64] : 0.0;
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int r = x + 8 * k;
-                    if (r < rows) acc = __builtin_fma(v[k], readlane_f64(kfv, r), acc);
-                }
-            }
-            vec_page(K, sh, bo)[(KB_ROW_PART + x) * KB_CH + lane] = acc;
-        }
-        {  // rows of the blocks br < bo: along the rows of tile (bo, br)
-            const int cl = lane >> 3, sg = lane & 7, c = 8 * x + cl;
-            double acc = 0.0;
-            for (int br = 0; br < bo; ++br) {
-                const double* kfp = vec_page(K, sh, br) + KB_ROW_KF * KB_CH + sg;
-                const double* tp = kinv_tile_lo(K, sh, bo, br) + c * 64 + sg;
-                double v[8], kv[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    v[k] = tp[8 * k];
-                    kv[k] = kfp[8 * k];
-                }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc = __builtin_fma(v[k], kv[k], acc);
-            }
-            vec_page(K, sh, bo)[(KB_ROW_PARTT + sg) * KB_CH + c] = acc;
-        }
-    }
-}
-
-__device__ __forceinline__ void matvec_tri_combine(const KbState& K, const uint64_t* sh, int m) {
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-        double* P = vec_page(K, sh, i >> 6) + (i & 63);
-        double p[8], q[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            p[k] = P[(KB_ROW_PART + k) * KB_CH];
-            q[k] = P[(KB_ROW_PARTT + k) * KB_CH];
-        }
-        const double a = ((p[0] + p[1]) + (p[2] + p[3])) + ((p[4] + p[5]) + (p[6] + p[7]));
-        const double b = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
-        P[KB_ROW_DS * KB_CH] = a + b;
-    }
-    __syncthreads();
-}
-
-__device__ __forceinline__ void matvec_tri_colsum(const KbState& K, const uint64_t* sh, int m) {
-    matvec_tri_units(K, sh, m, threadIdx.x >> 6, blockDim.x >> 6);
-    __syncthreads();
-    matvec_tri_combine(K, sh, m);
-}
-
 // tile t of the lower block triangle in the order (0,0) (1,0) (1,1) (2,0) ...
 __device__ __forceinline__ void tri_tile_of(int t, int* bi, int* bj) {
     int b = (int)((__builtin_sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -812,6 +745,91 @@ __device__ __forceinline__ void tri_tile_of(int t, int* bi, int* bj) {
     while (b * (b + 1) / 2 > t) --b;
     *bi = b;
     *bj = t - b * (b + 1) / 2;
+}
+
+// ---- triangle storage (KbDev.tri): d* = Kinv K_f when only the tiles (b_i, b_j), b_j <= b_i, exist -- every tile read ONCE.
+// Tile (bi, bj) holds Kinv[64 bi + r][64 bj + c].  It contributes to the outputs of block bj down its columns,
+//     dpart[c] = sum_r T[r][c] K_f[64 bi + r],
+// and, Kinv being symmetric, to the outputs of block bi along its rows (off-diagonal tiles only),
+//     tpart[r] = sum_c T[r][c] K_f[64 bj + c].
+// One wave forms both from one pass over the tile, eight rows at a time: the rows come in coalesced for dpart (lane =
+// column; the eight rows of a slab are one row of each class r mod 8, so eight accumulators step once per slab), and the
+// same 4 KB -- still in the CU's L1 -- come in again dealt as lane = (row 8 x + (lane >> 3), column class lane & 7) for
+// tpart: the eight lanes of a row read 64 consecutive bytes, chain their eight products and meet in a three-step butterfly.
+// Both partial sums have one shape in every kernel: eight chains of fused multiply-adds over the classes (index mod 8, in
+// increasing index) and ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)).  The tile's 128 partial sums go to its slot of
+// the shell's partial area; matvec_tri_combine adds, per output, the dpart of its column of tiles (increasing bi) and the
+// tpart of its row of tiles (increasing bj), plain additions in that order.  Tiles are independent work units (the
+// chip-wide rounds lay them end to end), and d* costs one read of the stored triangle -- half of what reading every tile
+// once per orientation cost (the first round-4 version), a quarter of a square Kinv's row walk AND column walk.
+__device__ __forceinline__ double* tri_part(const KbState& K, const uint64_t* sh, int bi, int bj) {
+    return K.pool + sh[bi] + KB_VEC + (size_t)(bi + 1) * KB_TILE + (size_t)bj * 128;
+}
+
+__device__ __forceinline__ void matvec_tri_tiles(const KbState& K, const uint64_t* sh, int m, int t0, int tstride,
+                                                 int t_end = 0x7fffffff) {
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
+    const int cl = lane >> 3, sg = lane & 7;
+    const int nt = nb * (nb + 1) / 2;
+    for (int t = t0; t < nt && t < t_end; t += tstride) {
+        int bi, bj;
+        tri_tile_of(t, &bi, &bj);
+        const double* Tp = kinv_tile_lo(K, sh, bi, bj);
+        const int rows = m - 64 * bi < 64 ? m - 64 * bi : 64;
+        const bool off = bi != bj;
+        const double kfr = vec_page(K, sh, bi)[KB_ROW_KF * KB_CH + lane];
+        double kc[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) kc[k] = off ? vec_page(K, sh, bj)[KB_ROW_KF * KB_CH + sg + 8 * k] : 0.0;
+        double* part = tri_part(K, sh, bi, bj);
+        double acc[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+        for (int x = 0; x < 8; ++x) {
+            if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
+            // (issuing a slab's loads one slab ahead of their use was tried: 159 registers and three waves per SIMD, or 128 with
+            // 60 B of scratch -- 0.335 ms per step against 0.295, profiles/r04_f_*)
+            double v[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
+            if (off) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tv[k] = Tp[(8 * x + cl) * 64 + sg + 8 * k];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (8 * x + u < rows) acc[u] = __builtin_fma(v[u], readlane_f64(kfr, 8 * x + u), acc[u]);
+            if (off) {
+                double ta = 0.0;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) ta = __builtin_fma(tv[k], kc[k], ta);
+                ta += __shfl_xor(ta, 1);
+                ta += __shfl_xor(ta, 2);
+                ta += __shfl_xor(ta, 4);
+                if (sg == 0) part[64 + 8 * x + cl] = ta;
+            }
+        }
+        part[lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+}
+
+__device__ __forceinline__ void matvec_tri_combine(const KbState& K, const uint64_t* sh, int m) {
+    const int nb = (m + 63) >> 6;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+        const int b = i >> 6, c = i & 63;
+        double dsum = tri_part(K, sh, b, b)[c];
+        for (int br = b + 1; br < nb; ++br) dsum += tri_part(K, sh, br, b)[c];
+        double tsum = 0.0;
+        for (int br = 0; br < b; ++br) tsum += tri_part(K, sh, b, br)[64 + c];
+        vec_page(K, sh, b)[KB_ROW_DS * KB_CH + c] = dsum + tsum;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void matvec_tri_colsum(const KbState& K, const uint64_t* sh, int m) {
+    matvec_tri_tiles(K, sh, m, threadIdx.x >> 6, blockDim.x >> 6);
+    __syncthreads();
+    matvec_tri_combine(K, sh, m);
 }
 
 // Kinv <- [[Kinv,0],[0,0]] + outer([d*,-1],[d*,-1]) / delta (projectron.py:54-58) over the m1 = m + 1 landmarks, d* (with
@@ -1116,19 +1134,19 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (threadIdx.x < 64) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-            const bool any = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W);
-            if (lane == 0) sm.ired[4] = any ? 1 : 0;
+            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W);
+            if (lane == 0) sm.ired[4] = direct;
         }
         __syncthreads();
-        const bool any_direct = sm.ired[4] != 0;
+        const int any_direct = sm.ired[4];
         if (blockDim.x >= 256) {
             if (g < w.ng) {
                 chain_scores<1>(D, sm.G2, sm.W, w.base + 64 * g, 1, f1);
-                if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, f1);
+                if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, (any_direct & 2) != 0, f1);
             }
         } else if (threadIdx.x < 64) {
             chain_scores<4>(D, sm.G2, sm.W, w.base, w.ng, f);
-            if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, f);
+            if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, (any_direct & 2) != 0, f);
         }
     } else if (blockDim.x >= 256) {
         if (g < w.ng) score<1, 1>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);  // (w.ng <= 4: waves beyond it idle)
@@ -1376,7 +1394,7 @@ __global__ __launch_bounds__(1024) void heavy_plan_kernel(KbDev D, KbState K) {
         if (slot < count) {
             if (K.hv_state[slot] == 1) {
                 const long long nb = (K.m[dict_of(D, K.heavy[4 + slot])] + 63) >> 6;
-                wmv = nb * nb * 8;
+                wmv = D.tri ? nb * (nb + 1) / 2 : nb * nb * 8;  // tri: tiles; else units of nb passes (below)
             }
             if (K.hv_grew[slot] == 1) {
                 const long long nb1 = (K.hv_m[slot] + 1 + 63) >> 6;
@@ -1441,14 +1459,12 @@ __global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
         const int dict = dict_of(D, K.heavy[4 + slot]);
         const int m = K.m[dict];
         const long long nb = (m + 63) >> 6;
-        // units whose first pass lies in [lo, hi)
         const long long a = lo > sb ? lo - sb : 0, b = (hi < se ? hi : se) - sb;
-        const int u0 = (int)((a + nb - 1) / nb), u1 = (int)((b + nb - 1) / nb);
-        if (u0 < u1) {
-            if (D.tri)
-                matvec_tri_units(K, shells_of(D, K, dict), m, u0, 1, u1);
-            else
-                matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
+        if (D.tri) {  // the work line counts tiles
+            if (a < b) matvec_tri_tiles(K, shells_of(D, K, dict), m, (int)a, 1, (int)b);
+        } else {      // units whose first pass lies in [lo, hi)
+            const int u0 = (int)((a + nb - 1) / nb), u1 = (int)((b + nb - 1) / nb);
+            if (u0 < u1) matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
         }
         lo = se;
     }
@@ -1760,12 +1776,12 @@ __global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const bool any_direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W);
+    const int direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W);
     __syncthreads();
     double* Wg = K.Wg + (size_t)task * 256;
 #pragma unroll
     for (int k = 0; k < 4; ++k) Wg[lane + 64 * k] = W[lane + 64 * k];
-    if (lane == 0) K.fdirect[task] = any_direct ? 1 : 0;
+    if (lane == 0) K.fdirect[task] = direct;
 }
 
 #define KB_WT_LD 17  // doubles between the rows of W^T in LDS (16 learners + 1: the transposing stores spread over the banks)
@@ -1851,7 +1867,8 @@ __global__ __launch_bounds__(256) void select_gemm_kernel(SelArgs A) {
         if (m >= 2) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) f[g] = 64 * g <= n ? sm.Fs[l][64 * g + lane] : 0.0;
-            if (K.fdirect[task]) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, f);
+            const int direct = K.fdirect[task];
+            if (direct) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, (direct & 2) != 0, f);
         } else if (m == 1) {
             double x[KB_DMAX];
 #pragma unroll

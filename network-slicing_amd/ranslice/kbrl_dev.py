@@ -177,7 +177,7 @@ class VecKBRL:
         matvec_launches, rank1_launches) -- counted by the kernels from their work plan (kb_get_repair_work)"""
         w = (C.c_uint64 * 4)()
         self._check(self.L.kb_get_repair_work(self.h, w))
-        return dict(matvec_bytes=int(w[0]) * 4096, rank1_bytes=int(w[1]) * 16384, matvec_launches=int(w[2]),
+        return dict(matvec_bytes=int(w[0]) * (32768 + 1024), rank1_bytes=int(w[1]) * 16384, matvec_launches=int(w[2]),
                     rank1_launches=int(w[3]))
 
     def set_kernel_timing(self, enable=True):

@@ -569,7 +569,7 @@ def test_projectron_to_3000_landmarks_vs_oracle():
     p = ag.pool()
     # the triangle: shells 0 .. 47 hold 48 pages and 48 * 49 / 2 tiles
     nb = (m + 63) // 64
-    assert p['used_bytes'] == 64 * 8 + (nb * 38 * 64 + nb * (nb + 1) // 2 * 4096) * 8, p
+    assert p['used_bytes'] == 64 * 8 + (nb * 30 * 64 + nb * (nb + 1) // 2 * (4096 + 128)) * 8, p
     assert p['saturated'] == 0 and p['pool_full'] == 0
     ag.close()
 
@@ -692,8 +692,8 @@ def test_pool_grows_on_demand_and_reports_exhaustion():
     big = VecKBRL(4096, [10] * 5, 200, capacity=4096, pool_bytes=4 << 30)
     assert big.pool()['total_bytes'] <= 4 << 30
     big.close()
-    def shell(b):   # bytes of shell b: the vector page (38 rows x 64) + the tiles (b, 0) .. (b, b) of Kinv's lower triangle
-        return (38 * 64 + (b + 1) * 4096) * 8
+    def shell(b):   # bytes of shell b: the vector page (30 rows x 64) + the tiles (b, 0) .. (b, b) of Kinv's lower triangle with
+        return (30 * 64 + (b + 1) * (4096 + 128)) * 8   # their 128 partial sums each
     # room for shells 0, 1, 2 of one dictionary and 0, 1 of the other; shell 3 (147 KB) is larger than what two shells leave
     ag = VecKBRL(2, [10], 200, capacity=65536, pool_bytes=64 * 8 + 2 * shell(0) + 2 * shell(1) + shell(2) + 4096)
     ag.reset([[10], [10]], [[3], [3]])
