@@ -193,7 +193,8 @@ void rs_destroy(rs_handle* h);
 typedef struct kb_config {
     int32_t n_envs;               /* agents (one per env replica) */
     int32_t n_slices;             /* learners per agent */
-    int32_t n_prbs;
+    int32_t n_prbs;               /* <= 255: the candidates 0 .. n_prbs of a learner fill four 64-lane groups (rs_create takes carriers
+                                     of up to 256 PRBs; an agent for a 256-PRB carrier is refused by kb_create with RS_EINVAL) */
     int32_t capacity;             /* most landmarks a dictionary may hold (<= KB_CAPACITY_MAX); storage is taken from the
                                      pool 64 landmarks at a time as dictionaries grow, so this is a limit, not a reservation */
     int32_t dims[KB_MAX_SLICES];  /* state variables of learner s: 10 eMBB / 3 mMTC (scenario_creator.py:209-235) */
@@ -292,6 +293,9 @@ int kb_get_sizes(kb_handle* k, int32_t* m);
 /* the dictionary pool: bytes in use / in total, replicas with a dictionary at its capacity, replicas that found the pool
  * exhausted (both keep learning by projection -- build-defined, the reference's SVvariable is unbounded; any may be NULL) */
 int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_bytes, int32_t* n_saturated, int32_t* n_pool_full);
+/* per-replica flag words [n_envs] behind kb_get_pool's counts: bit 8 a dictionary of the replica reached its capacity, bit 16
+ * it found the pool exhausted */
+int kb_get_flags(kb_handle* k, int32_t* flags);
 /* bytes behind the repair rounds of the large dictionaries since kb_reset (projectron.py:42 Kinv @ K_f, :54-58 the rank-1
  * update), as their kernels count them: work[0] tiles of Kinv the mat-vec kernel read (32,768 bytes each), work[1] units of
  * the rank-1 kernel (8,192 bytes read + 8,192 written each), work[2] / work[3] launches of either that had work */

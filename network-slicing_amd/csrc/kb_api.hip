@@ -785,6 +785,16 @@ extern "C" int kb_get_pool(kb_handle* k, uint64_t* used_bytes, uint64_t* total_b
     return RS_OK;
 }
 
+// the per-replica flag words behind kb_get_pool's counts: bit 8 a dictionary of the replica is at its capacity, bit 16 it found
+// the pool exhausted (both keep learning by projection)
+extern "C" int kb_get_flags(kb_handle* k, int32_t* flags) {
+    if (!k || !flags) return RS_EINVAL;
+    HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipMemcpyAsync(flags, k->K.err, sizeof(int32_t) * (size_t)k->cfg.n_envs, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    return RS_OK;
+}
+
 // What the chip-wide repair rounds have streamed since kb_reset, counted by the kernels from their own work plan:
 // work[0] tiles of Kinv heavy_matvec_kernel read (32,768 bytes each; 128 partial sums written per tile), work[1] units
 // of heavy_rank1_kernel (sixteen rows: 8,192 bytes read and 8,192 written each), work[2] / work[3] launches of the two

@@ -9,7 +9,10 @@ ONE VecRanSlice + VecKBRL pair, advanced by the device-resident closed loop with
 the device (BatchedEvaluator).  Run i is seeded exactly as Evaluator.evaluate(i) seeds it, so its results file is
 the one the run-by-run path writes (tests/test_gpu_kbrl.py::test_batched_evaluator_equals_run_by_run).
 
-  python experiments_kbrl.py [--steps 50400] [--runs 30] [--scenarios 0 1 2] [--serial]
+The whole grid (3 scenarios x 2 accuracy ranges x RUNS) is ONE job: evaluate_grid advances all six cells in one host loop,
+each on its own streams, so their kernels share the chip.
+
+  python experiments_kbrl.py [--steps 50400] [--runs 30] [--scenarios 0 1 2] [--serial | --cell-by-cell]
 """
 import argparse
 import os
@@ -53,7 +56,8 @@ class Evaluator():
 class BatchedEvaluator(Evaluator):
     """All runs of one (scenario, accuracy range) at once: run i = replica i."""
 
-    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True):
+    def _setup(self, runs, device=0, capacity=16384, pool_bytes=32 << 30):
+        """environment + agent of this cell with run i as replica i, reset and given the first action; nothing waits"""
         import ctypes as C
         from ranslice import config as _c
         from ranslice.kbrl_dev import VecKBRL
@@ -90,10 +94,18 @@ class BatchedEvaluator(Evaluator):
         # KBRL_Control.run (kbrl_control.py:126-141): the first action is the learners' initial action
         a0 = np.ascontiguousarray(ia)
         env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
-        for i in range(self.steps):
-            agent.step_resident(env)          # update_control + select_action + this step's history column
-            if i + 1 < self.steps:
-                env.step_resident()
+        self._ctx = dict(runs=runs, env=env, agent=agent, capacity=capacity)
+
+    def _advance(self, i):
+        """step i of KBRL_Control.run's loop, enqueued on this cell's own streams (no host wait)"""
+        c = self._ctx
+        c['agent'].step_resident(c['env'])    # update_control + select_action + this step's history column
+        if i + 1 < self.steps:
+            c['env'].step_resident()
+
+    def _finish(self, verbose=True):
+        c = self._ctx
+        env, agent, runs, capacity = c['env'], c['agent'], c['runs'], c['capacity']
         hist = agent.history_fetch()          # waits for the loop; raises on a device-side error
         env.fetch()                           # surfaces simulator capacity errors
         assert hist['recorded'] == self.steps
@@ -102,9 +114,14 @@ class BatchedEvaluator(Evaluator):
         self.last_run = dict(max_dictionary=int(sizes.max()), mean_dictionary=float(sizes.mean()), pool=pool)
         if pool['saturated'] or pool['pool_full']:
             import warnings
-            warnings.warn('KBRL dictionaries of runs %s could not grow any further (capacity %d landmarks, pool %.1f of %.1f '
-                          'MB in use) and projected further samples instead of growing: raise capacity / pool_bytes'
-                          % (sorted({runs[k] for k in np.nonzero(sizes >= capacity)[0]}), capacity,
+            # the replicas that carry the flags (err bits 8 / 16), not a guess from the sizes: a dictionary that found the pool
+            # exhausted is below its capacity
+            flagged = agent.flagged_replicas()
+            warnings.warn('KBRL dictionaries of runs %s reached their capacity (%d landmarks) and of runs %s found the pool '
+                          'exhausted (%.1f of %.1f MB in use): they projected further samples instead of growing -- raise '
+                          'capacity / pool_bytes'
+                          % (sorted(runs[k] for k in flagged['saturated']), capacity,
+                             sorted(runs[k] for k in flagged['pool_full']),
                              pool['used_bytes'] / 2 ** 20, pool['total_bytes'] / 2 ** 20))
         files = []
         for k, i in enumerate(runs):
@@ -118,7 +135,35 @@ class BatchedEvaluator(Evaluator):
                     i, results['resources'].mean(), results['violation'].sum()))
         env.close()
         agent.close()
+        self._ctx = None
         return files
+
+    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True):
+        self._setup(runs, device=device, capacity=capacity, pool_bytes=pool_bytes)
+        for i in range(self.steps):
+            self._advance(i)
+        return self._finish(verbose=verbose)
+
+
+def evaluate_grid(cells, runs, steps=STEPS, out_dir='./results', device=0, capacity=16384, pool_bytes=16 << 30, verbose=False):
+    """The reference's whole experiment (experiments_kbrl.py:57-70: every scenario x accuracy range x run) as ONE job on
+    one GPU: a BatchedEvaluator per cell, each with its environment and agents on streams of their own, all advanced in
+    the same host loop -- a cell of 30 runs leaves most of the chip idle (a handful of waves per kernel), so the cells'
+    kernels run beside each other.  Nothing in the loop waits for the device.  Returns {(scenario, a_lo): [files]}, file
+    for file what evaluate_all writes cell by cell (tests/test_gpu_kbrl.py::test_grid_of_cells_equals_cell_by_cell)."""
+    evs = []
+    for scenario, a_range in cells:
+        ev = BatchedEvaluator(scenario, a_range, steps=steps, out_dir=out_dir)
+        ev._setup(runs, device=device, capacity=capacity, pool_bytes=pool_bytes)
+        evs.append(ev)
+    for i in range(steps):
+        for ev in evs:
+            ev._advance(i)
+    out = {}
+    for (scenario, a_range), ev in zip(cells, evs):
+        out[(scenario, a_range[0])] = ev._finish(verbose=verbose)
+    evaluate_grid.last_runs = {(c[0], c[1][0]): ev.last_run for c, ev in zip(cells, evs)}
+    return out
 
 
 if __name__ == '__main__':
@@ -128,11 +173,16 @@ if __name__ == '__main__':
     ap.add_argument('--scenarios', type=int, nargs='*', default=scenarios)
     ap.add_argument('--out', default='./results')
     ap.add_argument('--serial', action='store_true', help='one run at a time through the N=1 drop-in classes')
+    ap.add_argument('--cell-by-cell', action='store_true', help='one (scenario, accuracy range) after the other instead of all at once')
     args = ap.parse_args()
-    for scenario, a_range in product(args.scenarios, accuracy_list):
-        if args.serial:
+    cells = list(product(args.scenarios, accuracy_list))
+    if args.serial:
+        for scenario, a_range in cells:
             evaluator = Evaluator(scenario, a_range, steps=args.steps, out_dir=args.out)
             for run in range(args.runs):
                 evaluator.evaluate(run)
-        else:
+    elif args.cell_by_cell:
+        for scenario, a_range in cells:
             BatchedEvaluator(scenario, a_range, steps=args.steps, out_dir=args.out).evaluate_all(range(args.runs))
+    else:
+        evaluate_grid(cells, range(args.runs), steps=args.steps, out_dir=args.out, verbose=True)

@@ -172,6 +172,12 @@ class VecKBRL:
         self._check(self.L.kb_get_pool(self.h, C.byref(u), C.byref(t), C.byref(ns), C.byref(nf)))
         return dict(used_bytes=u.value, total_bytes=t.value, saturated=ns.value, pool_full=nf.value)
 
+    def flagged_replicas(self):
+        """replicas whose err word carries 'a dictionary is at its capacity' (bit 8) / 'the pool was exhausted' (bit 16)"""
+        e = np.zeros(self.n_envs, dtype=np.int32)
+        self._check(self.L.kb_get_flags(self.h, e.ctypes.data_as(_ip)))
+        return dict(saturated=[int(k) for k in np.nonzero(e & 8)[0]], pool_full=[int(k) for k in np.nonzero(e & 16)[0]])
+
     def repair_work(self):
         """bytes the chip-wide repair rounds streamed since reset: dict(matvec_bytes read, rank1_bytes read + written,
         matvec_launches, rank1_launches) -- counted by the kernels from their work plan (kb_get_repair_work)"""
