@@ -1833,14 +1833,16 @@ __global__ __launch_bounds__(256) void select_gemm_kernel(SelArgs A) {
     {
         const double* Wb = sm.Wt + kq * KB_WT_LD + li;      // B operand: W^T[a0 + kq][learner li]
         const double* Ga = sm.G2 + 256 + kq - (16 * wv + li);  // A operand of tile t: T[16 (w + 4 t) + li][a0 + kq] = G2[256 + a - c]
+        // (all four tiles unconditionally -- a tile past the last candidate costs its MFMAs and is never stored; a wave-uniform
+        // "if (tile < nt)" around each MFMA made the compiler park the accumulators in VGPRs and move them through the same
+        // eight AGPRs around every instruction: 340 cycles per MFMA instead of 64)
         for (int a0 = 0; a0 < KA; a0 += 4) {
             const double b = Wb[a0 * KB_WT_LD];
             double ta[4];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) ta[t] = wv + 4 * t < nt ? Ga[a0 - 64 * t] : 0.0;
+            for (int t = 0; t < 4; ++t) ta[t] = Ga[a0 - 64 * t];
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                if (wv + 4 * t < nt) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], b, acc[t], 0, 0, 0);
+            for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ta[t], b, acc[t], 0, 0, 0);
         }
     }
     __syncthreads();  // (every wave is done with W^T: F takes its place)

@@ -803,6 +803,80 @@ def test_long_closed_loop_with_repair_rounds_vs_oracle():
         assert sizes[k] == m_ref, (r, sizes[k], m_ref)
 
 
+def test_pool_exhaustion_at_batch_size_vs_oracle():
+    """the pool-full path at batch size.  512 replicas of scenario_0 with agents on a pool that holds every
+    dictionary's first shell and only a hundred and fifty second ones: within a few hundred steps dictionaries that reach 64
+    landmarks find the pool exhausted, project instead of growing (size stays at 64) and flag their replica; the run goes
+    on without an error.  WHICH dictionaries get the last shells depends on the order their workgroups reach the allocator
+    (atomics), so the oracle cannot be told in advance where growth stops; replicas are independent, though, so
+      * a replica that never met the exhausted pool agrees with oracle env + oracle agent at every step, and
+      * one that did agrees up to the last poll (every 20 steps) at which its flag was still clear."""
+    import ctypes as C
+    from concurrent.futures import ProcessPoolExecutor
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    N, steps, cols, cap, poll = 512, 420, 10000, 4096, 20
+    scenario = 0
+    dims, n_prbs = _dims(scenario)
+
+    def shell(b):
+        return (30 * 64 + (b + 1) * (4096 + 128)) * 8
+    pool_bytes = 64 * 8 + N * len(dims) * shell(0) + 150 * shell(1)
+    rng = np.random.default_rng(21)
+    ia = rng.integers(10, 35, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)], seed=77)
+    ag = VecKBRL(N, dims, n_prbs, capacity=cap, pool_bytes=pool_bytes)
+    ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 5)
+    env.reset()
+    a0 = np.ascontiguousarray(ia)
+    env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+    hip = []
+    clear_until = np.full(N, steps, dtype=np.int64)   # steps [0, clear_until) ran with the replica's flag clear
+    executed = ia.copy()
+    for i in range(steps):
+        f = env.fetch()
+        ag.step_resident(env)
+        nxt = env.fetch()['actions']
+        hip.append((executed.copy(), f['obs'].copy(), f['labels'].copy(), nxt.copy()))
+        executed = nxt
+        if i + 1 < steps:
+            env.step_resident()
+        if i % poll == poll - 1:
+            for r in ag.flagged_replicas()['pool_full']:
+                clear_until[r] = min(clear_until[r], i + 1 - poll)
+    ag.synchronize()      # a pool that ran out is not an error
+    p = ag.pool()
+    sizes = ag.dictionary_sizes()
+    flagged = set(ag.flagged_replicas()['pool_full'])
+    for r in flagged:
+        clear_until[r] = min(clear_until[r], steps - steps % poll - poll if steps % poll else steps - poll)
+    env.close()
+    ag.close()
+    assert p['pool_full'] == len(flagged) >= 20, p
+    assert p['used_bytes'] <= p['total_bytes'] and p['total_bytes'] - p['used_bytes'] < shell(1), p
+    assert (sizes > 64).sum() <= 150 and (sizes == 64).sum() >= 20, ((sizes > 64).sum(), (sizes == 64).sum())
+    never = [r for r in range(N) if r not in flagged]
+    met = sorted(flagged, key=lambda r: -clear_until[r])
+    sample = never[:6] + [r for r in met if clear_until[r] >= 100][:6]
+    assert len(never) >= 6 and len(sample) >= 8
+    with ProcessPoolExecutor(max_workers=min(12, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
+        ref = list(ex.map(_oracle_closed_loop, [(scenario, replica_seed(77, r), 5 + r, ia[r], sf[r], int(clear_until[r]), cols, cap)
+                                                for r in sample], chunksize=1))
+    for k, r in enumerate(sample):
+        steps_ref, m_ref = ref[k]
+        for i in range(int(clear_until[r])):
+            act, obs, lab, hits, na, adj = steps_ref[i]
+            h = hip[i]
+            assert (h[0][r] == act).all(), ('executed action', r, i)
+            assert h[1][r].tobytes() == obs.tobytes(), ('obs', r, i)
+            assert (h[2][r] == lab).all(), ('labels', r, i)
+            assert (h[3][r] == na).all(), ('selected action', r, i)
+        if r not in flagged:
+            assert sizes[r].tolist() == m_ref, (r, sizes[r], m_ref)
+
+
 def test_long_closed_loop_run_to_run_and_reset():
     """Two runs of 4096 replicas x 900 closed-loop steps from the same seeds on ONE pair of handles (the second after
     env.reset / kb_reset): identical selected actions at every 25th step, identical dictionary sizes and coefficients at
