@@ -231,7 +231,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.heavy, T + 4, true);
     KA(K.hv_cfrom, T, true); KA(K.hv_cstar, T, true); KA(K.hv_state, T, true); KA(K.hv_grew, T, true); KA(K.hv_m, T, true);
     KA(K.hv_pend, 2 * T, true); KA(K.hv_delta, T, true); KA(K.hv_f, 256 * T, true);
-    KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true); KA(K.hv_work, 4, true);
+    KA(K.hv_mvbase, T + 1, true); KA(K.hv_r1base, T + 1, true); KA(K.hv_work, 8, true);
     KA(K.big, 2 * (1 + KB_BIG_MAX), true); KA(K.isbig, 2 * T, true);
     {
         // The pool every dictionary of the handle grows in (kb_kbrl.hip, "Storage").  Upper bound on what can ever be
@@ -284,6 +284,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(K.fver, T, true);
     KA(K.Wg, D.shared ? 1 : T * 256, true);
     KA(K.fdirect, T, true);
+    KA(K.dlist, D.shared ? 1 : T * KB_DLIST * 3, true);
     KA(K.ver, ND, true);
     KA(K.workq, D.shared ? (size_t)cfg->n_slices * 16 * kb::kb_capr(cfg->capacity) * 16 : 1, true);
     KA(K.workF, D.shared ? (size_t)cfg->n_slices * KB_GEMM_KS * N * 256 : 1, true);
@@ -374,7 +375,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.ver, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.fver, 0xFF, sizeof(int32_t) * T, k->stream));  // -1: no stored scores
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));
-    HIPCHK(k, hipMemsetAsync(k->K.hv_work, 0, sizeof(unsigned long long) * 4, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.hv_work, 0, sizeof(unsigned long long) * 8, k->stream));
     HIPCHK(k, hipGetLastError());
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
@@ -799,10 +800,12 @@ extern "C" int kb_get_flags(kb_handle* k, int32_t* flags) {
 // work[0] tiles of Kinv heavy_matvec_kernel read (32,768 bytes each; 128 partial sums written per tile), work[1] units
 // of heavy_rank1_kernel (sixteen rows: 8,192 bytes read and 8,192 written each), work[2] / work[3] launches of the two
 // that had anything to do.  The algorithmic bytes of projectron.py:42 (Kinv @ K_f) and :54-58 (the rank-1 update).
-extern "C" int kb_get_repair_work(kb_handle* k, uint64_t work[4]) {
+// work[4] scoring passes that had to evaluate landmarks' exponentials directly (add_direct_terms), work[5] the landmarks they
+// evaluated, each for every open candidate group; work[6], work[7] reserved.
+extern "C" int kb_get_repair_work(kb_handle* k, uint64_t work[8]) {
     if (!k || !work) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
-    HIPCHK(k, hipMemcpyAsync(work, k->K.hv_work, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, k->stream));
+    HIPCHK(k, hipMemcpyAsync(work, k->K.hv_work, sizeof(uint64_t) * 8, hipMemcpyDeviceToHost, k->stream));
     HIPCHK(k, hipStreamSynchronize(k->stream));
     return RS_OK;
 }

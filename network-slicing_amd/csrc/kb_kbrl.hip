@@ -67,7 +67,9 @@ namespace kb {
 #define KB_BIG_MAX 4096    // at most this many (the rest keep their place)
 #define KB_GEMM_M 256      // shared dictionaries from this size on are scored for all replicas at once as F = E Q on MFMA
 #define KB_GEMM_KS 8       // the landmarks are split in this many parts (one wave each per 16 replicas)
-#define KB_E_TINY 1e-280   // below this E_j G[.] would leave the normal range: direct evaluation (score_pass)
+#define KB_E_TINY 1e-300   // below this E_j G[.] (G >= 0.19) would come near the end of the normal range (2.2e-308), where a product of
+                           // two roundings is no longer the kernel value to a few ulp: direct evaluation (score_pass, bin_pass)
+#define KB_DLIST 48        // landmarks of one scoring pass that take the direct evaluation, listed by bin_pass (more: the rows are walked again)
 #define KB_HEAD 256       // ints per dictionary: newest landmark per grid index (chains through the link row)
 #define KB_BIN_M 128      // a repair rescoring a dictionary of this many landmarks or more uses the binned form (score_binned)
 #define KB_SEL_WAVES 16   // learners per workgroup of select_gemm_kernel: the N dimension of its v_mfma_f64_16x16x4 tiles
@@ -124,7 +126,7 @@ struct KbState {
     double* hv_delta;   // [T]
     long long* hv_mvbase;  // [T + 1] prefix sums of the mat-vec work of the pending learners (heavy_plan_kernel)
     long long* hv_r1base;  // [T + 1] prefix sums of the rank-1 work of the learners that inserted
-    unsigned long long* hv_work;  // [4] since kb_reset: tile passes of the chip-wide mat-vec kernel (8 rows x 512 B each), 16-row units of
+    unsigned long long* hv_work;  // [8] since kb_reset ([4], [5]: scoring passes that took direct exponentials, landmarks they evaluated): tile passes of the chip-wide mat-vec kernel (8 rows x 512 B each), 16-row units of
                                   // the rank-1 kernel (8 KB read + 8 KB written each), launches of either that had work
     double* hv_f;       // [T][256] the scores of the candidates
     // launch order of the one-wave kernels: learners with large dictionaries first (their waves are the long ones)
@@ -139,6 +141,7 @@ struct KbState {
     int32_t* fver;     // [T] K.ver[dict] when F was computed (-1: none)
     int32_t* ver;      // [ND] bumped by every Projectron.update that changed the dictionary (finish_update)
     double* Wg;        // [T][256] W[a] of select_action's state, from select_bin_kernel to select_gemm_kernel
+    double* dlist;     // [T][KB_DLIST][3] (coeff, last coordinate, D0) of those landmarks (bin_pass)
     int32_t* fdirect;  // [T] bin_pass's flags: the learner has landmarks that take the direct evaluation for that state (1) / off the grid (2)
     double* workq;     // shared mode: [S][16][capr][16] Q[j][c] = coeff_j G[|a_j - c|] in MFMA B-operand tiles (shared_q_kernel)
     double* workF;     // shared mode: [S][KB_GEMM_KS][n_envs][256] partial scores F = E Q (shared_fgemm_kernel)
@@ -211,6 +214,7 @@ struct Lds {
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
     double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned)
+    double dl[KB_DLIST * 3];  //   and the (coeff, last coordinate, D0) of the landmarks that take the direct evaluation (bin_pass)
     int ired[8];
 };
 
@@ -467,13 +471,16 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // order (tools/experiments/lds_add_order.hip, profiles/r04_lds_add_order.txt: 4,194,304 of 4,194,304 bins bit for bit the
 // lane-ordered sum, sixteen waves of a CU at it together, three launches identical), and the LDS executes a wave's
 // instructions in order -- so every W[a] is the sum over its landmarks in increasing j, on every run and in every kernel.
-// Returns bit 0: some landmark takes the direct evaluation; bit 1: some landmark is off the candidate grid.
+// Returns bit 0: some landmark takes the direct evaluation; bit 1: some landmark is off the candidate grid; bits 8..: how
+// many take it -- their (coeff, last coordinate, D0) are listed in dlist, in increasing j, the first KB_DLIST of them (a state
+// far from everything the dictionary holds leaves a handful of landmarks in the band where E_j is 1e-300 .. 5e-324: common
+// enough -- thousands of learners per step in BASELINE config 3 -- that walking the rows a second time for them showed).
 template <int MODE>
 __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
-                                         double* W) {
+                                         double* W, double* dlist) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
-    int flags = 0;
+    int flags = 0, ndir = 0;
     ChunkRows<MODE> R, Rn;
     load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
     for (int b = 0; b < nch; ++b) {
@@ -500,11 +507,21 @@ __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const 
         }
         const bool offg = lane < cnt && R.a < 0;
         const bool direct = offg || (lane < cnt && !(E >= KB_E_TINY) && E > 0.0);
-        flags |= (__ballot(direct) != 0ull ? 1 : 0) | (__ballot(offg) != 0ull ? 2 : 0);
+        const unsigned long long dmask = __ballot(direct);
+        if (dmask) {
+            flags |= 1 | (__ballot(offg) != 0ull ? 2 : 0);
+            const int pos = ndir + __builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+            if (direct && pos < KB_DLIST) {
+                dlist[3 * pos] = R.co;
+                dlist[3 * pos + 1] = P[(d - 1) * KB_CH + lane];
+                dlist[3 * pos + 2] = MODE == 1 ? P[KB_ROW_D0 * KB_CH + lane] : d0;
+            }
+            ndir += __builtin_popcountll(dmask);
+        }
         const double w = R.co * E;
         if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(W + R.a, w);  // ds_add_f64
     }
-    return flags;
+    return flags | (ndir << 8);
 }
 
 // f[g] = sum_a G[|a - c|] W[a], c = c_base + 64 g + lane: one chain of fused multiply-adds over a = 0 .. KA - 1 per candidate
@@ -543,9 +560,11 @@ __device__ __forceinline__ void chain_scores(const KbDev& D, const double* G2, c
 #define KB_F_SETTLED 1e-240
 template <int NG>
 __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, int c_base, int ng,
-                                                 bool off_grid, double (&f)[NG]) {
+                                                 int flags, const double* dlist, double (&f)[NG]) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
+    const bool off_grid = (flags & 2) != 0;
+    const int ndir = flags >> 8;
     double tc[NG];
     bool open_[NG], any = false;
 #pragma unroll
@@ -556,27 +575,37 @@ __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& 
         any = any || open_[g];
     }
     if (!__ballot(any)) return;
-    for (int b = 0; b < nch; ++b) {
-        const double* P = vec_page(K, sh, b);
-        const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
-        const double E = P[KB_ROW_E * KB_CH + lane];
-        const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
-        unsigned long long dm = __ballot(lane < cnt && (a < 0 || (!(E >= KB_E_TINY) && E > 0.0)));
-        if (!dm) continue;
-        const double d0 = P[KB_ROW_D0 * KB_CH + lane], lam = P[(d - 1) * KB_CH + lane], co = P[KB_ROW_CO * KB_CH + lane];
-        while (dm) {
-            const int jj = __builtin_ctzll(dm);
-            dm &= dm - 1ull;
-            const double cs = readlane_f64(co, jj), ls = readlane_f64(lam, jj), d0s = readlane_f64(d0, jj);
+    auto term = [&](double cs, double ls, double d0s) {
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                if (__ballot(open_[g])) {
-                    const double dl = ls - tc[g];
-                    const double v = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
-                    f[g] = open_[g] ? v : f[g];
-                }
+        for (int g = 0; g < NG; ++g) {
+            if (__ballot(open_[g])) {
+                const double dl = ls - tc[g];
+                const double v = __builtin_fma(cs, rs_exp_nonpos(-D.gamma * (d0s + dl * dl)), f[g]);
+                f[g] = open_[g] ? v : f[g];
             }
         }
+    };
+    if (ndir <= KB_DLIST) {  // bin_pass listed them all
+        for (int q = 0; q < ndir; ++q) term(dlist[3 * q], dlist[3 * q + 1], dlist[3 * q + 2]);
+    } else {                 // more than the list holds: the rows again
+        for (int b = 0; b < nch; ++b) {
+            const double* P = vec_page(K, sh, b);
+            const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
+            const double E = P[KB_ROW_E * KB_CH + lane];
+            const int a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
+            unsigned long long dm = __ballot(lane < cnt && (a < 0 || (!(E >= KB_E_TINY) && E > 0.0)));
+            if (!dm) continue;
+            const double d0 = P[KB_ROW_D0 * KB_CH + lane], lam = P[(d - 1) * KB_CH + lane], co = P[KB_ROW_CO * KB_CH + lane];
+            while (dm) {
+                const int jj = __builtin_ctzll(dm);
+                dm &= dm - 1ull;
+                term(readlane_f64(co, jj), readlane_f64(lam, jj), readlane_f64(d0, jj));
+            }
+        }
+    }
+    if (lane == 0) {  // (how often, and how much: kb_get_repair_work)
+        atomicAdd(&K.hv_work[4], 1ull);
+        atomicAdd(&K.hv_work[5], (unsigned long long)ndir);
     }
 }
 
@@ -593,9 +622,9 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W);
+        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.dl);
         chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
-        if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, (direct & 2) != 0, f);
+        if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, direct, (const double*)sm.dl, f);
     }
 }
 
@@ -1134,7 +1163,7 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (threadIdx.x < 64) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W);
+            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.dl);
             if (lane == 0) sm.ired[4] = direct;
         }
         __syncthreads();
@@ -1142,11 +1171,11 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (blockDim.x >= 256) {
             if (g < w.ng) {
                 chain_scores<1>(D, sm.G2, sm.W, w.base + 64 * g, 1, f1);
-                if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, (any_direct & 2) != 0, f1);
+                if (any_direct) add_direct_terms<1>(D, K, sh, m, d, w.base + 64 * g, 1, any_direct, (const double*)sm.dl, f1);
             }
         } else if (threadIdx.x < 64) {
             chain_scores<4>(D, sm.G2, sm.W, w.base, w.ng, f);
-            if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, (any_direct & 2) != 0, f);
+            if (any_direct) add_direct_terms<4>(D, K, sh, m, d, w.base, w.ng, any_direct, (const double*)sm.dl, f);
         }
     } else if (blockDim.x >= 256) {
         if (g < w.ng) score<1, 1>(D, K, sh, m, d, sm, w.base + 64 * g, 1, f1);  // (w.ng <= 4: waves beyond it idle)
@@ -1776,7 +1805,7 @@ __global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const int direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W);
+    const int direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W, K.dlist + (size_t)task * (KB_DLIST * 3));
     __syncthreads();
     double* Wg = K.Wg + (size_t)task * 256;
 #pragma unroll
@@ -1870,7 +1899,7 @@ __global__ __launch_bounds__(256) void select_gemm_kernel(SelArgs A) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) f[g] = 64 * g <= n ? sm.Fs[l][64 * g + lane] : 0.0;
             const int direct = K.fdirect[task];
-            if (direct) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, (direct & 2) != 0, f);
+            if (direct) add_direct_terms<4>(D, K, sh, m, d, 0, n / 64 + 1, direct, K.dlist + (size_t)task * (KB_DLIST * 3), f);
         } else if (m == 1) {
             double x[KB_DMAX];
 #pragma unroll

@@ -181,10 +181,10 @@ class VecKBRL:
     def repair_work(self):
         """bytes the chip-wide repair rounds streamed since reset: dict(matvec_bytes read, rank1_bytes read + written,
         matvec_launches, rank1_launches) -- counted by the kernels from their work plan (kb_get_repair_work)"""
-        w = (C.c_uint64 * 4)()
+        w = (C.c_uint64 * 8)()
         self._check(self.L.kb_get_repair_work(self.h, w))
         return dict(matvec_bytes=int(w[0]) * (32768 + 1024), rank1_bytes=int(w[1]) * 16384, matvec_launches=int(w[2]),
-                    rank1_launches=int(w[3]))
+                    rank1_launches=int(w[3]), direct_passes=int(w[4]), direct_landmarks=int(w[5]))
 
     def set_kernel_timing(self, enable=True):
         self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))

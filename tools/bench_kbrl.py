@@ -101,6 +101,8 @@ def main():
         'step_workload_per_env_step': {'fading_samples': per(0), 'pf_iterations': per(2), 'ue_slots': per(3)},
         'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
         'kinv_streaming': {'heavy_matvec_kernel': roof('matvec', 'matvec_launch_ms', 'n_matvec'), 'heavy_rank1_kernel': roof('rank1', 'rank1_launch_ms', 'n_rank1')},
+        'direct_passes_per_step': (w1['direct_passes'] - w0['direct_passes']) / args.steps,
+        'direct_landmarks_per_step': (w1['direct_landmarks'] - w0['direct_landmarks']) / args.steps,
         'driver': 'random script' if args.random else 'KBRL agents',
         'violations_per_env_step_last': float(out['violations'].sum(axis=1).mean()),
     }))
