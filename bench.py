@@ -29,8 +29,10 @@ The JSON line also carries
                  the same workload -- a reported baseline, never the thing measured above;
   kbrl         : (1 GPU) BASELINE config 3 -- the same 4096 replicas with one KBRL agent each, closed loop on
                  the device, at two points of learning: steps 100-300 (dictionaries of tens of landmarks) and from
-                 step 3000 (hundreds): env-steps/s, per-phase kernel times, kernel evaluations/s, dictionary sizes
-                 and the pool in use.
+                 step 3000 (hundreds).  `value` is the LATE one.  Per point: env-steps/s, per-phase kernel times, the HBM
+                 roofline of the two kernels that stream Kinv (bytes from their own work plan / HIP-event launch times),
+                 the MFMA work of select_action, dictionary sizes, the pool in use and the step at which it would run out.
+                 kbrl = the 'tdl' trace profile, kbrl_sos = the fixtures' profile (rounds 1-3 quoted that one).
   python bench.py --scaling 1,2,4,8 prints ONE line with the curve over N and the CPU baseline.
 """
 import argparse
@@ -55,7 +57,6 @@ FADING_COLS = 10000
 ACTION_SEED = 2024
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 F64_PEAK_TFLOPS = 78.6     # MI355X f64 vector / matrix peak
-LDS_PAIRS_PEAK = 256 * 16 * 2.4e9   # 8-byte LDS reads per second: 256 CUs x 128 B/clk x 2.4 GHz
 BURN_BLOCK = 500
 BURN_MAX = 8000
 
@@ -125,13 +126,18 @@ def cpu_baseline(burn, timed):
     with ctx.Pool(cores, initializer=_init_pool, initargs=(barrier,)) as pool:
         jobs = [(i, {}, burn, timed, _barrier_wait, [i]) for i in range(cores)]
         res = pool.map(_cpu_worker, jobs, chunksize=1)
-    t0 = min(r[0] for r in res)
-    t1 = max(r[1] for r in res)
-    total = sum(r[2] for r in res)
+        t0 = min(r[0] for r in res)
+        t1 = max(r[1] for r in res)
+        total = sum(r[2] for r in res)
+    # BASELINE.md section 3 also asks for the single-core number: one replica, one process, the other cores idle
+    b1 = ctx.Barrier(1)
+    with ctx.Pool(1, initializer=_init_pool, initargs=(b1,)) as pool:
+        one = pool.map(_cpu_worker, [(0, {}, burn, timed, _barrier_wait, [0])], chunksize=1)[0]
     return dict(value=total / (t1 - t0), unit='env-steps/s', cores=cores, kind='port',
+                single_core_value=one[2] / (one[1] - one[0]),
                 sample='%d replicas (one per host core) x %d steps of the same scenario_0 workload and action '
-                       'script after a %d-step burn-in; C oracle (oracle/rs_oracle.c), 1 thread per replica'
-                       % (cores, timed, burn))
+                       'script after a %d-step burn-in; C oracle (oracle/rs_oracle.c), 1 thread per replica; '
+                       'single_core_value: one replica alone, same steps' % (cores, timed, burn))
 
 
 def _free_port():
@@ -145,18 +151,19 @@ def _free_port():
 KBRL_CAPACITY = 4096          # a limit, not a reservation: dictionaries take their storage from the pool as they grow
 KBRL_POOL_BYTES = 64 << 30
 KBRL_LATE_STEP = 3000         # second measurement point: dictionaries of several hundred landmarks
+SEL_TILE_ROWS = 16            # select_gemm_kernel: v_mfma_f64_16x16x4 tiles of 16 candidates x 16 learners, 4 grid indices per instruction
 
 
-def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
+def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile='tdl'):
     """BASELINE config 3 on this GPU: closed loop with one KBRL agent per replica (kb_step_resident), measured twice:
     early in learning (steps `warmup`..`warmup + steps`, the point of rounds 1-2) and from step `late_step` on, where the
-    dictionaries hold what a run of that length holds."""
+    dictionaries hold what a run of that length holds.  `value` is the LATE number (it falls with run length: the step is
+    stated)."""
     import ctypes as C
     from ranslice.config import make_config, EMBB_A, EMBB_SEC
     from ranslice.fading import synth_traces
     from ranslice.kbrl_dev import VecKBRL
     from ranslice.vec_env import VecRanSlice
-    profile = os.environ.get('KBRL_TRACES', 'sos')        # (developer knob) synthetic trace profile of this leg
     cap = int(os.environ.get('KBRL_CAPACITY', KBRL_CAPACITY))
     cfg = make_config(SCENARIO, n_envs=n_envs)
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=synth_traces(FADING_COLS, profile), device=device)
@@ -169,6 +176,7 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
     agent.reset(ia, sf)
     env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
     done = [0]
+    n_learners = n_envs * cfg.n_embb
 
     def run(k):
         for _ in range(k):
@@ -176,11 +184,17 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
             env.step_resident()
         done[0] += k
     d = 11   # eMBB learner: 10 state variables + the candidate allocation
+    # select_gemm_kernel per launch: workgroups of 16 learners (launch slots: the learners + the 4096 places of the
+    # large-learner list), 4 waves x 4 candidate tiles x (n_prbs + 4) / 4 instructions each
+    sel_blocks = (n_learners + 4096 + 15) // 16
+    mfma_per_launch = sel_blocks * 4 * 4 * ((cfg.n_prbs + 4) // 4)
 
     def point(k):
         env.synchronize()
         agent.synchronize()
         s0 = agent.stats()
+        w0 = agent.repair_work()
+        p0 = agent.pool()
         agent.set_kernel_timing(True)
         env.set_kernel_timing(True)
         first = done[0]
@@ -191,48 +205,77 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP):
         dt = time.perf_counter() - t0
         s1 = agent.stats()
         ph = agent.phase_times_ms()
+        w1 = agent.repair_work()
         env_ms, _ = env.kernel_time_ms()
         agent.set_kernel_timing(False)
         env.set_kernel_timing(False)
         sizes = agent.dictionary_sizes()
+        pool = agent.pool()
         evals = s1[3] - s0[3]
-        # what the table-factorised scoring actually executes per (landmark, candidate) pair: one FMA + one LDS read
-        # (2 flop); per landmark and pass one exp and the 3 (d - 1) flop of its distance.  SURVEY.md 8d's model -- the
-        # (3 d + 3) flop of a direct evaluation per pair -- is kept beside it for comparison with rounds 1-2.
-        passes = 2.0 + (s1[1] - s0[1]) / float(n_envs * cfg.n_embb * k)   # update pass, select pass, one per repair
-        exps = passes * float(sizes.sum()) * k
-        return {
+
+        def stream_roof(kind, ms_key, n_key):
+            # ALGORITHMIC bytes (Kinv tiles the work plan of the launch lists: projectron.py:42 reads them, :54-58 reads and
+            # rewrites them) over the duration of all launches of the kernel in the window (HIP events on the agent's stream;
+            # the later rounds of a step often find nothing left: their launches are in the time), against the HBM peak
+            nw = w1[kind + '_launches'] - w0[kind + '_launches']
+            if not nw or not ph[ms_key]:
+                return None
+            total = float(w1[kind + '_bytes'] - w0[kind + '_bytes'])
+            ms = ph[ms_key] * ph[n_key]
+            gbs = total / (ms * 1e-3) / 1e9
+            return {'bound': 'hbm', 'kernel': 'heavy_%s_kernel' % kind, 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': gbs / HBM_PEAK_GBS, 'bytes_per_launch': total / nw, 'bytes_per_step': total / k,
+                    'launches_with_work': nw, 'launches_timed': ph[n_key], 'launch_ms_mean': ph[ms_key], 'ms_per_step': ms / k}
+        rec = {
             'steps': [first, first + k], 'value': n_envs * k / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / k,
             'embb_kernel_ms': env_ms, 'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
-            'kernel_evaluations_per_s': evals / dt, 'exps_per_s_estimate': exps / dt,
+            'kernel_evaluations_per_s': evals / dt,
             'predicts_per_env_step': (s1[0] - s0[0]) / (n_envs * k),
             'mistakes_per_env_step': (s1[1] - s0[1]) / (n_envs * k),
-            # what bounds the table-factorised scoring per (landmark, candidate) pair is one 8-byte LDS read (128 B/clk/CU) and
-            # three VALU instructions per 64 pairs, not flops: the LDS-side bound is 256 CUs x 16 pairs/clk x 2.4 GHz
-            'scoring_bound': {'bound': 'lds', 'achieved_pairs_per_s': evals / dt, 'peak_pairs_per_s': LDS_PAIRS_PEAK,
-                              'frac': evals / dt / LDS_PAIRS_PEAK,
-                              'note': 'the one-wave kernels are latency-bound (waves wait ~70 % of their cycles, '
-                                      'profiles/kbrl_mfma_share.json), not throughput-bound'},
+            # the reference's cost model of the same predictions ((3 d + 3) flop per landmark and candidate),
+            # kept for comparison with rounds 1-3; the build forms them from W[a] (one pass over the landmarks) and a
+            # 16 x 204 x 16 product per 16 candidates x 16 learners on the matrix cores
             'direct_model_tflops': evals * (3 * d + 3) / dt / 1e12,
-            'direct_model_frac_of_f64_peak': evals * (3 * d + 3) / dt / 1e12 / F64_PEAK_TFLOPS,
+            'select_mfma': {'instructions_per_launch': mfma_per_launch, 'flop_per_launch': mfma_per_launch * 2048,
+                            'select_phase_ms': ph['select_ms'],
+                            'tflops_over_the_select_phase': mfma_per_launch * 2048 / (ph['select_ms'] * 1e-3) / 1e12 if ph['select_ms'] else None,
+                            'peak_tflops_f64': F64_PEAK_TFLOPS,
+                            'note': 'the select phase is select_bin_kernel (one pass over every landmark: HBM) + '
+                                    'select_gemm_kernel (the MFMA product); rocprofv3 counters of the latter in profiled_counters'},
+            'direct_exponential_passes_per_step': (w1['direct_passes'] - w0['direct_passes']) / k,
             'dictionary_size_mean': float(np.mean(sizes)), 'dictionary_size_max': int(np.max(sizes)),
             'dictionary_size_p50_p90_p99': [float(np.percentile(sizes, q)) for q in (50, 90, 99)],
-            'pool': agent.pool(),
+            'pool': pool,
+            'kinv_streaming': {'rank1': stream_roof('rank1', 'rank1_launch_ms', 'n_rank1'),
+                               'matvec': stream_roof('matvec', 'matvec_launch_ms', 'n_matvec')},
         }
+        # the memory horizon: the pool never frees before kb_reset; at the growth of this window it is exhausted at ...
+        grow = (pool['used_bytes'] - p0['used_bytes']) / float(k)
+        if grow > 0:
+            left = (pool['total_bytes'] - pool['used_bytes']) / grow
+            rec['pool_horizon'] = {'bytes_per_step': grow, 'steps_left_at_this_rate': left, 'exhausted_near_step': first + k + left,
+                                   'note': 'linear extrapolation of this window; Kinv grows with the square of a dictionary, so a '
+                                           'lower bound on the rate and an upper bound on the step.  Past it dictionaries that '
+                                           'ask for a shell project instead of growing and their replicas are flagged '
+                                           '(kb_get_pool / kb_get_flags; tests/test_gpu_kbrl.py::test_pool_exhaustion_at_batch_size_vs_oracle)'}
+        return rec
     run(warmup)
     early = point(steps)
     late = None
     if late_step and late_step > done[0]:
         run(late_step - done[0])
         late = point(steps)
+    head = late or early
     rec = {
         'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device (%s traces)'
                     % (n_envs, profile),
         'dictionary_capacity': cap, 'pool_bytes': KBRL_POOL_BYTES,
-        'value': early['value'], 'unit': 'env-steps/s', 'ms_per_step': early['ms_per_step'],
+        'value': head['value'], 'unit': 'env-steps/s', 'ms_per_step': head['ms_per_step'], 'value_at_steps': head['steps'],
+        'roofline': (head['kinv_streaming'] or {}).get('rank1'),
         'early': early, 'late': late,
-        'scoring': 'k(l_j, x_c) = E_j G[|a_j - c|]: one exp per landmark and pass, one FMA + one LDS read per (landmark, '
-                   'candidate); no MFMA in these kernels (a one-column product; DESIGN.md §4 KBRL)',
+        'scoring': 'f(c) = sum_a G[|a - c|] W[a], W[a] = sum of coeff_j E_j over the landmarks of grid index a: one pass over the '
+                   'landmarks per state, then T W for 16 learners at a time on v_mfma_f64_16x16x4 (select_gemm_kernel); '
+                   'update_control starts from the scores select_action left (DESIGN.md section 4 KBRL)',
         'peak_tflops_f64': F64_PEAK_TFLOPS,
     }
     ppath = os.path.join(ROOT, 'profiles', 'kbrl_mfma_share.json')
@@ -505,9 +548,15 @@ def main():
         line['cpu_baseline'] = cpu_base
         if world == 1 and not args.no_kbrl:
             try:
-                line['kbrl'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100)
+                # config 3 on both synthetic trace profiles: 'tdl' (tapped delay lines, the construction of the ns-3 traces the
+                # reference was run on; the profile the reference comparison of DESIGN.md section 7 was recorded on) is the
+                # headline, 'sos' (the fixtures' profile, rounds 1-3's numbers) beside it
+                line['kbrl'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100, profile=os.environ.get('KBRL_TRACES', 'tdl'))
+                if not os.environ.get('KBRL_TRACES'):
+                    line['kbrl_sos'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100, profile='sos')
             except Exception as e:  # the headline line must not depend on the agent's sub-record
-                line['kbrl'] = {'error': repr(e)}
+                line.setdefault('kbrl', {'error': repr(e)})
+                line['kbrl_error'] = repr(e)
         print(json.dumps(line), flush=True)
 
     if world > 1:

@@ -299,7 +299,8 @@ int kb_get_flags(kb_handle* k, int32_t* flags);
 /* bytes behind the repair rounds of the large dictionaries since kb_reset (projectron.py:42 Kinv @ K_f, :54-58 the rank-1
  * update), as their kernels count them: work[0] tiles of Kinv the mat-vec kernel read (32,768 bytes each), work[1] units of
  * the rank-1 kernel (8,192 bytes read + 8,192 written each), work[2] / work[3] launches of either that had work; work[4] scoring passes that
- * evaluated landmarks' exponentials one by one (outlier states, off-grid landmarks), work[5] the landmarks they evaluated */
+ * evaluated landmarks' exponentials one by one (outlier states, off-grid landmarks), work[5] the landmarks they evaluated --
+ * both counted by developer builds only (-DKB_COUNT_DIRECT), 0 otherwise */
 int kb_get_repair_work(kb_handle* k, uint64_t work[8]);
 int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches);
 /* the same per phase: ms[0] / n[0] the update phase (update_control_kernel and its repair kernels; shared mode: the scan

@@ -585,8 +585,17 @@ __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& 
             }
         }
     };
-    if (ndir <= KB_DLIST) {  // bin_pass listed them all
-        for (int q = 0; q < ndir; ++q) term(dlist[3 * q], dlist[3 * q + 1], dlist[3 * q + 2]);
+    if (ndir <= KB_DLIST) {  // bin_pass listed them all: the list comes in with one round of loads, its entries by readlane
+        static_assert(KB_DLIST * 3 <= 192, "three registers hold the list");
+        const int ne = 3 * ndir;
+        const double e0 = lane < ne ? dlist[lane] : 0.0;
+        const double e1 = 64 + lane < ne ? dlist[64 + lane] : 0.0;
+        const double e2 = 128 + lane < ne ? dlist[128 + lane] : 0.0;
+        auto entry = [&](int i) -> double {  // (i is wave-uniform)
+            const double r = i < 64 ? e0 : (i < 128 ? e1 : e2);
+            return readlane_f64(r, i & 63);
+        };
+        for (int q = 0; q < ndir; ++q) term(entry(3 * q), entry(3 * q + 1), entry(3 * q + 2));
     } else {                 // more than the list holds: the rows again
         for (int b = 0; b < nch; ++b) {
             const double* P = vec_page(K, sh, b);
@@ -603,10 +612,13 @@ __device__ __forceinline__ void add_direct_terms(const KbDev& D, const KbState& 
             }
         }
     }
-    if (lane == 0) {  // (how often, and how much: kb_get_repair_work)
+#ifdef KB_COUNT_DIRECT  // (how often, and how much: kb_get_repair_work[4], [5].  A developer build only: thousands of passes a step
+                        // adding to ONE address cost select_gemm_kernel 0.1 ms per step, profiles/r04_m_*)
+    if (lane == 0) {
         atomicAdd(&K.hv_work[4], 1ull);
         atomicAdd(&K.hv_work[5], (unsigned long long)ndir);
     }
+#endif
 }
 
 // the binned scores of the first ng (<= NG) groups of 64 candidates from c_base on, by ONE wave using the block's sm.W / sm.tag
