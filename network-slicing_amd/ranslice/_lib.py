@@ -48,6 +48,12 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError('libranslice.so not found at %s: build it with `make -C network-slicing_amd/csrc` '
                           '(hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+    # A handle drives two or three HIP streams (the simulator's, its mMTC side stream, the agent's) and several handles may run
+    # side by side in one process (experiments_kbrl.evaluate_grid: six cells = 18 streams).  The HIP runtime multiplexes
+    # streams onto 4 hardware queues unless told otherwise, and streams that share a queue run one after the other: the
+    # six-cell grid took 26.5 s per 6,000 steps on 4 queues, 16.3 s on 24 (profiles/r04_g_queues.txt).  Read by the runtime
+    # at its first call, so it has to be in the environment before the library initialises; a value the user set stays.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
