@@ -11,7 +11,7 @@ in HBM when the timed region starts; nothing crosses PCIe inside it.
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Replicas are independent, so GPUs shard them with no data-path collective (weak scaling: 4096
-replicas per GPU).  torch is used only for the process group (barrier, max-over-ranks).
+replicas per GPU).  torch is used only for the process group (gloo: barrier, max-over-ranks) and torch.cuda.synchronize.
 
 Before the W warm-up steps the environments are advanced until the UE population is stationary: blocks of 500
 steps (25 s of simulated time; the holding times have a 30 s mean) until the mean number of UEs per slice changes
@@ -399,7 +399,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+        # The ranks only agree on wall-clock time (barrier, MAX of the elapsed time): a gloo group over 127.0.0.1.  RanSlice.step
+        # has no collective, and the one RCCL communicator of the build (the shared-dictionary exchange) is formed inside
+        # libranslice.so, which binds the RCCL copy the process has already mapped (torch links one) rather than a second one.
+        dist.init_process_group(backend='gloo')
 
     def barrier():
         if world > 1:
@@ -449,7 +452,7 @@ def main():
             done = prev is not None and abs(cur - prev) <= 0.005 * prev
             # every rank must run the same number of blocks: continue while ANY rank is still moving
             if world > 1:
-                done = max_over_ranks(0.0 if done else 1.0, device='cuda') == 0.0
+                done = max_over_ranks(0.0 if done else 1.0) == 0.0
             prev = cur
             if done:
                 break
@@ -484,7 +487,7 @@ def main():
     out = env.fetch()  # also surfaces capacity-overflow errors
     assert np.isfinite(out['reward']).all()
 
-    elapsed = max_over_ranks(t1 - t0, device='cuda')
+    elapsed = max_over_ranks(t1 - t0)
     env.close()
 
     if rank == 0:

@@ -29,7 +29,7 @@ struct kb_handle {
     double* d_mprops = nullptr;    // merged proposals [S][budget_cap][KB_PROP_W]
     int32_t* d_mcounts = nullptr;  // [S]
     int32_t* d_taken = nullptr;    // [S]
-    int32_t* d_total = nullptr;    // [1]
+    int32_t* d_total = nullptr;    // [2] proposers of all ranks in the round; 1 when a rank marked its block as failed
     // histories of the resident loop (kb_history_begin)
     double* h_reward = nullptr;
     int16_t *h_resources = nullptr, *h_hits = nullptr, *h_adjusted = nullptr, *h_sla = nullptr, *h_violation = nullptr;
@@ -75,6 +75,8 @@ static int kalloc(kb_handle* k, Tp** p, size_t n, bool zero = true) {
 // shared-dictionary mode, on the agent's own HIP stream, between device buffers.  librccl.so is opened on first
 // use, so libranslice.so itself has no link-time dependency on it (replica-sharded runs never need it).
 #include <dlfcn.h>
+#include <chrono>
+#include <unistd.h>
 namespace rccl {
 typedef struct { char internal[128]; } UniqueId;
 typedef int (*GetUniqueId_t)(UniqueId*);
@@ -82,7 +84,11 @@ typedef int (*CommInitRank_t)(void**, int, UniqueId, int);
 typedef int (*CommDestroy_t)(void*);
 typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*GetErrorString_t)(int);
+typedef int (*CommAbort_t)(void*);
+typedef int (*CommGetAsyncError_t)(void*, int*);
 static void* lib = nullptr;
+static CommAbort_t CommAbort = nullptr;
+static CommGetAsyncError_t CommGetAsyncError = nullptr;
 static GetUniqueId_t GetUniqueId = nullptr;
 static CommInitRank_t CommInitRank = nullptr;
 static CommDestroy_t CommDestroy = nullptr;
@@ -94,14 +100,21 @@ static bool load() {
     // RANSLICE_RCCL_LIB names the library to bind (a process that has already loaded an RCCL of its own -- e.g. through
     // torch.distributed's nccl backend -- should point this at the same file so that one copy serves both)
     const char* names[] = {getenv("RANSLICE_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // one copy per process: a library of that name the process has already mapped (torch.distributed's nccl backend brings
+    // its own) is taken as it is -- RTLD_NOLOAD finds it without loading anything -- before a second one would be opened
     for (const char* n : names)
-        if (n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+        if (n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) break;
+    if (!lib)
+        for (const char* n : names)
+            if (n && (lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
     if (!lib) return false;
     GetUniqueId = (GetUniqueId_t)dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (CommInitRank_t)dlsym(lib, "ncclCommInitRank");
     CommDestroy = (CommDestroy_t)dlsym(lib, "ncclCommDestroy");
     AllGather = (AllGather_t)dlsym(lib, "ncclAllGather");
     GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
+    CommAbort = (CommAbort_t)dlsym(lib, "ncclCommAbort");                          // (optional: the abort path)
+    CommGetAsyncError = (CommGetAsyncError_t)dlsym(lib, "ncclCommGetAsyncError");  // (optional)
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather) {
         dlclose(lib);
         lib = nullptr;
@@ -298,7 +311,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_mprops, (size_t)cfg->n_slices * k->budget_cap * KB_PROP_W, true);
     KA(k->d_mcounts, (size_t)cfg->n_slices, true);
     KA(k->d_taken, (size_t)cfg->n_slices, true);
-    KA(k->d_total, 1, true);
+    KA(k->d_total, 2, true);
 #undef KA
     if (D.shared) {
         // shared_apply_kernel keeps the coefficient column of a full dictionary and the proposals' Gram block in LDS
@@ -968,14 +981,56 @@ extern "C" int kb_shared_commit(kb_handle* k, const int32_t* n_accept) {
 // (whether any rank still had proposals; not even that after the last permitted round when rounds_out is NULL).
 // Without kb_comm_init the handle is its own world.
 // the rounds of one shared learning step on device buffers (state / action / labels of the local replicas)
+// Wait for the agent's stream.  With a communicator the wait is bounded: while the stream is busy the communicator is asked
+// for an asynchronous error (a peer that died: ncclCommGetAsyncError) and a clock runs (KBRL_COLLECTIVE_TIMEOUT_S, default
+// 120 s); either one aborts the communicator (ncclCommAbort) and returns RS_EHIP instead of leaving the rank in the
+// collective for an outside watchdog to find.
+static int shared_wait(kb_handle* k) {
+    if (!k->comm) {
+        HIPCHK(k, hipStreamSynchronize(k->stream));
+        return RS_OK;
+    }
+    static const double limit = getenv("KBRL_COLLECTIVE_TIMEOUT_S") ? atof(getenv("KBRL_COLLECTIVE_TIMEOUT_S")) : 120.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(k->stream);
+        if (q == hipSuccess) return RS_OK;
+        const char* why = nullptr;
+        int async_err = 0;
+        if (q != hipErrorNotReady) why = hipGetErrorString(q);
+        else if (rccl::CommGetAsyncError && rccl::CommGetAsyncError(k->comm, &async_err) == 0 && async_err != 0)
+            why = rccl::GetErrorString ? rccl::GetErrorString(async_err) : "asynchronous RCCL error";
+        else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+            why = "no answer from the other ranks within KBRL_COLLECTIVE_TIMEOUT_S";
+        if (why) {
+            k->err = std::string("kb_shared_step: the exchange did not complete (") + why + "); communicator aborted";
+            if (rccl::CommAbort) (void)rccl::CommAbort(k->comm);
+            k->comm = nullptr;  // (aborted: kb_comm_init forms a new one)
+            return RS_EHIP;
+        }
+        usleep(50);
+    }
+}
+
+// the rounds of one shared learning step on device buffers (state / action / labels of the local replicas)
 static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d_action, const int32_t* d_labels, int32_t budget,
                             int32_t max_rounds, int32_t* hits_host, int32_t* rounds_out) {
     const size_t T = (size_t)k->T, S = (size_t)k->cfg.n_slices;
     const int W = k->comm ? k->comm_world : 1, me = k->comm ? k->comm_rank : 0;
     const size_t blk = S * (1 + (size_t)budget * KB_PROP_W);
-    if (!k->d_gather) HIPCHK(k, hipMalloc((void**)&k->d_gather, sizeof(double) * S * (1 + (size_t)k->budget_cap * KB_PROP_W) * (size_t)W));
+    // test knob: behave as if this rank's round r had failed locally (the abort path below, without breaking anything)
+    const int inject = getenv("KBRL_INJECT_FAIL_ROUND") ? atoi(getenv("KBRL_INJECT_FAIL_ROUND")) : -1;
     int rounds = 0;
     for (int rnd = 0; rnd < max_rounds; ++rnd) {
+        // ---- this rank's part of the round.  A failure here (an allocation, a launch) must not leave the other ranks waiting
+        // in the collective: the rank still takes part in the all-gather, with the failure mark in the place of its counts, and
+        // every rank -- this one included -- learns of it from the merge kernel and returns RS_EHIP after the same round.
+        std::string local_err;
+        auto local = [&](hipError_t e, const char* what) {
+            if (e != hipSuccess && local_err.empty()) local_err = std::string(what) + ": " + hipGetErrorString(e);
+        };
+        if (!k->d_gather)
+            local(hipMalloc((void**)&k->d_gather, sizeof(double) * S * (1 + (size_t)k->budget_cap * KB_PROP_W) * (size_t)W), "hipMalloc of the gather buffer");
         kb::ScanArgs a;
         a.D = k->D;
         a.K = k->K;
@@ -986,39 +1041,63 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         a.cursor = k->d_cursor;
         a.cstar = k->d_cstar;
         a.round = rnd;
-        hipEvent_t e1;
-        int rc = kb_time_begin(k, &e1);
-        if (rc != RS_OK) return rc;
+        hipEvent_t e1 = nullptr;
+        if (kb_time_begin(k, &e1) != RS_OK) local(hipErrorUnknown, "event for the kernel timing");
         // (resident loop, round 0: select_action of the previous step scored this very state against these very dictionaries)
         if (!(rnd == 0 && k->gemm_fresh && d_state == k->d_prev_state)) launch_shared_gemm(k, a.state);
         k->gemm_fresh = false;
         hipLaunchKernelGGL(kb::shared_scan_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a);
-        if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
+        if (e1) local(hipEventRecord(e1, k->stream), "hipEventRecord");
         hipLaunchKernelGGL(kb::shared_collect_block_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, d_state,
                            d_labels, k->d_cstar, (int)budget, k->d_block);
-        if (rnd == 0 && hits_host) HIPCHK(k, hipMemcpyAsync(hits_host, k->d_hits, sizeof(int32_t) * T, hipMemcpyDeviceToHost, k->stream));
+        if (rnd == 0 && hits_host) local(hipMemcpyAsync(hits_host, k->d_hits, sizeof(int32_t) * T, hipMemcpyDeviceToHost, k->stream), "copy of the hits");
+        local(hipGetLastError(), "launch of the scan kernels");
+        if (rnd == inject) local_err = "failure injected by KBRL_INJECT_FAIL_ROUND";
+        if (!local_err.empty() && k->d_gather) {
+            static const double mark[KB_MAX_SLICES] = {-1.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0};
+            (void)hipMemcpyAsync(k->d_block, mark, sizeof(double) * S, hipMemcpyHostToDevice, k->stream);
+        }
+        if (!k->d_gather) {  // nothing to gather into: this rank cannot even say so
+            k->err = "kb_shared_step: " + local_err;
+            if (k->comm && rccl::CommAbort) {
+                (void)rccl::CommAbort(k->comm);
+                k->comm = nullptr;
+            }
+            return RS_EHIP;
+        }
         if (k->comm) {
             const int nrc = rccl::AllGather(k->d_block, k->d_gather, blk, rccl::kDouble, k->comm, k->stream);
             if (nrc != 0) {
                 k->err = std::string("ncclAllGather: ") + (rccl::GetErrorString ? rccl::GetErrorString(nrc) : "error");
+                if (rccl::CommAbort) (void)rccl::CommAbort(k->comm);
+                k->comm = nullptr;
                 return RS_EHIP;
             }
         } else {
             HIPCHK(k, hipMemcpyAsync(k->d_gather, k->d_block, sizeof(double) * blk, hipMemcpyDeviceToDevice, k->stream));
         }
-        HIPCHK(k, hipMemsetAsync(k->d_total, 0, sizeof(int32_t), k->stream));
+        HIPCHK(k, hipMemsetAsync(k->d_total, 0, 2 * sizeof(int32_t), k->stream));
         hipLaunchKernelGGL(kb::shared_merge_kernel, dim3((unsigned)S), dim3(256), 0, k->stream, k->D, k->d_gather, W, me,
                            (int)budget, blk, k->d_mprops, k->d_mcounts, k->d_taken, k->d_total);
         launch_shared_apply(k, k->d_mprops, k->d_mcounts, (int)budget);
         hipLaunchKernelGGL(kb::shared_commit_kernel, dim3((unsigned)S), dim3(KB_RANK_THREADS), 0, k->stream, k->D, k->d_cstar, k->d_taken,
                            k->d_cursor);
         HIPCHK(k, hipGetLastError());
-        // the last permitted round decides nothing: without a caller asking for the count the host does not wait for it
-        if (rnd + 1 == max_rounds && !rounds_out) break;
-        int32_t total = 0;
-        HIPCHK(k, hipMemcpyAsync(&total, k->d_total, sizeof total, hipMemcpyDeviceToHost, k->stream));
-        HIPCHK(k, hipStreamSynchronize(k->stream));
-        if (total == 0) break;  // identical on every rank: all ranks leave together
+        // the last permitted round decides nothing: a single-rank handle whose caller does not ask for the count does not wait
+        // for it (with other ranks in the step the failure flag is read after every round, so that all leave together)
+        if (rnd + 1 == max_rounds && !rounds_out && !k->comm && local_err.empty()) break;
+        int32_t total[2] = {0, 0};
+        HIPCHK(k, hipMemcpyAsync(total, k->d_total, sizeof total, hipMemcpyDeviceToHost, k->stream));
+        const int wrc = shared_wait(k);
+        if (wrc != RS_OK) return wrc;
+        if (total[1] != 0 || !local_err.empty()) {
+            k->err = !local_err.empty() ? "kb_shared_step: this rank failed in round " + std::to_string(rnd) + " (" + local_err +
+                                              "); the other ranks were told through the exchange and leave the step with it"
+                                        : "kb_shared_step: another rank of the shared-dictionary group reported a failure in round " +
+                                              std::to_string(rnd) + "; all ranks leave the step together";
+            return RS_EHIP;
+        }
+        if (total[0] == 0) break;  // identical on every rank: all ranks leave together
         rounds = rnd + 1;
     }
     if (rounds_out) *rounds_out = rounds;
@@ -1031,8 +1110,9 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
 // until no rank proposes anything or max_rounds is reached.  Only one 4-byte flag per round returns to the host
 // (whether any rank still had proposals).  Without kb_comm_init the handle is its own world.
 // Every argument is validated BEFORE the first collective, so a rank that refuses its input never leaves the others
-// waiting in ncclAllGather; a HIP error in the middle of the rounds is not recoverable on any rank (the process group's
-// own watchdog / the launcher ends the job).
+// waiting in ncclAllGather.  A failure in the middle of the rounds travels with the exchange: the failing rank still
+// contributes a block, marked, and every rank returns RS_EHIP after that round (shared_step_core); a rank that has stopped
+// answering altogether is met by a bounded wait and ncclCommAbort (shared_wait).
 extern "C" int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels,
                               int32_t budget, int32_t max_rounds, int32_t* hits, int32_t* rounds_out) {
     if (!k || !state || !action || !labels || budget <= 0 || max_rounds <= 0) return RS_EINVAL;
@@ -1106,7 +1186,7 @@ extern "C" int kb_shared_merge(kb_handle* k, const double* gathered, int32_t wor
     HIPCHK(k, hipMalloc((void**)&d_g, sizeof(double) * blk * (size_t)world));
     int rc = RS_OK;
     hipError_t e = hipMemcpyAsync(d_g, gathered, sizeof(double) * blk * (size_t)world, hipMemcpyHostToDevice, k->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(k->d_total, 0, sizeof(int32_t), k->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(k->d_total, 0, 2 * sizeof(int32_t), k->stream);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(kb::shared_merge_kernel, dim3((unsigned)S), dim3(256), 0, k->stream, k->D, d_g, (int)world, (int)me,
                            (int)budget, blk, k->d_mprops, k->d_mcounts, k->d_taken, k->d_total);

@@ -2312,7 +2312,8 @@ __global__ __launch_bounds__(KB_RANK_THREADS) void shared_collect_block_kernel(K
 
 // Merge the gathered blocks of all W ranks for slice s = blockIdx.x: ascending global replica id, the first `budget`
 // (the rule of kbrl_dev.merge_proposals, evaluated where the data is).  taken[s] = how many of rank `me`'s proposers
-// made it; total[0] += proposers of all ranks (0 ends the learning step).
+// made it; total[0] += proposers of all ranks (0 ends the learning step); total[1] = 1 when a rank's block carries the
+// failure mark (a negative count: kb_shared_step's abort path).
 __global__ __launch_bounds__(256) void shared_merge_kernel(KbDev D, const double* gathered, int W, int me, int budget,
                                                            size_t blk_doubles, double* mprops, int32_t* mcounts,
                                                            int32_t* taken, int32_t* total) {
@@ -2321,9 +2322,13 @@ __global__ __launch_bounds__(256) void shared_merge_kernel(KbDev D, const double
     __shared__ int off_of[65];
     __shared__ int s_taken, s_all;
     if (threadIdx.x == 0) {
-        int o = 0, all = 0;
+        int o = 0, all = 0, failed = 0;
         for (int w = 0; w < W; ++w) {
-            const int c = (int)gathered[(size_t)w * blk_doubles + s];
+            int c = (int)gathered[(size_t)w * blk_doubles + s];
+            if (c < 0) {  // a rank that could not complete its round says so in the place of its count: every rank sees it here
+                failed = 1;
+                c = 0;
+            }
             all += c;
             n_of[w] = c < budget ? c : budget;
             off_of[w] = o;
@@ -2332,6 +2337,7 @@ __global__ __launch_bounds__(256) void shared_merge_kernel(KbDev D, const double
         off_of[W] = o;
         s_taken = 0;
         s_all = all;
+        if (failed) atomicOr(&total[1], 1);
     }
     __syncthreads();
     const int n = off_of[W];

@@ -11,6 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
+from ranslice import _lib  # noqa: E402
 from ranslice.kbrl_dev import SharedVecKBRL  # noqa: E402
 
 
@@ -66,8 +67,17 @@ def main():
         agent.comm_init(uid, rank, world)
     agent.reset(ia[lo:hi], sf[lo:hi])
     acts = []
-    for state, action, labels, nxt in seq:
-        agent.update_control(state[lo:hi], action[lo:hi], labels[lo:hi])
+    fail_rank, fail_step = int(os.environ.get('FAIL_RANK', '-1')), int(os.environ.get('FAIL_STEP', '-1'))
+    for i, (state, action, labels, nxt) in enumerate(seq):
+        if rank == fail_rank and i == fail_step:
+            os.environ['KBRL_INJECT_FAIL_ROUND'] = '0'   # this rank's round 0 "fails" (kb_api.hip: shared_step_core)
+        try:
+            agent.update_control(state[lo:hi], action[lo:hi], labels[lo:hi])
+        except _lib.RanSliceError as e:
+            # every rank of the group must get here at the same step, told by the exchange itself
+            print('FAILED %d step %d: %s' % (rank, i, e), flush=True)
+            agent.close()
+            sys.exit(3)
         a, _ = agent.select_action(nxt[lo:hi])
         acts.append(a)
     d, sizes = digest(agent)

@@ -55,3 +55,39 @@ def test_rank_count_must_match(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert 'WORLD_SIZE' in str(e.value.code)
+
+
+def test_scaling_report_runs_end_to_end_on_a_one_gpu_box(monkeypatch, capsys):
+    """python bench.py --scaling 1,2 on a box with ONE device: the N=1 point is a child run of this script (intercepted: its
+    line is supplied), N=2 is listed as skipped with the reason, the CPU baseline is in the same line (VERDICT r3 #6c)."""
+    import json
+    import types
+    bench = _load_bench()
+    from ranslice import _lib
+    monkeypatch.setattr(_lib, 'device_count', lambda: 1)
+    monkeypatch.setattr(bench, 'cpu_baseline', lambda burn, timed: {'value': 2.0e4, 'unit': 'env-steps/s', 'cores': 16,
+                                                                   'kind': 'port', 'sample': 'stub', 'single_core_value': 1.5e3})
+    seen = []
+
+    def fake_run(cmd, env=None, stdout=None, text=None):
+        seen.append((list(cmd), dict(env or {})))
+        n = int(cmd[cmd.index('--gpus') + 1])
+        line = {'value': 3.6e6 * n, 'ms_per_step': 1.13, 'roofline': {'frac': 0.104, 'kernel_ms': 1.1},
+                'config': {'global_envs': 4096 * n}}
+        return types.SimpleNamespace(returncode=0, stdout='noise\n' + json.dumps(line) + '\n')
+    monkeypatch.setattr(bench.subprocess, 'run', fake_run)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--scaling', '1,2', '--steps', '50', '--warmup', '5'])
+    bench.main()
+    out = [x for x in capsys.readouterr().out.splitlines() if x.startswith('{')]
+    rep = json.loads(out[-1])
+    assert rep['scaling'] == 'weak' and rep['cpu_baseline']['cores'] == 16 and rep['unit'] == 'env-steps/s'
+    assert [c['n_gpus'] for c in rep['curve']] == [1, 2]
+    one, two = rep['curve']
+    assert one['value'] == 3.6e6 and one['per_gpu_vs_1gpu'] == 1.0 and one['global_envs'] == 4096
+    assert 'value' not in two and '1 GPU' in two['skipped']
+    assert len(seen) == 1                                   # only N = 1 was launched
+    cmd, env = seen[0]
+    assert cmd[cmd.index('--gpus') + 1] == '1' and '--no-cpu-baseline' in cmd and '--no-kbrl' in cmd
+    assert 'RANK' not in env and 'WORLD_SIZE' not in env

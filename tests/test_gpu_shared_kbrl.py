@@ -330,6 +330,50 @@ def test_device_exchange_two_ranks_over_rccl(tmp_path):
     assert _result(two[0][1]) == _result(two[1][1]) == _result(whole[0][1])
 
 
+def test_failure_in_a_round_leaves_the_step_through_the_exchange(monkeypatch, tmp_path):
+    """kb_shared_step's abort path (VERDICT r3 #6a): a rank whose round fails locally still takes part in the all-gather, with
+    a mark in the place of its proposer counts; the merge kernel shows the mark to every rank and all of them return RS_EHIP
+    after that same round -- nobody stays behind in the collective.  Here: one handle (its own world) with the failure
+    injected in round 1 of a step, in process and through a real one-rank RCCL communicator; the handle goes on working
+    afterwards.  The two-rank case runs where two GPUs are visible (below)."""
+    from ranslice import _lib
+    from ranslice.kbrl_dev import SharedVecKBRL
+    sys_path_worker = os.path.join(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('rccl_worker', os.path.join(sys_path_worker, 'shared_rccl_worker.py'))
+    wk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(wk)
+    ia, sf, seq = wk.batch(16, 5)
+    ag = SharedVecKBRL(16, [10] * 5, 200, capacity=256, budget=16, max_rounds=3)
+    ag.reset(ia, sf)
+    for i, (state, action, labels, nxt) in enumerate(seq):
+        if i == 2:
+            monkeypatch.setenv('KBRL_INJECT_FAIL_ROUND', '1')
+            with pytest.raises(_lib.RanSliceError) as e:
+                ag.update_control(state, action, labels)
+            assert 'failed in round 1' in str(e.value) and 'leave the step' in str(e.value), str(e.value)
+            monkeypatch.delenv('KBRL_INJECT_FAIL_ROUND')
+            continue
+        ag.update_control(state, action, labels)      # before and after the failed step: business as usual
+        ag.select_action(nxt)
+    assert ag.dictionary_sizes().sum() > 0
+    ag.close()
+    out = _run_ranks(1, 16, 6, tmp_path, {'RCCL_WORLD1': '1', 'FAIL_RANK': '0', 'FAIL_STEP': '3'})
+    assert out[0][0] == 3 and 'FAILED 0 step 3' in out[0][1], (out[0][1][-500:], out[0][2][-1500:])
+
+
+def test_failure_on_one_of_two_ranks_ends_both(tmp_path):
+    """two ranks over RCCL, rank 1's round fails at step 3: BOTH ranks leave kb_shared_step with RS_EHIP at step 3 (skipped
+    -- not verified -- where RCCL cannot form a two-rank communicator: one GPU)"""
+    two = _run_ranks(2, 8, 6, tmp_path, {'FAIL_RANK': '1', 'FAIL_STEP': '3', 'KBRL_COLLECTIVE_TIMEOUT_S': '60'})
+    err = ' '.join(e[-400:] for _, _, e in two)
+    if any('ncclCommInitRank' in e or 'Duplicate' in e or 'invalid usage' in e for _, _, e in two):
+        pytest.skip('RCCL does not form a 2-rank communicator on a single device: %s' % err[-300:])
+    for r, (rc, o, e) in enumerate(two):
+        assert rc == 3 and ('FAILED %d step 3' % r) in o, (r, rc, o[-500:], e[-1500:])
+    assert 'this rank failed' in two[1][1] and 'another rank' in two[0][1]
+
+
 def test_shared_resident_loop_equals_host_loop():
     """kb_shared_step_resident (the shared learning step and select_action on the simulator's own device buffers) == the
     same closed loop driven through host buffers (env.step / update_control / select_action): selected actions at every
