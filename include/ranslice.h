@@ -177,6 +177,13 @@ int rs_synchronize(rs_handle* h);
 /* HIP devices visible to this process, or RS_EHIP */
 int rs_device_count(void);
 int rs_n_vars(const rs_handle* h);
+/* Checkpoint / restore (no reference counterpart: a run of experiments_kbrl.py that dies starts over).  The state of a handle
+ * -- every device array behind it except the tables (fading traces, constants), plus its slot clock -- as one blob of
+ * rs_state_bytes bytes; rs_load_state accepts a blob saved by a handle of the same configuration, on any device.  Loading
+ * and stepping on reproduces the steps the saving handle would have made, bit for bit. */
+int rs_state_bytes(rs_handle* h, uint64_t* bytes);
+int rs_save_state(rs_handle* h, void* blob, uint64_t bytes);
+int rs_load_state(rs_handle* h, const void* blob, uint64_t bytes);
 int rs_n_slices(const rs_handle* h);
 const char* rs_last_error(const rs_handle* h);
 void rs_destroy(rs_handle* h);
@@ -310,6 +317,12 @@ int kb_set_kernel_timing(kb_handle* k, int enable);
 /* mean duration of one launch of the two kernels that stream Kinv in the repair rounds -- ms[0] / n[0] the mat-vec, ms[1] /
  * n[1] the rank-1 update -- over the span the last kb_phase_times_ms call covered (for their HBM roofline) */
 int kb_repair_times_ms(kb_handle* k, double ms[2], int64_t n[2]);
+/* Checkpoint / restore of the agents: the per-learner tables, the control state, the part of the dictionary pool in use and
+ * the recorded histories, as one blob (kb_state_bytes waits for the stream and sizes it); kb_load_state takes a blob saved by
+ * a handle of the same configuration whose pool is no larger than this handle's. */
+int kb_state_bytes(kb_handle* k, uint64_t* bytes);
+int kb_save_state(kb_handle* k, void* blob, uint64_t bytes);
+int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes);
 /* waits for the agent's stream and reports an internal error flag raised by any kernel since kb_reset (the
  * device-resident loop kb_step_resident does not check on its own); dictionaries at capacity are not errors (kb_get_pool) */
 int kb_synchronize(kb_handle* k);

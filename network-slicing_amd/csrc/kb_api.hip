@@ -12,6 +12,7 @@ struct kb_handle {
     kb::KbState K;
     std::vector<void*> allocs;
     std::vector<GuardedAlloc> guarded;
+    std::vector<std::pair<void*, size_t>> regions;  // every device array behind the handle (kb_save_state)
     float* d_state = nullptr;      // staging for host-provided states
     float* d_prev_state = nullptr; // resident loop: obs the executed action was chosen in
     int32_t* d_action = nullptr;
@@ -66,6 +67,7 @@ static int kalloc(kb_handle* k, Tp** p, size_t n, bool zero = true) {
     HIPCHK(k, guarded_malloc(&q, bytes, &k->guarded));
     if (zero) HIPCHK(k, hipMemsetAsync(q, 0, bytes, k->stream));
     if (!guards_on()) k->allocs.push_back(q);
+    k->regions.emplace_back(q, bytes);
     *p = (Tp*)q;
     return RS_OK;
 }
@@ -1254,4 +1256,120 @@ extern "C" int kb_history_fetch(kb_handle* k, double* reward, int16_t* resources
     HIPCHK(k, hipStreamSynchronize(k->stream));
     if (n_recorded) *n_recorded = cur < k->h_steps ? cur : k->h_steps;
     return kb_check(k);
+}
+
+// ------------------------------------------------------------------ checkpoint / restore of the agents (with rs_save_state: a
+// long evaluation can be cut and resumed; the reference has no counterpart)
+// Everything behind the handle: the per-learner tables, the control state, the queues, and of the dictionary pool the part in
+// use (offsets inside the pool are relative, so a blob fits any handle of the same configuration and pool size).  The
+// histories of kb_history_begin travel too.
+struct kb_state_header {
+    uint64_t magic, n_regions, cfg_hash, pool_doubles_used, hist_steps, total_bytes;
+    int32_t big_par, is_reset, seen0, seen1;
+};
+static const uint64_t kKbStateMagic = 0x4b42534c49434534ull;
+static uint64_t kb_cfg_hash(const kb_handle* k) {
+    uint64_t x = 1469598103934665603ull;
+    const unsigned char* p = (const unsigned char*)&k->cfg;
+    for (size_t i = 0; i < sizeof k->cfg; ++i) x = (x ^ p[i]) * 1099511628211ull;
+    for (auto& r : k->regions) x = (x ^ (uint64_t)r.second) * 1099511628211ull;
+    return x;
+}
+static size_t kb_hist_bytes(const kb_handle* k, size_t part[7]) {
+    const size_t n = (size_t)k->cfg.n_envs * (size_t)k->h_steps, S = (size_t)k->cfg.n_slices;
+    const size_t b[7] = {sizeof(double) * n, 2 * n, 2 * n * S, 2 * n, 2 * n, 2 * n, sizeof(int32_t)};
+    size_t t = 0;
+    for (int i = 0; i < 7; ++i) {
+        part[i] = k->h_steps > 0 ? b[i] : 0;
+        t += part[i];
+    }
+    return t;
+}
+static int kb_pool_used(kb_handle* k, unsigned long long* top) {
+    HIPCHK(k, hipMemcpy(top, k->K.pool_top, sizeof *top, hipMemcpyDeviceToHost));
+    if (*top > k->D.pool_doubles) *top = k->D.pool_doubles;
+    return RS_OK;
+}
+extern "C" int kb_state_bytes(kb_handle* k, uint64_t* bytes) {
+    if (!k || !bytes) return RS_EINVAL;
+    HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    unsigned long long top = 0;
+    int rc = kb_pool_used(k, &top);
+    if (rc != RS_OK) return rc;
+    size_t part[7];
+    uint64_t t = sizeof(kb_state_header) + kb_hist_bytes(k, part);
+    for (auto& r : k->regions) t += r.first == (void*)k->K.pool ? (uint64_t)top * 8 : (uint64_t)r.second;
+    *bytes = t;
+    return RS_OK;
+}
+extern "C" int kb_save_state(kb_handle* k, void* blob, uint64_t bytes) {
+    uint64_t need = 0;
+    if (!k || !blob) return RS_EINVAL;
+    int rc = kb_state_bytes(k, &need);
+    if (rc != RS_OK) return rc;
+    if (bytes < need) {
+        k->err = "kb_save_state: buffer smaller than kb_state_bytes";
+        return RS_EINVAL;
+    }
+    unsigned long long top = 0;
+    if ((rc = kb_pool_used(k, &top)) != RS_OK) return rc;
+    kb_state_header hd = {kKbStateMagic, (uint64_t)k->regions.size(), kb_cfg_hash(k), (uint64_t)top, (uint64_t)k->h_steps, need,
+                          k->big_par, k->is_reset ? 1 : 0, k->h_seen ? k->h_seen[0] : 0, k->h_seen ? k->h_seen[1] : 0};
+    memcpy(blob, &hd, sizeof hd);
+    char* o = (char*)blob + sizeof hd;
+    for (auto& r : k->regions) {
+        const size_t b = r.first == (void*)k->K.pool ? (size_t)top * 8 : r.second;
+        HIPCHK(k, hipMemcpy(o, r.first, b, hipMemcpyDeviceToHost));
+        o += b;
+    }
+    size_t part[7];
+    (void)kb_hist_bytes(k, part);
+    void* hp[7] = {k->h_reward, k->h_resources, k->h_hits, k->h_adjusted, k->h_sla, k->h_violation, k->h_cursor};
+    for (int i = 0; i < 7; ++i)
+        if (part[i]) {
+            HIPCHK(k, hipMemcpy(o, hp[i], part[i], hipMemcpyDeviceToHost));
+            o += part[i];
+        }
+    return RS_OK;
+}
+extern "C" int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes) {
+    if (!k || !blob || bytes < sizeof(kb_state_header)) return RS_EINVAL;
+    kb_state_header hd;
+    memcpy(&hd, blob, sizeof hd);
+    if (hd.magic != kKbStateMagic || hd.n_regions != k->regions.size() || hd.cfg_hash != kb_cfg_hash(k) ||
+        hd.pool_doubles_used > k->D.pool_doubles || bytes < hd.total_bytes) {
+        k->err = "kb_load_state: the blob was not saved by a handle of this configuration (or its pool is larger than this one's)";
+        return RS_EINVAL;
+    }
+    HIPCHK(k, hipSetDevice(k->device));
+    HIPCHK(k, hipStreamSynchronize(k->stream));
+    if (hd.hist_steps != (uint64_t)k->h_steps) {
+        int rc = hd.hist_steps ? kb_history_begin(k, (int32_t)hd.hist_steps) : RS_OK;
+        if (rc != RS_OK) return rc;
+        if (!hd.hist_steps) kb_history_release(k);
+        HIPCHK(k, hipStreamSynchronize(k->stream));
+    }
+    const char* o = (const char*)blob + sizeof hd;
+    for (auto& r : k->regions) {
+        const size_t b = r.first == (void*)k->K.pool ? (size_t)hd.pool_doubles_used * 8 : r.second;
+        HIPCHK(k, hipMemcpy(r.first, o, b, hipMemcpyHostToDevice));
+        o += b;
+    }
+    size_t part[7];
+    (void)kb_hist_bytes(k, part);
+    void* hp[7] = {k->h_reward, k->h_resources, k->h_hits, k->h_adjusted, k->h_sla, k->h_violation, k->h_cursor};
+    for (int i = 0; i < 7; ++i)
+        if (part[i]) {
+            HIPCHK(k, hipMemcpy(hp[i], o, part[i], hipMemcpyHostToDevice));
+            o += part[i];
+        }
+    k->big_par = hd.big_par;
+    k->is_reset = hd.is_reset != 0;
+    if (k->h_seen) {
+        k->h_seen[0] = hd.seen0;
+        k->h_seen[1] = hd.seen1;
+    }
+    k->gemm_fresh = false;
+    return RS_OK;
 }

@@ -79,6 +79,7 @@ struct rs_handle {
     MtcState mst;
     std::vector<void*> allocs;
     std::vector<GuardedAlloc> guarded;
+    std::vector<std::pair<void*, size_t>> regions;  // every device array behind the handle but the tables (rs_save_state)
     double* fad = nullptr;
     uint8_t* fad_valid = nullptr;
     bool fad_loaded[RS_N_TRACES] = {false, false, false};
@@ -144,6 +145,7 @@ static int dalloc(rs_handle* h, T** p, size_t n) {
     HIPCHK(h, guarded_malloc(&q, bytes, &h->guarded));
     HIPCHK(h, hipMemsetAsync(q, 0, bytes, h->stream));
     if (!guards_on()) h->allocs.push_back(q);
+    h->regions.emplace_back(q, bytes);
     *p = (T*)q;
     return RS_OK;
 }
@@ -1121,6 +1123,83 @@ extern "C" int rs_synchronize(rs_handle* h) {
     if (!h) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    return RS_OK;
+}
+
+// ------------------------------------------------------------------ checkpoint / restore (the reference has
+// none -- a run of experiments_kbrl.py that dies starts over; here a 50,400-step evaluation can be cut and resumed)
+// The state of a handle is every device array behind it (the structure-of-arrays simulator state, the outputs of the last
+// step, the counters, the launch-order scratch) plus a few host words; the tables (fading traces, constants) are inputs and
+// are not saved.  A blob only fits a handle of the same configuration (checked).
+struct rs_state_header {
+    uint64_t magic, n_regions, total_bytes, cfg_hash;
+    int64_t clock, steps;
+    int32_t order_par, graph_par, block_hint, hint_auto, is_reset, pad;
+};
+static const uint64_t kRsStateMagic = 0x52534c4943453034ull;  // "RSLICE04"
+static uint64_t rs_cfg_hash(const rs_handle* h) {
+    uint64_t x = 1469598103934665603ull;
+    const unsigned char* p = (const unsigned char*)&h->cfg;
+    for (size_t i = 0; i < sizeof h->cfg; ++i) x = (x ^ p[i]) * 1099511628211ull;
+    for (auto& r : h->regions) x = (x ^ (uint64_t)r.second) * 1099511628211ull;
+    return x;
+}
+extern "C" int rs_state_bytes(rs_handle* h, uint64_t* bytes) {
+    if (!h || !bytes) return RS_EINVAL;
+    uint64_t t = sizeof(rs_state_header);
+    for (auto& r : h->regions) t += r.second;
+    *bytes = t;
+    return RS_OK;
+}
+extern "C" int rs_save_state(rs_handle* h, void* blob, uint64_t bytes) {
+    uint64_t need = 0;
+    if (!h || !blob || rs_state_bytes(h, &need) != RS_OK) return RS_EINVAL;
+    if (bytes < need) {
+        h->err = "rs_save_state: buffer smaller than rs_state_bytes";
+        return RS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    rs_state_header hd = {kRsStateMagic, (uint64_t)h->regions.size(), need, rs_cfg_hash(h), (int64_t)h->clock, (int64_t)h->steps,
+                          h->order_par, h->graph_par, h->block_hint, h->hint_auto ? 1 : 0, h->is_reset ? 1 : 0, 0};
+    memcpy(blob, &hd, sizeof hd);
+    char* o = (char*)blob + sizeof hd;
+    for (auto& r : h->regions) {
+        HIPCHK(h, hipMemcpy(o, r.first, r.second, hipMemcpyDeviceToHost));
+        o += r.second;
+    }
+    return RS_OK;
+}
+extern "C" int rs_load_state(rs_handle* h, const void* blob, uint64_t bytes) {
+    uint64_t need = 0;
+    if (!h || !blob || rs_state_bytes(h, &need) != RS_OK) return RS_EINVAL;
+    rs_state_header hd;
+    if (bytes < sizeof hd) return RS_EINVAL;
+    memcpy(&hd, blob, sizeof hd);
+    if (hd.magic != kRsStateMagic || hd.n_regions != h->regions.size() || hd.total_bytes != need || bytes < need ||
+        hd.cfg_hash != rs_cfg_hash(h)) {
+        h->err = "rs_load_state: the blob was not saved by a handle of this configuration";
+        return RS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    drop_graph(h);
+    const char* o = (const char*)blob + sizeof hd;
+    for (auto& r : h->regions) {
+        if (r.first != (void*)h->ddev && r.first != (void*)h->d_st)  // (constants and the pointer table belong to THIS handle)
+            HIPCHK(h, hipMemcpy(r.first, o, r.second, hipMemcpyHostToDevice));
+        o += r.second;
+    }
+    h->clock = (int32_t)hd.clock;
+    h->steps = (uint64_t)hd.steps;
+    h->order_par = hd.order_par;
+    h->graph_par = hd.graph_par;
+    h->graph_sig = -1;
+    h->block_hint = hd.block_hint;
+    h->hint_auto = hd.hint_auto != 0;
+    h->is_reset = hd.is_reset != 0;
     return RS_OK;
 }
 #include "kb_api.hip"

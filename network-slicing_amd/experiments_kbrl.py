@@ -138,10 +138,43 @@ class BatchedEvaluator(Evaluator):
         self._ctx = None
         return files
 
-    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True):
+    def save_checkpoint(self, path, next_step):
+        """the cell's whole state (simulator + agents + the histories recorded so far) and the step to go on from"""
+        c = self._ctx
+        np.savez(path, next_step=np.int64(next_step), steps=np.int64(self.steps), runs=np.asarray(c['runs'], dtype=np.int64),
+                 env=c['env'].save_state(), agent=c['agent'].save_state())
+
+    def load_checkpoint(self, path):
+        """-> the step to go on from.  The cell must have been set up for the same runs, capacity and pool."""
+        z = np.load(path)
+        c = self._ctx
+        if int(z['steps']) != self.steps or list(z['runs']) != list(c['runs']):
+            raise ValueError('checkpoint %s belongs to another evaluation (steps / runs differ)' % path)
+        c['env'].load_state(z['env'])
+        c['agent'].load_state(z['agent'])
+        return int(z['next_step'])
+
+    def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True, checkpoint=None,
+                     checkpoint_every=0, stop_after=None):
+        """checkpoint: a .npz path.  If it exists the evaluation resumes from it; with checkpoint_every = k it is rewritten
+        every k steps (a 50,400-step evaluation that dies loses at most k steps -- the reference starts over).  stop_after = s
+        ends the call after step s - 1 with the checkpoint written and no result files (tests, planned interruptions)."""
         self._setup(runs, device=device, capacity=capacity, pool_bytes=pool_bytes)
-        for i in range(self.steps):
+        first = 0
+        ck = checkpoint if (checkpoint is None or checkpoint.endswith('.npz')) else checkpoint + '.npz'
+        if ck and os.path.exists(ck):
+            first = self.load_checkpoint(ck)
+        for i in range(first, self.steps):
             self._advance(i)
+            last = stop_after is not None and i + 1 == stop_after
+            if ck and (last or (checkpoint_every and (i + 1) % checkpoint_every == 0 and i + 1 < self.steps)):
+                self.save_checkpoint(ck, i + 1)
+            if last:
+                c = self._ctx
+                c['env'].close()
+                c['agent'].close()
+                self._ctx = None
+                return None
         return self._finish(verbose=verbose)
 
 

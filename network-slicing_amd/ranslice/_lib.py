@@ -13,13 +13,13 @@ RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
 KB_EXPORTS = (
     'kb_create', 'kb_destroy', 'kb_last_error', 'kb_reset', 'kb_update_control', 'kb_select_action',
     'kb_step_resident', 'kb_predict', 'kb_update', 'kb_get_learner', 'kb_get_control', 'kb_set_adjusted',
-    'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
+    'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_state_bytes', 'kb_save_state', 'kb_load_state', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
 )
 
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
     'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
-    'rs_set_kernel_timing', 'rs_synchronize', 'rs_device_count', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
+    'rs_set_kernel_timing', 'rs_synchronize', 'rs_state_bytes', 'rs_save_state', 'rs_load_state', 'rs_device_count', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
 ) + KB_EXPORTS
 
 
@@ -101,6 +101,10 @@ def load():
     L.kb_get_sizes.argtypes = [vp, ip]
     L.kb_get_pool.argtypes = [vp, up, up, ip, ip]
     L.kb_get_repair_work.argtypes = [vp, up]
+    for _n in ('rs', 'kb'):
+        getattr(L, _n + '_state_bytes').argtypes = [vp, up]
+        getattr(L, _n + '_save_state').argtypes = [vp, vp, C.c_uint64]
+        getattr(L, _n + '_load_state').argtypes = [vp, vp, C.c_uint64]
     L.kb_get_flags.argtypes = [vp, ip]
     L.kb_get_kernel_row.argtypes = [vp, C.c_int, C.c_int, ip, dp]
     L.kb_shared_scan.argtypes = [vp, fp, ip, ip, C.c_int32, C.c_int32, ip, ip, dp]

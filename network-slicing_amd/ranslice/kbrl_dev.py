@@ -206,6 +206,20 @@ class VecKBRL:
         return dict(update_ms=ms[0], select_ms=ms[1], n_update=n[0], n_select=n[1],
                     matvec_launch_ms=rm[0], rank1_launch_ms=rm[1], n_matvec=rn[0], n_rank1=rn[1])
 
+    def save_state(self):
+        """the handle's whole state as one uint8 array (kb_save_state): feed it to load_state of a handle of the same
+        configuration -- this one later, or a fresh one in another process -- and the run goes on bit for bit"""
+        n = C.c_uint64()
+        self._check(self.L.kb_state_bytes(self.h, C.byref(n)))
+        blob = np.empty(n.value, dtype=np.uint8)
+        self._check(self.L.kb_save_state(self.h, blob.ctypes.data_as(C.c_void_p), n.value))
+        return blob
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self.L.kb_load_state(self.h, blob.ctypes.data_as(C.c_void_p), blob.size))
+        self._hist_steps = int(np.frombuffer(blob[32:40].tobytes(), dtype=np.uint64)[0])  # kb_state_header.hist_steps
+
     def synchronize(self):
         self._check(self.L.kb_synchronize(self.h))
 

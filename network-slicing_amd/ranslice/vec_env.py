@@ -111,6 +111,19 @@ class VecRanSlice:
         return dict(actions=actions, obs=self._obs.copy(), reward=self._reward.copy(),
                     labels=self._labels.copy(), violations=self._viol.copy())
 
+    def save_state(self):
+        """the handle's whole state as one uint8 array (rs_save_state): feed it to load_state of a handle of the same
+        configuration -- this one later, or a fresh one in another process -- and the run goes on bit for bit"""
+        n = C.c_uint64()
+        self._check(self.L.rs_state_bytes(self.h, C.byref(n)))
+        blob = np.empty(n.value, dtype=np.uint8)
+        self._check(self.L.rs_save_state(self.h, blob.ctypes.data_as(C.c_void_p), n.value))
+        return blob
+
+    def load_state(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        self._check(self.L.rs_load_state(self.h, blob.ctypes.data_as(C.c_void_p), blob.size))
+
     def synchronize(self):
         self._check(self.L.rs_synchronize(self.h))
 

@@ -390,6 +390,90 @@ def test_batched_evaluator_equals_run_by_run(golden_dir, tmp_path):
     sc.set_fading(None)
 
 
+def test_checkpoint_and_resume(golden_dir, tmp_path):
+    """rs_save_state / kb_save_state: (1) a closed loop cut after 25 steps, restored into FRESH handles and continued, makes
+    the steps the uncut loop makes (observations, actions, dictionaries bit for bit); a blob of another configuration is
+    refused; (2) BatchedEvaluator.evaluate_all interrupted at step 35 and resumed from its checkpoint writes the result
+    files of the uninterrupted evaluation."""
+    import ctypes as C
+    import experiments_kbrl as ek
+    import scenario_creator as sc
+    from ranslice import _lib
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    fading = [g['t0'], g['t1'], g['t2']]
+    scenario, N = 1, 12
+    dims, n_prbs = _dims(scenario)
+    rng = np.random.default_rng(3)
+    ia = np.stack([np.concatenate([rng.integers(4, 20, 3), rng.integers(2, 10, 2)]) for _ in range(N)]).astype(np.int32)
+    sf = np.stack([np.concatenate([rng.integers(2, 8, 3), rng.integers(1, 4, 2)]) for _ in range(N)]).astype(np.int32)
+
+    def make(n=N):
+        env = VecRanSlice(n_envs=n, cfg=make_config(scenario, n_envs=n), fading=fading, seed=9)
+        ag = VecKBRL(n, dims, n_prbs, capacity=512, pool_bytes=256 << 20)
+        return env, ag
+
+    def loop(env, ag, k, out):
+        for _ in range(k):
+            ag.step_resident(env)
+            env.step_resident()
+            f = env.fetch()
+            out.append((f['obs'].copy(), f['actions'].copy(), f['reward'].copy()))
+    env, ag = make()
+    env.reset()
+    ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 2)
+    ag.history_begin(60)
+    env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+    whole = []
+    loop(env, ag, 25, whole)
+    blob_e, blob_a = env.save_state(), ag.save_state()
+    loop(env, ag, 35, whole)
+    hist_w = ag.history_fetch()
+    dict_w = [ag.learner(r, s, with_kinv=True) for r in (0, N - 1) for s in range(len(dims))]
+    env.close()
+    ag.close()
+    env2, ag2 = make()                       # fresh handles: nothing but the blobs carries over
+    env2.reset()
+    ag2.reset(ia * 0 + 1, sf * 0 + 1)
+    env2.load_state(blob_e)
+    ag2.load_state(blob_a)
+    cont = []
+    loop(env2, ag2, 35, cont)
+    for i in range(35):
+        for a, b in zip(whole[25 + i], cont[i]):
+            assert a.tobytes() == b.tobytes(), i
+    hist_c = ag2.history_fetch()
+    assert hist_c['recorded'] == hist_w['recorded'] == 60
+    for key in ('reward', 'resources', 'hits', 'adjusted', 'SLA', 'violation'):
+        assert (hist_c[key] == hist_w[key]).all(), key
+    dict_c = [ag2.learner(r, s, with_kinv=True) for r in (0, N - 1) for s in range(len(dims))]
+    for a, b in zip(dict_w, dict_c):
+        assert a['m'] == b['m'] and all(a[k].tobytes() == b[k].tobytes() for k in ('landmarks', 'coeff', 'kinv'))
+    env3, ag3 = make(n=N + 1)
+    with pytest.raises(_lib.RanSliceError):
+        env3.load_state(blob_e)
+    with pytest.raises(_lib.RanSliceError):
+        ag3.load_state(blob_a)
+    for h in (env2, ag2, env3, ag3):
+        h.close()
+    # ---- the evaluator: interrupted and resumed == uninterrupted
+    sc.set_fading(fading)
+    steps, runs = 60, [0, 1, 2, 3]
+    one = ek.BatchedEvaluator(0, [0.97, 0.99], steps=steps, out_dir=str(tmp_path / 'whole'))
+    files_w = one.evaluate_all(runs, verbose=False, pool_bytes=1 << 30)
+    two = ek.BatchedEvaluator(0, [0.97, 0.99], steps=steps, out_dir=str(tmp_path / 'cut'))
+    ck = str(tmp_path / 'cell.npz')
+    assert two.evaluate_all(runs, verbose=False, pool_bytes=1 << 30, checkpoint=ck, stop_after=35) is None and os.path.exists(ck)
+    files_c = ek.BatchedEvaluator(0, [0.97, 0.99], steps=steps, out_dir=str(tmp_path / 'cut')).evaluate_all(
+        runs, verbose=False, pool_bytes=1 << 30, checkpoint=ck)
+    for fa, fb in zip(files_w, files_c):
+        a, b = np.load(fa), np.load(fb)
+        for key in a.files:
+            assert (a[key] == b[key]).all(), key
+    sc.set_fading(None)
+
+
 def test_grid_of_cells_equals_cell_by_cell(golden_dir, tmp_path):
     """experiments_kbrl.evaluate_grid runs several (scenario, accuracy range) cells of the reference's experiment grid
     (experiments_kbrl.py:57-70) as ONE job -- every cell's environment and agents on streams of their own, advanced in the same
