@@ -541,6 +541,41 @@ def test_projectron_long_golden_to_790_landmarks(golden_dir):
     ag.close()
 
 
+def test_projectron_reference_golden_to_3000_landmarks(golden_dir):
+    """G17: the REFERENCE's Projectron driven to 3,000+ landmarks (12,400 samples) through kb_predict / kb_update -- the device
+    against the reference itself where long runs live, not only against the oracle: f within 1e-8 relative, every predicted
+    sign, branch and dictionary size exact, delta 1e-6; final landmarks exact, coefficients 1e-6, Kinv (diagonal, every 256th
+    row, four probe products) 1e-6 of its scale, symmetric bit for bit."""
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g17_projectron_3000')
+    xs = np.concatenate([g['state'].astype(np.float64), (g['a'].astype(np.float64) / 200)[:, None]], axis=1)
+    ys = g['y']
+    ag = VecKBRL(1, [10], 200, capacity=4096)
+    ag.reset([[10]], [[3]])
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, 0, xs[i])
+        fr = g['f'][i]
+        assert f == pytest.approx(fr, rel=1e-8, abs=TOL), i
+        if abs(fr) > 1e-7:
+            assert yp == g['ypred'][i], i
+        br, dl = ag.update(0, 0, xs[i], int(ys[i]))
+        assert br == g['branch'][i], (i, dl, g['delta'][i])
+        if br:
+            assert dl == pytest.approx(g['delta'][i], rel=1e-6, abs=1e-9), i
+        if i % 256 == 0 or i > len(xs) - 8:
+            assert ag.dictionary_sizes()[0, 0] == g['m'][i], i
+    L = ag.learner(0, 0, with_kinv=True)
+    assert L['m'] == g['m'][-1] >= 3000
+    np.testing.assert_array_equal(L['landmarks'], xs[g['branch'] == 2])
+    np.testing.assert_allclose(L['coeff'], g['coeff'], rtol=1e-6, atol=1e-8)
+    scale = np.abs(g['kinv_diag']).max()
+    np.testing.assert_allclose(L['kinv'][::256], g['kinv_rows'], rtol=1e-6, atol=1e-6 * scale)
+    np.testing.assert_allclose(np.diag(L['kinv']), g['kinv_diag'], rtol=1e-6, atol=1e-6 * scale)
+    np.testing.assert_allclose(L['kinv'] @ g['kinv_probes'], g['kinv_kp'], rtol=1e-6, atol=1e-6 * np.abs(g['kinv_kp']).max())
+    assert np.array_equal(L['kinv'], L['kinv'].T)
+    ag.close()
+
+
 @pytest.mark.parametrize('name,min_m,heavy_m,rounds', [('g15_kbrl_long_s0', 200, None, None), ('g15_kbrl_long_s0', 200, None, 3),
                                                        ('g16_kbrl_long_tdl_s0', 0, None, 2), ('g15_kbrl_long_s0', 200, 100, 1),
                                                        ('g16_kbrl_long_tdl_s0', 0, 1000000, None)])

@@ -162,6 +162,44 @@ def test_g14_projectron_long(golden_dir):
     assert ag.error() == 0
 
 
+def _g17_samples(g):
+    return np.concatenate([g['state'].astype(np.float64), (g['a'].astype(np.float64) / 200)[:, None]], axis=1), g['y']
+
+
+def test_g17_projectron_to_3000_landmarks(golden_dir):
+    """G17 (round 4): the REFERENCE's Projectron teacher-forced to 3,000+ landmarks -- the sizes its 50,400-step runs end at --
+    replayed by the oracle: f within 1e-8, predicted sign / branch / dictionary size exact at every one of 12,400 samples,
+    delta 1e-6 relative (1 - k.Kinv k against a Kinv that has been through three thousand rank-1 updates in numpy's BLAS
+    order there and in index order here), final coefficients 1e-6, Kinv (diagonal, every 256th row, four probe products)
+    1e-6 of its scale."""
+    g = _load(golden_dir, 'g17_projectron_3000')
+    ag = po.OracleKBRL([10], 200, [10], [3], capacity=4096)
+    ag.set_tape(g['ties'])
+    xs, ys = _g17_samples(g)
+    for i in range(len(xs)):
+        yp, f = ag.predict(0, xs[i])
+        fr = g['f'][i]
+        assert f == pytest.approx(fr, rel=1e-8, abs=TOL), i
+        if abs(fr) > 1e-7:
+            assert yp == g['ypred'][i], i
+        br, dl = ag.update(0, xs[i], int(ys[i]))
+        assert br == g['branch'][i], (i, dl, g['delta'][i])
+        if br:
+            assert dl == pytest.approx(g['delta'][i], rel=1e-6, abs=1e-9), i
+        assert ag.m(0) == g['m'][i], i
+    m = ag.m(0)
+    assert m == g['m'][-1] >= 3000
+    assert ((g['branch'] == 1) & (g['m'] > 2000)).sum() >= 20   # projections onto a dictionary of thousands are exercised
+    np.testing.assert_array_equal(ag.landmarks(0), xs[g['branch'] == 2])
+    np.testing.assert_allclose(ag.coeff(0), g['coeff'], rtol=1e-6, atol=1e-8)
+    kinv = ag.kinv(0)
+    scale = np.abs(g['kinv_diag']).max()
+    np.testing.assert_allclose(kinv[::256], g['kinv_rows'], rtol=1e-6, atol=1e-6 * scale)
+    np.testing.assert_allclose(np.diag(kinv), g['kinv_diag'], rtol=1e-6, atol=1e-6 * scale)
+    np.testing.assert_allclose(kinv @ g['kinv_probes'], g['kinv_kp'], rtol=1e-6, atol=1e-6 * np.abs(g['kinv_kp']).max())
+    assert ag.error() == 0
+
+
 @pytest.mark.parametrize('name,min_m', [('g15_kbrl_long_s0', 200), ('g16_kbrl_long_tdl_s0', 0)])
 def test_g15_g16_kbrl_control_long(golden_dir, name, min_m):
     """KBRL_Control teacher-forced over 2,200 recorded steps of scenario_0 -- G15 on the first trace profile

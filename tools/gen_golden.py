@@ -345,7 +345,7 @@ def main():
             print('G9-G11 generator not present yet')
         else:
             gen_golden_kbrl.generate(rh, tape, save)
-    if 'G14' in todo or 'G15' in todo or 'G16' in todo:   # long KBRL sequences (minutes of reference time): only on request
+    if 'G14' in todo or 'G15' in todo or 'G16' in todo or 'G17' in todo:   # long KBRL sequences (minutes of reference time): only on request
         import gen_golden_kbrl
         gen_golden_kbrl.generate_long(rh, tape, save, todo)
 

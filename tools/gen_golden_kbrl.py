@@ -163,6 +163,53 @@ def _g14(rh, tape, save):
          kinv_probes=dg['probes'], kinv_kp=dg['kp'])
 
 
+def _g17(rh, tape, save):
+    """G17 (round 4): Projectron teacher-forced by the REFERENCE to more than 3,000 landmarks -- where the 50,400-step runs of
+    experiments_kbrl.py end (1,431-2,595 landmarks in the reference's own runs on the build's traces, 3,651 in the
+    device's).  The stream is tests/test_gpu_kbrl.py::_fast_growing_samples(12400, spread=3.0, revisit=0.35): states spread
+    over [0, 3]^10, a third of the samples revisiting an earlier state with a new action.  Kept compact: the states as
+    float32, the last coordinate as its grid index; of Kinv (72 MB) the diagonal, every 256th row and Kinv @ four probes."""
+    from algorithms.kernel import GaussianKernel
+    from algorithms.projectron import SVvariable, Projectron
+    spread, revisit, n, d = 3.0, 0.35, 12400, 11
+    rng = np.random.default_rng(141)
+    np.random.seed(17)
+    tape.clear()
+    alg = Projectron(GaussianKernel(SVvariable(), 1))
+    S, A, ys, fs, ypred, branch, delta, ms, states = [], [], [], [], [], [], [], [], []
+    for i in range(n):
+        if states and rng.random() < revisit:
+            s = states[rng.integers(len(states))]
+        else:
+            s = (rng.random(10) * spread).astype(np.float32)
+        states.append(s)
+        a = int(rng.integers(0, 201))
+        x = np.append(s, a / 200)
+        score = x[:-1].mean() * 0.5 * 1.6 / spread + 0.35 - x[-1]
+        y = -1 if score + rng.normal(0, 0.15) > 0 else 1
+        yp = alg.predict(x)
+        f = float(alg.f)
+        m0 = alg.counter
+        dl = np.nan
+        if alg.f * y <= 0:  # projectron.py:41-44 on the reference's arrays
+            d_star = alg.Kinv @ alg.K_f
+            if np.ndim(d_star) == 0:
+                d_star = np.array([d_star], dtype=np.float32)
+            dl = float(max(alg.kernel.k_eval(x, x) - d_star @ alg.K_f, 0))
+        alg.update(x, y)
+        br = 0 if not (f * y <= 0) else (2 if alg.counter > m0 else 1)
+        S.append(s); A.append(a); ys.append(y); fs.append(f); ypred.append(int(yp)); branch.append(br)
+        delta.append(dl); ms.append(alg.counter)
+    kind, val = tape.arrays()
+    kinv = np.atleast_2d(np.asarray(alg.Kinv, dtype=np.float64))
+    probes = np.random.default_rng(17).standard_normal((kinv.shape[0], 4))
+    save('g17_projectron_3000', state=np.asarray(S, dtype=np.float32), a=np.asarray(A, dtype=np.uint8),
+         y=np.asarray(ys, dtype=np.int8), f=np.asarray(fs), ypred=np.asarray(ypred, dtype=np.int8),
+         branch=np.asarray(branch, dtype=np.int8), delta=np.asarray(delta), m=np.asarray(ms, dtype=np.int32), ties=val,
+         coeff=np.asarray(alg.sv.coeff, dtype=np.float64), kinv_rows=kinv[::256].copy(), kinv_diag=np.diag(kinv).copy(),
+         kinv_probes=probes, kinv_kp=kinv @ probes)
+
+
 def _long_control(rh, tape, save, name, profile, seed):
     import tempfile
     from ranslice.fading import synth_traces
@@ -206,3 +253,5 @@ def generate_long(rh, tape, save, which):
         _g15(rh, tape, save)
     if 'G16' in which:
         _g16(rh, tape, save)
+    if 'G17' in which:
+        _g17(rh, tape, save)
