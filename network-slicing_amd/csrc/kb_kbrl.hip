@@ -1206,28 +1206,10 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
     for (int q = 0; q < 4; ++q) f[q] = sm.fbuf[q * 64 + lane];
 }
 
-// shell0_lds (update_small_kernel): the dictionary's first shell -- vector page, Kinv tile (0,0) and its partial sums -- has
-// been copied into LDS and the loop works on the copy for as long as the dictionary fits it (fewer than KB_LDS_STOP
-// landmarks): the very same code, reading and writing through a pool pointer that makes shell 0 land in LDS (generic
-// addressing), so every number is the one the global-memory path produces, at LDS latency instead of ~8 global round trips
-// per repaired mistake.  The copy goes back before the dictionary outgrows the shell, or at the end.
-#define KB_SHELL0 (KB_VEC + KB_TILE + 128)  // doubles of a shell 0 (triangle storage)
-#define KB_LDS_STOP 63
-__device__ __forceinline__ void shell0_writeback(const KbState& K, const uint64_t* sh, const double* shell0_lds) {
-    __syncthreads();
-    double* g = K.pool + sh[0];
-    for (int i = threadIdx.x; i < KB_SHELL0; i += blockDim.x) g[i] = shell0_lds[i];
-    __syncthreads();
-}
-
 __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, int task, int env, int dict, int m, int d, int y,
-                                            int c_from, int c_to, Win w, double (&f)[4], Lds& sm, LoopStats& st,
-                                            double* shell0_lds = nullptr) {
+                                            int c_from, int c_to, Win w, double (&f)[4], Lds& sm, LoopStats& st) {
     const uint64_t* sh = shells_of(D, K, dict);
     const int n = D.n_prbs;
-    KbState KL = K;  // the state the Projectron updates go through: K, or K with shell 0 redirected to its LDS copy
-    bool in_lds = shell0_lds != nullptr;
-    if (in_lds) KL.pool = (double*)((uintptr_t)shell0_lds - (uintptr_t)sh[0] * sizeof(double));
     while (c_from <= c_to) {
         int zeros;
         const int cstar = first_mistake(f, w, y, c_from, c_to, &zeros);
@@ -1237,16 +1219,11 @@ __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, in
         if (m > 0 && zeros > 0 && threadIdx.x == 0) K.tie_ctr[task] += (uint32_t)zeros;
         if (cstar < 0) break;
         st.n_mist += 1;
-        if (in_lds && m >= KB_LDS_STOP) {  // (block-uniform) the next insertion may need shell 1: back to the pool
-            shell0_writeback(K, sh, shell0_lds);
-            KL.pool = K.pool;
-            in_lds = false;
-        }
-        kernel_column_from_d0(D, KL, sh, m, d, (double)cstar / (double)n);
+        kernel_column_from_d0(D, K, sh, m, d, (double)cstar / (double)n);
         int branch;
         double delta;
         bool saturated;
-        const int m_new = apply_update(D, KL, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta, &saturated);
+        const int m_new = apply_update(D, K, dict, env, m, d, sm.x, (double)cstar / (double)n, cstar, y, sm, &branch, &delta, &saturated);
         // A FULL dictionary that met a sample it would have added cannot represent this region: the remaining
         // candidates would meet the same wall one O(m^2) projection at a time, so the augmentation of this learner
         // stops for this step (build-defined; the reference's dictionary is unbounded; the oracle does the same)
@@ -1268,12 +1245,11 @@ __device__ __forceinline__ int augment_loop(const KbDev& D, const KbState& K, in
             st.n_eval += left;
         } else {  // projection (every coefficient moved), or the first two landmarks
             if (branch == 2 && m_new > m) st.n_grow += 1;
-            rescore(D, KL, sh, m_new, d, sm, w, f);
+            rescore(D, K, sh, m_new, d, sm, w, f);
             st.n_eval += left * (uint64_t)m_new;
         }
         m = m_new;
     }
-    if (in_lds) shell0_writeback(K, sh, shell0_lds);
     return m;
 }
 
@@ -1397,7 +1373,7 @@ __global__ __launch_bounds__(64, INLINE ? 2 : KB_OCC) void update_control_kernel
 
 // the learners update_control_kernel queued.  Dictionaries below KB_SMALL_M landmarks: a workgroup of four waves each, all at
 // once (update_small_kernel; workgroups beyond the queue leave at once); larger ones: the repair rounds below.
-__device__ __forceinline__ void repair_learner(const CtlArgs& A, int qslot, Lds& sm, double* shell0_lds) {
+__device__ __forceinline__ void repair_learner(const CtlArgs& A, int qslot, Lds& sm) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     const int task = K.heavy[4 + qslot];
@@ -1406,12 +1382,6 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int qslot, Lds&
     const int dict = dict_of(D, task);
     int m = K.m[dict];
     stage_state(D, A.state, env, s, d, sm);
-    // a dictionary that fits its first shell with room to spare is repaired in LDS (augment_loop)
-    const bool in_lds = D.tri && m >= 1 && m < KB_LDS_STOP;
-    if (in_lds) {
-        const double* g = K.pool + shells_of(D, K, dict)[0];
-        for (int i = threadIdx.x; i < KB_SHELL0; i += blockDim.x) shell0_lds[i] = g[i];
-    }
     __syncthreads();
     const int a_i = A.action[env * D.S + s];
     const int y = A.labels[env * D.S + s];
@@ -1422,7 +1392,7 @@ __device__ __forceinline__ void repair_learner(const CtlArgs& A, int qslot, Lds&
     const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int g = 0; g < 4; ++g) f[g] = K.hv_f[(size_t)qslot * 256 + 64 * g + lane];
-    m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, w, f, sm, st, in_lds ? shell0_lds : nullptr);
+    m = augment_loop(D, K, task, env, dict, m, d, y, c_from, c_to, w, f, sm, st);
     flush_stats(K, task, dict, m, st);
 }
 
@@ -1434,11 +1404,10 @@ __global__ __launch_bounds__(256, KB_SMALL_OCC) void update_small_kernel(CtlArgs
     const int count = K.heavy[2];
     if ((int)blockIdx.x >= count) return;
     __shared__ Lds sm;
-    __shared__ double shell0_lds[KB_SHELL0];
     load_gtab(K, sm);
     for (int slot = blockIdx.x; slot < count; slot += gridDim.x) {
         __syncthreads();
-        repair_learner(A, A.D.n_envs * A.D.S - 1 - slot, sm, shell0_lds);
+        repair_learner(A, A.D.n_envs * A.D.S - 1 - slot, sm);
     }
 }
 
