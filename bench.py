@@ -396,6 +396,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    # RANSLICE_BENCH_SHARE_GPU=1 (developer check of the N > 1 path on a box with fewer GPUs than ranks): ranks wrap around the
+    # visible devices; the line says so and is NOT a scaling measurement
+    share_gpu = os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1' and local_rank >= torch.cuda.device_count()
+    if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1':
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -543,7 +548,9 @@ def main():
                 'burn_in': ('fixed' if args.burn_in >= 0 else
                             'until stationary: mean UEs/slice per %d-step block %s' % (BURN_BLOCK, burn_hist)),
                 'fading': '3 synthetic traces x %d samples x 200 PRB, f64' % FADING_COLS,
-                'parallelism': 'replica-sharded x%d, no collective in step' % world,
+                'parallelism': 'replica-sharded x%d, no collective in step' % world +
+                               (' (RANSLICE_BENCH_SHARE_GPU: the ranks share %d device(s) -- a check of the launch path, not a '
+                                'scaling measurement)' % torch.cuda.device_count() if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1' else ''),
                 'loop': 'hipGraph replay (rs_run_random)' if args.graph else 'one launch sequence per step from the host',
             },
             'roofline': roof,
