@@ -75,6 +75,7 @@ namespace kb {
 #define KB_SEL_WAVES 16   // learners per workgroup of select_gemm_kernel: the N dimension of its v_mfma_f64_16x16x4 tiles
 
 typedef double kb_f64x4 __attribute__((ext_vector_type(4)));
+typedef double kb_f64x2 __attribute__((ext_vector_type(2)));
 
 struct KbDev {
     int32_t n_envs, S, n_prbs, cap, nv;
@@ -893,22 +894,38 @@ __device__ __forceinline__ void rank1_units(const KbState& K, const uint64_t* sh
             bj = tb - bi * nb;
         }
         const int rows = m1 - 64 * bi < 64 ? m1 - 64 * bi : 64;
-        const int j = 64 * bj + lane;
         if (r0 >= rows) continue;  // (wave-uniform)
-        double* T = (tri ? kinv_tile_lo(K, sh, bi, bj) : kinv_tile(K, sh, bi, bj)) + lane;
+        // 16-byte accesses: a lane owns two neighbouring columns of one row, a half-wave a whole 512-byte row, one load
+        // instruction two rows (the tile's rows are 16-byte aligned: every pool offset is even)
+        const int h = lane >> 5, cp = (lane & 31) * 2;
+        const int j0 = 64 * bj + cp;
+        kb_f64x2* T = (kb_f64x2*)((tri ? kinv_tile_lo(K, sh, bi, bj) : kinv_tile(K, sh, bi, bj)) + cp);
         const double dsi_v = vec_page(K, sh, bi)[KB_ROW_DS * KB_CH + lane];
-        const double dsj = vec_page(K, sh, bj)[KB_ROW_DS * KB_CH + lane];
-        double old[16];
+        const kb_f64x2 dsj = *(const kb_f64x2*)(vec_page(K, sh, bj) + KB_ROW_DS * KB_CH + cp);
+        kb_f64x2 old[8];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int r = r0 + k, i = 64 * bi + r;
-            old[k] = (r < rows && i < m && j < m) ? T[r * 64] : 0.0;
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + 2 * k + h, i = 64 * bi + r;
+            const bool in = r < rows && i < m;
+            kb_f64x2 v = {0.0, 0.0};
+            if (in && j0 < m) v = T[r * 32];  // (a pair straddling m: its second entry is unwritten memory, masked below)
+            old[k][0] = v[0];
+            old[k][1] = (in && j0 + 1 < m) ? v[1] : 0.0;
         }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int r = r0 + k;
-            const double dsi = readlane_f64(dsi_v, r);
-            if (r < rows && j < m1) T[r * 64] = old[k] + (dsi * dsj) / delta;
+        for (int k = 0; k < 8; ++k) {
+            const int r = r0 + 2 * k + h;
+            const double da = readlane_f64(dsi_v, r0 + 2 * k), db = readlane_f64(dsi_v, r0 + 2 * k + 1);
+            const double dsi = h ? db : da;
+            kb_f64x2 nv;
+            nv[0] = old[k][0] + (dsi * dsj[0]) / delta;
+            nv[1] = old[k][1] + (dsi * dsj[1]) / delta;
+            if (r < rows) {
+                if (j0 + 1 < m1)
+                    T[r * 32] = nv;
+                else if (j0 < m1)
+                    ((double*)&T[r * 32])[0] = nv[0];
+            }
         }
     }
 }
