@@ -233,6 +233,10 @@ int kb_select_action(kb_handle* k, const float* state, int32_t* action, int32_t*
  * update_control(previous obs, the action just executed by `env`, its SLA labels) followed by
  * select_action(new obs); the selected action is written into env's device action buffer. */
 int kb_step_resident(kb_handle* k, rs_handle* env);
+/* n_steps of that loop body followed each by the simulator's step -- n x (kb_step_resident(k, env); rs_step_resident(env)) --
+ * enqueued by one call; with use_graph two consecutive steps are captured once into a hipGraph and replayed (one graph launch
+ * per two steps instead of ~50 kernel launches).  Identical results either way. */
+int kb_run_resident(kb_handle* k, rs_handle* env, int n_steps, int use_graph);
 /* Projectron.predict(x) / update(x, y) on learner `s` of agent `e` (projectron.py:32-60).
  * branch: 0 none, 1 projection, 2 dictionary grew. */
 int kb_predict(kb_handle* k, int e, int s, const double* x, int32_t* y_pred, double* f);

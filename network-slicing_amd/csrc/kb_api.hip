@@ -44,6 +44,11 @@ struct kb_handle {
     int heavy_rounds = 3;
     int rounds_gate = 200;         // tiles of Kinv queued per step from which the rounds are enqueued (eight learners of 320 landmarks;
                                    // KBRL_ROUNDS_GATE)
+    hipGraph_t graph = nullptr;    // two captured closed-loop steps (agent step + simulator step) of kb_run_resident
+    hipGraphExec_t gexec = nullptr;
+    int g_big_par = 0, g_order_par = 0;  // the parities of the two alternating buffers the graph was captured at
+    rs_handle* g_env = nullptr;
+    uint64_t g_sig = 0;            // env->launch_sig at the capture
     bool gemm_fresh = false;       // shared, resident loop: workF / workE hold the scores of d_prev_state against the dictionaries as they are
     int big_par = 0;               // the large-learner list the next launches are ordered by (per-replica agents)
     int32_t* h_seen = nullptr;     // pinned, device-visible: large learners queued in a recent step (heavy_reset_kernel)
@@ -340,9 +345,18 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     return RS_OK;
 }
 
+static void kb_drop_graph(kb_handle* k) {
+    if (k->gexec) (void)hipGraphExecDestroy(k->gexec);
+    if (k->graph) (void)hipGraphDestroy(k->graph);
+    k->gexec = nullptr;
+    k->graph = nullptr;
+    k->g_env = nullptr;
+}
+
 extern "C" void kb_destroy(kb_handle* k) {
     if (!k) return;
     if (k->stream) (void)hipStreamSynchronize(k->stream);
+    kb_drop_graph(k);
     if (k->D.shared && getenv("KBRL_APPLY_TIMES") && k->d_gstats) {  // developer aid: where shared_apply_kernel spends its time
         uint64_t g[32];
         if (hipMemcpy(g, k->d_gstats, sizeof g, hipMemcpyDeviceToHost) == hipSuccess)
@@ -396,6 +410,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
     k->gemm_fresh = false;
     k->big_par = 0;
+    kb_drop_graph(k);
     HIPCHK(k, hipMemset(k->K.big, 0, sizeof(int32_t) * 2 * (1 + KB_BIG_MAX)));
     HIPCHK(k, hipMemset(k->K.isbig, 0, sizeof(int32_t) * 2 * T));
     (void)hipFree(dseed);
@@ -629,6 +644,73 @@ extern "C" int kb_step_resident(kb_handle* k, rs_handle* env) {
     return RS_OK;
 }
 
+// n_steps x (kb_step_resident(k, env); rs_step_resident(env)) -- KBRL_Control.run's loop body (kbrl_control.py:129-134) -- enqueued
+// by one call.  With use_graph two consecutive steps are captured once into a hipGraph (the agent's large-learner lists and
+// the simulator's order counters alternate between two buffers each; every kernel of the loop reads its step-dependent state
+// from device memory) and replayed: ~25 launches per step become one graph launch per two steps, which is what lets several
+// handles share a GPU without the host's launch rate becoming the limit (experiments_kbrl.evaluate_grid).  The captured
+// sequence always carries the chip-wide repair rounds (they return at once when nothing is queued).  Results are identical
+// either way.
+static int enqueue_closed_step(kb_handle* k, rs_handle* env) {
+    int rc = kb_step_resident(k, env);
+    if (rc != RS_OK) return rc;
+    rc = launch_step(env);
+    if (rc != RS_OK) k->err = env->err;
+    return rc;
+}
+
+extern "C" int kb_run_resident(kb_handle* k, rs_handle* env, int n_steps, int use_graph) {
+    if (!k || !env || n_steps < 0) return RS_EINVAL;
+    int done = 0, rc;
+    if (use_graph && !k->timing && !env->timing && !k->D.shared && n_steps >= 3) {
+        if (!k->gexec || k->g_env != env || k->g_sig != env->launch_sig) {
+            // (one plain step first: whatever the loop creates lazily -- events, the schedule hint -- exists before the capture)
+            kb_drop_graph(k);
+            if ((rc = enqueue_closed_step(k, env)) != RS_OK) return rc;
+            done += 1;
+        } else if (k->big_par != k->g_big_par || env->order_par != k->g_order_par) {
+            if ((rc = enqueue_closed_step(k, env)) != RS_OK) return rc;  // realign with the parities of the capture
+            done += 1;
+            if (k->big_par != k->g_big_par || env->order_par != k->g_order_par) kb_drop_graph(k);  // (out of phase with each other)
+        }
+        if (!k->gexec && n_steps - done >= 2) {
+            const int32_t clock0 = env->clock;
+            const uint64_t steps0 = env->steps;
+            const bool ra = k->rounds_always, gf = k->gemm_fresh;
+            k->g_big_par = k->big_par;
+            k->g_order_par = env->order_par;
+            k->rounds_always = true;
+            HIPCHK(k, hipStreamBeginCapture(env->stream, hipStreamCaptureModeThreadLocal));
+            const int rc1 = enqueue_closed_step(k, env);
+            const int rc2 = rc1 == RS_OK ? enqueue_closed_step(k, env) : rc1;
+            const hipError_t ec = hipStreamEndCapture(env->stream, &k->graph);
+            env->clock = clock0;
+            env->steps = steps0;
+            env->order_par = k->g_order_par;
+            k->big_par = k->g_big_par;
+            k->rounds_always = ra;
+            k->gemm_fresh = gf;
+            if (rc2 != RS_OK || ec != hipSuccess) {
+                kb_drop_graph(k);
+                if (rc2 == RS_OK) k->err = std::string("hipStreamEndCapture: ") + hipGetErrorString(ec);
+                return rc2 != RS_OK ? rc2 : RS_EHIP;
+            }
+            HIPCHK(k, hipGraphInstantiate(&k->gexec, k->graph, nullptr, nullptr, 0));
+            k->g_env = env;
+            k->g_sig = env->launch_sig;
+        }
+        while (k->gexec && n_steps - done >= 2) {
+            HIPCHK(k, hipGraphLaunch(k->gexec, env->stream));
+            env->clock += 2 * env->cfg.slots_per_step;
+            env->steps += 2;
+            done += 2;
+        }
+    }
+    for (; done < n_steps; ++done)
+        if ((rc = enqueue_closed_step(k, env)) != RS_OK) return rc;
+    return RS_OK;
+}
+
 static int kb_one(kb_handle* k, int e, int s, const double* x, int y, bool update, double out[4]) {
     if (!k || !x || e < 0 || e >= k->cfg.n_envs || s < 0 || s >= k->cfg.n_slices) return RS_EINVAL;
     k->gemm_fresh = false;
@@ -827,6 +909,7 @@ extern "C" int kb_get_repair_work(kb_handle* k, uint64_t work[8]) {
 
 extern "C" int kb_set_kernel_timing(kb_handle* k, int enable) {
     if (!k) return RS_EINVAL;
+    kb_drop_graph(k);
     k->timing = enable != 0;
     k->ev_used = 0;
     if (enable && k->D.shared && k->d_gstats && getenv("KBRL_APPLY_TIMES")) {  // (developer aid: count from here on)
@@ -1214,6 +1297,7 @@ extern "C" int kb_shared_merge(kb_handle* k, const double* gathered, int32_t wor
 // read-back; kb_history_fetch returns them ([n_envs][steps], hits [n_envs][S][steps]) and how many were recorded.
 extern "C" int kb_history_begin(kb_handle* k, int32_t steps) {
     if (!k || steps <= 0) return RS_EINVAL;
+    kb_drop_graph(k);  // (the captured loop carries the history kernels and their buffers)
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));
     kb_history_release(k);
@@ -1344,6 +1428,7 @@ extern "C" int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes) {
     }
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));
+    kb_drop_graph(k);
     if (hd.hist_steps != (uint64_t)k->h_steps) {
         int rc = hd.hist_steps ? kb_history_begin(k, (int32_t)hd.hist_steps) : RS_OK;
         if (rc != RS_OK) return rc;

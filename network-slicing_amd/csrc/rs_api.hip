@@ -115,6 +115,8 @@ struct rs_handle {
     hipGraph_t graph = nullptr;  // two captured steps (one per parity of the order counters) of rs_run_random
     hipGraphExec_t gexec = nullptr;
     int graph_par = 0, graph_sig = -1;
+    uint64_t launch_sig = 0;     // bumped whenever the launch shape of a step changes (drop_graph): a graph another handle captured
+                                 // around this one's steps (kb_run_resident) is stale then
     int32_t clock = 0;     // slots since reset (host mirror of d_run[0])
     uint64_t steps = 0;
     bool is_reset = false;
@@ -944,6 +946,7 @@ extern "C" int rs_random_actions(rs_handle* h, uint64_t seed, uint64_t step_inde
 }
 
 static void drop_graph(rs_handle* h) {
+    h->launch_sig += 1;
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
     h->gexec = nullptr;

@@ -28,6 +28,7 @@ from scenario_creator import create_env, create_kbrl_agent
 
 STEPS = 50400
 RUNS = 30
+CHUNK = 64      # closed-loop steps enqueued per call of the batched evaluators (kb_run_resident)
 scenarios = [0, 1, 2]
 accuracy_list = [[0.97, 0.99], [0.99, 0.999]]
 name = 'KBRL'
@@ -96,12 +97,16 @@ class BatchedEvaluator(Evaluator):
         env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
         self._ctx = dict(runs=runs, env=env, agent=agent, capacity=capacity)
 
-    def _advance(self, i):
-        """step i of KBRL_Control.run's loop, enqueued on this cell's own streams (no host wait)"""
+    def _advance(self, i, k=1, graph=True):
+        """steps i .. i + k - 1 of KBRL_Control.run's loop, enqueued on this cell's own streams (no host wait).  Every step
+        but the run's last is an agent step followed by a simulator step: those go out k at a time (kb_run_resident, two
+        captured steps replayed as a hipGraph)."""
         c = self._ctx
-        c['agent'].step_resident(c['env'])    # update_control + select_action + this step's history column
-        if i + 1 < self.steps:
-            c['env'].step_resident()
+        paired = min(k, self.steps - 1 - i)       # steps followed by a simulator step
+        if paired > 0:
+            c['agent'].run_resident(c['env'], paired, graph=graph)
+        if i + k >= self.steps:
+            c['agent'].step_resident(c['env'])    # the last step: update_control + select_action + its history column
 
     def _finish(self, verbose=True):
         c = self._ctx
@@ -155,7 +160,7 @@ class BatchedEvaluator(Evaluator):
         return int(z['next_step'])
 
     def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True, checkpoint=None,
-                     checkpoint_every=0, stop_after=None):
+                     checkpoint_every=0, stop_after=None, graph=True):
         """checkpoint: a .npz path.  If it exists the evaluation resumes from it; with checkpoint_every = k it is rewritten
         every k steps (a 50,400-step evaluation that dies loses at most k steps -- the reference starts over).  stop_after = s
         ends the call after step s - 1 with the checkpoint written and no result files (tests, planned interruptions)."""
@@ -164,11 +169,19 @@ class BatchedEvaluator(Evaluator):
         ck = checkpoint if (checkpoint is None or checkpoint.endswith('.npz')) else checkpoint + '.npz'
         if ck and os.path.exists(ck):
             first = self.load_checkpoint(ck)
-        for i in range(first, self.steps):
-            self._advance(i)
-            last = stop_after is not None and i + 1 == stop_after
-            if ck and (last or (checkpoint_every and (i + 1) % checkpoint_every == 0 and i + 1 < self.steps)):
-                self.save_checkpoint(ck, i + 1)
+        i = first
+        while i < self.steps:
+            # up to CHUNK steps per call, cut at the next checkpoint / stop boundary
+            k = min(CHUNK, self.steps - i)
+            if stop_after is not None and i < stop_after:
+                k = min(k, stop_after - i)
+            if ck and checkpoint_every:
+                k = min(k, checkpoint_every - i % checkpoint_every)
+            self._advance(i, k, graph=graph)
+            i += k
+            last = stop_after is not None and i == stop_after
+            if ck and (last or (checkpoint_every and i % checkpoint_every == 0 and i < self.steps)):
+                self.save_checkpoint(ck, i)
             if last:
                 c = self._ctx
                 c['env'].close()
@@ -178,7 +191,8 @@ class BatchedEvaluator(Evaluator):
         return self._finish(verbose=verbose)
 
 
-def evaluate_grid(cells, runs, steps=STEPS, out_dir='./results', device=0, capacity=16384, pool_bytes=16 << 30, verbose=False):
+def evaluate_grid(cells, runs, steps=STEPS, out_dir='./results', device=0, capacity=16384, pool_bytes=16 << 30, verbose=False,
+                  graph=True):
     """The reference's whole experiment (experiments_kbrl.py:57-70: every scenario x accuracy range x run) as ONE job on
     one GPU: a BatchedEvaluator per cell, each with its environment and agents on streams of their own, all advanced in
     the same host loop -- a cell of 30 runs leaves most of the chip idle (a handful of waves per kernel), so the cells'
@@ -189,9 +203,9 @@ def evaluate_grid(cells, runs, steps=STEPS, out_dir='./results', device=0, capac
         ev = BatchedEvaluator(scenario, a_range, steps=steps, out_dir=out_dir)
         ev._setup(runs, device=device, capacity=capacity, pool_bytes=pool_bytes)
         evs.append(ev)
-    for i in range(steps):
+    for i in range(0, steps, CHUNK):
         for ev in evs:
-            ev._advance(i)
+            ev._advance(i, min(CHUNK, steps - i), graph=graph)
     out = {}
     for (scenario, a_range), ev in zip(cells, evs):
         out[(scenario, a_range[0])] = ev._finish(verbose=verbose)

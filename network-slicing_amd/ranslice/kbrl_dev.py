@@ -81,6 +81,11 @@ class VecKBRL:
     def step_resident(self, env):
         self._check(self.L.kb_step_resident(self.h, env.h))
 
+    def run_resident(self, env, n_steps, graph=True):
+        """n_steps x (step_resident(env); env.step_resident()) from one call (kb_run_resident); graph: two captured steps
+        replayed as a hipGraph -- same results, a fraction of the launches"""
+        self._check(self.L.kb_run_resident(self.h, env.h, int(n_steps), 1 if graph else 0))
+
     def history_begin(self, steps):
         """start recording KBRL_Control.run's per-step histories on the device (one column per step_resident)"""
         self._hist_steps = int(steps)

@@ -390,6 +390,55 @@ def test_batched_evaluator_equals_run_by_run(golden_dir, tmp_path):
     sc.set_fading(None)
 
 
+def test_graph_replayed_closed_loop_equals_stepwise(golden_dir):
+    """kb_run_resident: the closed loop (agent step + simulator step) enqueued n steps at a time, two captured steps replayed as
+    a hipGraph, == the same loop one kb_step_resident / rs_step_resident pair at a time: histories, final observations and
+    actions, dictionaries (bit for bit).  Odd and even step counts, two calls in a row (the second finds the graph and has to
+    realign with the parity of the alternating buffers), scenario_1 (eMBB + mMTC learners, the side stream inside the capture)."""
+    import ctypes as C
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    fading = [g['t0'], g['t1'], g['t2']]
+    scenario, N = 1, 24
+    dims, n_prbs = _dims(scenario)
+    rng = np.random.default_rng(31)
+    ia = np.stack([np.concatenate([rng.integers(4, 20, 3), rng.integers(2, 10, 2)]) for _ in range(N)]).astype(np.int32)
+    sf = np.stack([np.concatenate([rng.integers(2, 8, 3), rng.integers(1, 4, 2)]) for _ in range(N)]).astype(np.int32)
+    total = 61 + 30 + 2
+    out = []
+    for mode in ('graph', 'stepwise', 'calls without graph'):
+        env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=fading, seed=19)
+        ag = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=256 << 20)
+        env.reset()
+        ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 4)
+        ag.history_begin(total)
+        env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        if mode == 'stepwise':
+            for _ in range(total):
+                ag.step_resident(env)
+                env.step_resident()
+        else:
+            for k in (61, 30, 2):
+                ag.run_resident(env, k, graph=mode == 'graph')
+        f = env.fetch()
+        h = ag.history_fetch()
+        d = [ag.learner(r, s, with_kinv=True) for r in (0, N - 1) for s in range(len(dims))]
+        out.append((f, h, d, ag.dictionary_sizes().copy()))
+        env.close()
+        ag.close()
+    ref = out[1]
+    assert ref[1]['recorded'] == total and ref[3].max() > 8
+    for o in (out[0], out[2]):
+        for key in ('obs', 'actions', 'reward', 'labels'):
+            assert o[0][key].tobytes() == ref[0][key].tobytes(), key
+        for key in ('reward', 'resources', 'hits', 'adjusted', 'SLA', 'violation', 'recorded'):
+            assert np.array_equal(o[1][key], ref[1][key]), key
+        assert (o[3] == ref[3]).all()
+        for a, b in zip(o[2], ref[2]):
+            assert a['m'] == b['m'] and all(a[k].tobytes() == b[k].tobytes() for k in ('landmarks', 'coeff', 'kinv'))
+
+
 def test_checkpoint_and_resume(golden_dir, tmp_path):
     """rs_save_state / kb_save_state: (1) a closed loop cut after 25 steps, restored into FRESH handles and continued, makes
     the steps the uncut loop makes (observations, actions, dictionaries bit for bit); a blob of another configuration is
