@@ -28,7 +28,8 @@ from scenario_creator import create_env, create_kbrl_agent
 
 STEPS = 50400
 RUNS = 30
-CHUNK = 64      # closed-loop steps enqueued per call of the batched evaluators (kb_run_resident)
+CHUNK = int(os.environ.get('KBRL_EVAL_CHUNK', '64'))   # closed-loop steps enqueued per call of the batched evaluators (kb_run_resident)
+GRAPH = os.environ.get('KBRL_EVAL_GRAPH', '1') != '0'   # ... replayed from a captured hipGraph
 scenarios = [0, 1, 2]
 accuracy_list = [[0.97, 0.99], [0.99, 0.999]]
 name = 'KBRL'
@@ -160,7 +161,7 @@ class BatchedEvaluator(Evaluator):
         return int(z['next_step'])
 
     def evaluate_all(self, runs, device=0, capacity=16384, pool_bytes=32 << 30, verbose=True, checkpoint=None,
-                     checkpoint_every=0, stop_after=None, graph=True):
+                     checkpoint_every=0, stop_after=None, graph=GRAPH):
         """checkpoint: a .npz path.  If it exists the evaluation resumes from it; with checkpoint_every = k it is rewritten
         every k steps (a 50,400-step evaluation that dies loses at most k steps -- the reference starts over).  stop_after = s
         ends the call after step s - 1 with the checkpoint written and no result files (tests, planned interruptions)."""
@@ -192,11 +193,13 @@ class BatchedEvaluator(Evaluator):
 
 
 def evaluate_grid(cells, runs, steps=STEPS, out_dir='./results', device=0, capacity=16384, pool_bytes=16 << 30, verbose=False,
-                  graph=True):
+                  graph=False):
     """The reference's whole experiment (experiments_kbrl.py:57-70: every scenario x accuracy range x run) as ONE job on
     one GPU: a BatchedEvaluator per cell, each with its environment and agents on streams of their own, all advanced in
     the same host loop -- a cell of 30 runs leaves most of the chip idle (a handful of waves per kernel), so the cells'
-    kernels run beside each other.  Nothing in the loop waits for the device.  Returns {(scenario, a_lo): [files]}, file
+    kernels run beside each other.  Nothing in the loop waits for the device.  (graph=False: graph launches of different
+    handles do not overlap on this runtime -- 22.4 s per 6,000 steps of the six cells against 16.1 s with plain launches,
+    profiles/r04_w_grid_graph.txt -- while a single cell gains 5 % from the graph.)  Returns {(scenario, a_lo): [files]}, file
     for file what evaluate_all writes cell by cell (tests/test_gpu_kbrl.py::test_grid_of_cells_equals_cell_by_cell)."""
     evs = []
     for scenario, a_range in cells:
