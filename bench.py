@@ -398,7 +398,6 @@ def main():
         raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
     # RANSLICE_BENCH_SHARE_GPU=1 (developer check of the N > 1 path on a box with fewer GPUs than ranks): ranks wrap around the
     # visible devices; the line says so and is NOT a scaling measurement
-    share_gpu = os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1' and local_rank >= torch.cuda.device_count()
     if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1':
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
