@@ -482,8 +482,10 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
     a.action = d_action;
     a.labels = d_labels;
     a.hits = k->d_hits;
-    a.big_par = k->D.shared ? -1 : k->big_par;
-    const unsigned grid1 = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
+    // (update_control_kernel starts from stored scores since round 4: every learner costs the same there, so it runs in task
+    // order -- no large-learner list to look up first, no 4,096 empty places in the grid)
+    a.big_par = -1;
+    const unsigned grid1 = (unsigned)k->T;
     hipEvent_t e1;
     int rc = kb_time_begin(k, &e1);
     if (rc != RS_OK) return rc;

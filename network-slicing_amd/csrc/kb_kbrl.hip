@@ -980,7 +980,8 @@ __device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err
     double delta = 1.0 - dot;  // Kii = k(x, x) = 1
     delta = delta > 0.0 ? delta : 0.0;
     *delta_out = delta;
-    if (threadIdx.x == 0) K.ver[dict] += 1;  // the dictionary changes (projection or insertion): stored scores are stale
+    if (threadIdx.x == 0) atomicAdd(&K.ver[dict], 1);  // the dictionary changes (projection or insertion): stored scores are stale
+                                                       // (no return value: nothing waits for it)
     // A dictionary that cannot grow (capacity reached, or the pool has no shell left) projects every further sample
     // onto its span -- the fixed-budget reading of Projectron -- instead of growing as the reference's unbounded
     // SVvariable would: learning goes on, nothing is dropped, and the replica is flagged (err bit 8 "saturated", bit 16
@@ -1274,11 +1275,13 @@ __device__ __forceinline__ void flush_stats(const KbState& K, int task, int dict
     if (threadIdx.x == 0) {
         K.m[dict] = m;
         if (st.n_mist) K.kf_owner[dict] = -1;  // the K_f row no longer holds a Projectron.predict's cache (Q12 guard)
-        uint64_t* o = K.stats + (size_t)task * 4;
-        o[0] += st.n_pred;
-        o[1] += st.n_mist;
-        o[2] += st.n_grow;
-        o[3] += st.n_eval;
+        // (atomics without a return value: the wave does not wait for four loads at its very end; a learner's counters are
+        // only ever touched by one workgroup at a time)
+        unsigned long long* o = (unsigned long long*)(K.stats + (size_t)task * 4);
+        if (st.n_pred) atomicAdd(&o[0], (unsigned long long)st.n_pred);
+        if (st.n_mist) atomicAdd(&o[1], (unsigned long long)st.n_mist);
+        if (st.n_grow) atomicAdd(&o[2], (unsigned long long)st.n_grow);
+        if (st.n_eval) atomicAdd(&o[3], (unsigned long long)st.n_eval);
     }
 }
 
