@@ -810,17 +810,25 @@ static int launch_step(rs_handle* h) {
             const bool tr = h->trace_on;
             // BLOCK instances hand out the RB pairs of wide contested slices in block rounds; the plain 16-lane one
             // carries the trip loop alone (rs_set_schedule_hint)
+#define RS_LAUNCH_STEP(G_, TR_, BL_)                                                                              \
+    do {                                                                                                          \
+        if (h->hdev.pf_div_fast)                                                                                  \
+            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, true>), grid, block, 0, h->stream, a);             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, false>), grid, block, 0, h->stream, a);            \
+    } while (0)
             if (g == 8) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<8, true, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<8, false, true>), grid, block, 0, h->stream, a);
+                if (tr) RS_LAUNCH_STEP(8, true, true);
+                else RS_LAUNCH_STEP(8, false, true);
             } else if (g == 16) {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<16, true, true>), grid, block, 0, h->stream, a);
-                else if (h->block_hint) hipLaunchKernelGGL((embb_step_kernel<16, false, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<16, false, false>), grid, block, 0, h->stream, a);
+                if (tr) RS_LAUNCH_STEP(16, true, true);
+                else if (h->block_hint) RS_LAUNCH_STEP(16, false, true);
+                else RS_LAUNCH_STEP(16, false, false);
             } else {
-                if (tr) hipLaunchKernelGGL((embb_step_kernel<32, true, true>), grid, block, 0, h->stream, a);
-                else hipLaunchKernelGGL((embb_step_kernel<32, false, true>), grid, block, 0, h->stream, a);
+                if (tr) RS_LAUNCH_STEP(32, true, true);
+                else RS_LAUNCH_STEP(32, false, true);
             }
+#undef RS_LAUNCH_STEP
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
         // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)

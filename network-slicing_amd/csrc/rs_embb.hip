@@ -621,7 +621,10 @@ __device__ __noinline__ double wide_response(const double* mi, const double* fad
 // instances are test tooling: they keep the register budget of 3 waves per SIMD.
 // BLOCK: the contested PF allocation may hand out RB pairs in block rounds (wide slices); without it the instance
 // carries only the trip loop (fewer live registers: the whole point at 5 waves per SIMD).
-template <int G, bool TRACE, bool BLOCK>
+// FDIV: pf_b * bits / slot_length by the verified reciprocal form (rs_create checks every reachable `bits`; RsDev.pf_div_fast)
+// -- a template parameter since round 4: as a run-time flag it put a branch into every one of the four shares a block-round
+// iteration forms and kept their (independent) chains from being interleaved.
+template <int G, bool TRACE, bool BLOCK, bool FDIV>
 __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) void embb_step_kernel(StepArgs A) {
     static_assert(G == 8 || G == 16 || G == 32, "lanes per task");
     constexpr int TPB = 256 / G;                     // tasks per block
@@ -671,7 +674,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const double slot_len = D->slot_length;
     const double pf_a = D->pf_a, pf_b = D->pf_b;
     const double slot_rc = D->slot_rc;
-    const bool pf_div_fast = D->pf_div_fast != 0;
+    constexpr bool pf_div_fast = FDIV;
     const int gran = D->gran;
     const bool has_nan = D->has_nan != 0;
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2];

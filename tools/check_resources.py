@@ -10,7 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG = os.path.join(ROOT, 'network-slicing_amd', 'csrc', 'build', 'resources.log')
 LIMIT = 240
-PRODUCTION = ["embb_step_kernelILi16ELb0ELb0E", "embb_step_kernelILi16ELb0ELb1E"]
+PRODUCTION = ["embb_step_kernelILi16ELb0ELb0ELb1E", "embb_step_kernelILi16ELb0ELb1ELb1E"]   # <16, false, plain | BLOCK, FDIV>
 
 
 def parse(path=LOG):
