@@ -823,7 +823,7 @@ static int launch_step(rs_handle* h) {
             } else if (g == 16) {
                 if (tr) RS_LAUNCH_STEP(16, true, true);
                 else if (h->block_hint) RS_LAUNCH_STEP(16, false, true);
-                else RS_LAUNCH_STEP(16, false, false);
+                else hipLaunchKernelGGL((embb_step_kernel<16, false, false, true>), grid, block, 0, h->stream, a);  // (run-time flag inside)
             } else {
                 if (tr) RS_LAUNCH_STEP(32, true, true);
                 else RS_LAUNCH_STEP(32, false, true);

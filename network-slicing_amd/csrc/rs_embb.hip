@@ -674,7 +674,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const double slot_len = D->slot_length;
     const double pf_a = D->pf_a, pf_b = D->pf_b;
     const double slot_rc = D->slot_rc;
-    constexpr bool pf_div_fast = FDIV;
+    // (the plain 16-lane instance keeps the run-time flag: its trip loop has one share per iteration, and it measured 1.5 %
+    // slower with the constant -- a different schedule at the same 96 registers)
+    const bool pf_div_fast = BLOCK ? FDIV : (D->pf_div_fast != 0);
     const int gran = D->gran;
     const bool has_nan = D->has_nan != 0;
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2];
