@@ -104,6 +104,8 @@ struct rs_handle {
     int order_mode = 6;          // 0: task index order; 1..3: cost keys of rs_order.hip (RANSLICE_ORDER)
     int order_pair = 256;        // modes 4..: share (/256) of the waves led by one heavy task (RANSLICE_PAIR)
     int block_hint = 0;          // 1: wide contested slices are expected, the 16-lane step uses its BLOCK instance (rs_set_schedule_hint)
+    int spread_mode = -1;        // one task per wave (StepArgs::spread): -1 = when the batch has at most spread_max tasks, 0 never, 1 always
+    int spread_max = 1024;       // SIMDs of the device (rs_create)
     bool hint_auto = true;      // block_hint follows the scenario / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
@@ -540,6 +542,12 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         const int g = atoi(e);
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->spread_max = cus * 4;
+        (void)hipGetLastError();
+        if (const char* e = getenv("RANSLICE_SPREAD")) h->spread_mode = atoi(e);  // developer knob
+    }
     h->block_hint = auto_hint(h);
     if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
@@ -792,6 +800,7 @@ static int launch_step(rs_handle* h) {
         a.pace = h->d_pace;
         a.replay = 0;
         a.order = nullptr;
+        a.spread = 0;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -805,7 +814,9 @@ static int launch_step(rs_handle* h) {
             h->ev_used++;
         }
         auto launch = [&](int g) {
-            const int per_block = 256 / g;
+            // at most one wave per SIMD of the chip: one task per wave (StepArgs::spread)
+            a.spread = (h->spread_mode == 1 || (h->spread_mode < 0 && h->n_tasks <= h->spread_max)) ? 1 : 0;
+            const int per_block = a.spread ? 4 : 256 / g;
             dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
             // BLOCK instances hand out the RB pairs of wide contested slices in block rounds; the plain 16-lane one

@@ -510,6 +510,9 @@ struct StepArgs {
     unsigned long long* pace; // [0] sum, [1] count of the wave paces (cycles per slot) of the launch in flight,
                               // [2] mean pace of the previous launch: the reference of the dynamic issue priority
     const int32_t* order;     // [n_tasks] launch order of the tasks (rs_order.hip) or null = task index order
+    int32_t spread;           // 1: ONE task per wave (its first group; the other groups idle).  For batches of at most one wave
+                              // per SIMD of the chip: groups of a wave run their loops in lockstep, so a wave costs the maximum
+                              // over its tasks loop by loop, and a batch this small gains nothing from packing them.
 };
 
 // select among three wave-uniform values by a per-lane index 0..2
@@ -661,8 +664,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const int wb = tid & ~63;            // first thread of my wave in the block
     const int tq = tid / G;              // my group's index in the block
     const int n_tasks = D->n_envs * D->n_embb;
-    int task = (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
-    const bool in_range = task < n_tasks;
+    int task = A.spread ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
+    const bool in_range = task < n_tasks && (!A.spread || gbase == 0);
     if (!in_range) task = n_tasks - 1;
     if (A.order) task = A.order[task];
     const bool selected = in_range && (!A.replay || A.redo[task] != 0);
@@ -1279,16 +1282,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                             // fl(rate / tmax) against L without the IEEE divide: fl(L (1 +- 2^-40) tmax) is within
                             // 2^-51 of the product, so rate above the upper one puts the exact quotient above the
                             // double after L, rate below the lower one under the double before it, and rounding is
-                            // monotone.  Anything closer (ties between equal UEs included) takes the divide.
+                            // monotone.  Anything closer (ties between equal UEs included) takes the divide (in the loop below).
                             const double L_hi = Lk * 0x1.0000000001p+0, L_lo = Lk * 0x1.fffffffffep-1;
-                            auto above = [&](double tm) -> bool {
-                                bool pass = rate_d > L_hi * tm;
-                                if (!pass && !(rate_d < L_lo * tm)) {
-                                    const double kk = rate_d / tm;
-                                    pass = kk > Lk || (kk == Lk && low);
-                                }
-                                return pass;
-                            };
                             double tmax = thl;
                             int kl2 = kl;  // pairs until my queue is empty
                             bool open_ = cont && (target || m > Lk || (m == Lk && low));
@@ -1305,11 +1300,28 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                                 const double a4 = pf_a * a3 + s4;
                                 const double x1 = max_finite(tmax, a1), x2 = max_finite(x1, a2);
                                 const double x3 = max_finite(x2, a3), x4 = max_finite(x3, a4);
+                                // ab_i: my key after i pairs of this iteration is above (L, u*).  All four without a branch (two
+                                // multiplies and two compares each: the guard-band test of `above`); only a lane whose key falls
+                                // INSIDE the band of some pair takes the IEEE divides, all four together, in one wave-uniform branch
+                                // -- as four short-circuit lambdas this was ~60 instructions and two divergent branches per pair.
+                                const bool h1 = rate_d > L_hi * x1, h2 = rate_d > L_hi * x2, h3 = rate_d > L_hi * x3, h4 = rate_d > L_hi * x4;
+                                bool ab1 = h1, ab2 = h2, ab3 = h3, ab4 = h4;
+                                {
+                                    const bool u1 = !h1 && !(rate_d < L_lo * x1), u2 = !h2 && !(rate_d < L_lo * x2);
+                                    const bool u3 = !h3 && !(rate_d < L_lo * x3), u4 = !h4 && !(rate_d < L_lo * x4);
+                                    if (wave_any(open_ && !target && (u1 || u2 || u3 || u4))) {
+                                        const double k1 = rate_d / x1, k2 = rate_d / x2, k3 = rate_d / x3, k4 = rate_d / x4;
+                                        ab1 = u1 ? (k1 > Lk || (k1 == Lk && low)) : h1;
+                                        ab2 = u2 ? (k2 > Lk || (k2 == Lk && low)) : h2;
+                                        ab3 = u3 ? (k3 > Lk || (k3 == Lk && low)) : h3;
+                                        ab4 = u4 ? (k4 > Lk || (k4 == Lk && low)) : h4;
+                                    }
+                                }
                                 // p_i: with i pairs of this iteration in hand, the next one is mine too
-                                const bool p1 = open_ && kl2 > 1 && 1 < lim && (target || above(x1));
-                                const bool p2 = p1 && kl2 > 2 && 2 < lim && (target || above(x2));
-                                const bool p3 = p2 && kl2 > 3 && 3 < lim && (target || above(x3));
-                                const bool p4 = p3 && kl2 > 4 && 4 < lim && (target || above(x4));
+                                const bool p1 = open_ & (kl2 > 1) & (1 < lim) & (target | ab1);
+                                const bool p2 = p1 & (kl2 > 2) & (2 < lim) & (target | ab2);
+                                const bool p3 = p2 & (kl2 > 3) & (3 < lim) & (target | ab3);
+                                const bool p4 = p3 & (kl2 > 4) & (4 < lim) & (target | ab4);
                                 if (open_) {
                                     const int n = 1 + (p1 ? 1 : 0) + (p2 ? 1 : 0) + (p3 ? 1 : 0);
                                     const int cn = p3 ? c4 : (p2 ? c3 : (p1 ? c2 : c1));
