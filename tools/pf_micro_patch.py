@@ -47,15 +47,26 @@ def apply():
                         SEC_MARK(11)''', '''                            MM(2)
                             if (cont) e = run1 ? rate_d / tmax1 : 0.0;
                         }
-                        MM(3)''')
+                        MM(2)''')
     rep('''                        const int ustar = __ffs((int)group_ballot<G>(e == Lk, gbase)) - 1;''',
         '''                        const int ustar = __ffs((int)group_ballot<G>(e == Lk, gbase)) - 1;
                         MM(4)''')
     rep('''                        SEC_MARK(12)
                         const int T = group_sum<G>(cnt);''', '''                        MM(5)
                         const int T = group_sum<G>(cnt);''')
-    rep('''                    const bool tm = more && !bmode;  // tasks on a trip this round''', '''                    MM(6)
-                    const bool tm = more && !bmode;  // tasks on a trip this round''')
+    rep('''                    bool rmode = false;
+                    if (RS_RANK != 0 && G >= 16 && wave_any(more && !bmode && rk_ok)) {''', '''                    MM(6)
+                    bool rmode = false;
+                    if (RS_RANK != 0 && G >= 16 && wave_any(more && !bmode && rk_ok)) {''')
+    rep('''                            __builtin_amdgcn_wave_barrier();
+                            const bool elane = gl < 16;''', '''                            MM(10)
+                            sec_acc[14] += 1;  // rank rounds (wave level; read from the slowest wave's bank only)
+                            __builtin_amdgcn_wave_barrier();
+                            const bool elane = gl < 16;''')
+    rep('''                            const int rl = group_min<G>((elane && ev < 0.0) ? rank : 255);''', '''                            MM(11)
+                            const int rl = group_min<G>((elane && ev < 0.0) ? rank : 255);''')
+    rep('''                    const bool tm = more && !bmode && !rmode;  // tasks on a trip this round''', '''                    MM(3)
+                    const bool tm = more && !bmode && !rmode;  // tasks on a trip this round''')
     rep('''                        int take = 0;
                         SEC_MARK(11)
                         if (tm) {''', '''                        int take = 0;

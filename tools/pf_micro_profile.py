@@ -34,7 +34,7 @@ for i in range(K): adv()
 env.synchronize(); env.L.rs_get_section_profile(env.h,a)
 d=[a[i]-base[i] for i in range(16)]
 rounds=d[15]; runs=d[13]
-names={0:'loop top (control)',1:'block: contenders, B',2:'block: pass 1 loop',3:'block: the B-th key (divide)',4:'block: max + u*',5:'block: pass 2',6:'block: tail (sum, metric divide)',7:'trip: reductions',8:'trip: leader run / closed form',9:'trip: take broadcast + update',12:'everything else (the slot outside contested PF rounds)'}
+names={0:'loop top (control)',1:'block: contenders, B',2:'block: pass 1 loop + B-th key',3:'rank: limit + commit',10:'rank: set-up + keys',11:'rank: ranking',4:'block: max + u*',5:'block: pass 2',6:'block: tail (sum, metric divide)',7:'trip: reductions',8:'trip: leader run / closed form',9:'trip: take broadcast + update',12:'everything else (the slot outside contested PF rounds)'}
 tot=sum(d[i] for i in names)
 print('N=%d: PF rounds (wave-level) %d, leader-run iterations (lane-level sum) %d over %d steps' % (N, rounds, runs, K))
 for i in names: print('%-40s %6.2f%%  %9.0f cycles per wave-round' % (names[i], 100.0*d[i]/tot, d[i]/max(1,rounds)))
@@ -43,5 +43,5 @@ raw=np.zeros(N*5*4+16,dtype=np.uint64)
 env.L.rs_get_task_profile(env.h, raw.ctypes.data_as(C.POINTER(C.c_uint64)))
 sw=raw[N*5*4:].astype(np.float64)
 tots=sum(sw[i] for i in names)
-print('slowest wave of the run: %.0f cycles per slot, %.1f PF rounds per slot, %.2f leader-run iterations per round' % (tots/50, sw[15]/50, sw[13]/max(1.0,sw[15])))
+print('slowest wave of the run: %.0f cycles per slot, %.1f PF rounds per slot (%.1f rank rounds), %.2f leader-run iterations per round' % (tots/50, sw[15]/50, sw[14]/50, sw[13]/max(1.0,sw[15])))
 for i in names: print('   %-40s %6.2f%%  %9.0f cycles per round  %9.0f per slot' % (names[i], 100.0*sw[i]/tots, sw[i]/max(1.0,sw[15]), sw[i]/50))
