@@ -12,8 +12,10 @@ P = os.path.join(ROOT, 'network-slicing_amd', 'csrc', 'rs_embb.hip')
 
 def apply():
     s = open(P).read()
-    def rep(a, b):
+    def rep(a, b, optional=False):
         nonlocal s
+        if optional and a not in s:
+            return
         assert a in s, a[:60]
         s = s.replace(a, b)
     rep('''#define SEC_MARK(i)                                              \\
@@ -57,16 +59,18 @@ def apply():
     rep('''                    bool rmode = false;
                     if (RS_RANK != 0 && G >= 16 && wave_any(more && !bmode && rk_ok)) {''', '''                    MM(6)
                     bool rmode = false;
-                    if (RS_RANK != 0 && G >= 16 && wave_any(more && !bmode && rk_ok)) {''')
+                    if (RS_RANK != 0 && G >= 16 && wave_any(more && !bmode && rk_ok)) {''', optional=True)
     rep('''                            __builtin_amdgcn_wave_barrier();
                             const bool elane = gl < 16;''', '''                            MM(10)
                             sec_acc[14] += 1;  // rank rounds (wave level; read from the slowest wave's bank only)
                             __builtin_amdgcn_wave_barrier();
-                            const bool elane = gl < 16;''')
+                            const bool elane = gl < 16;''', optional=True)
     rep('''                            const int rl = group_min<G>((elane && ev < 0.0) ? rank : 255);''', '''                            MM(11)
-                            const int rl = group_min<G>((elane && ev < 0.0) ? rank : 255);''')
+                            const int rl = group_min<G>((elane && ev < 0.0) ? rank : 255);''', optional=True)
     rep('''                    const bool tm = more && !bmode && !rmode;  // tasks on a trip this round''', '''                    MM(3)
-                    const bool tm = more && !bmode && !rmode;  // tasks on a trip this round''')
+                    const bool tm = more && !bmode && !rmode;  // tasks on a trip this round''', optional=True)
+    rep('''                    const bool tm = more && !bmode;  // tasks on a trip this round''', '''                    MM(6)
+                    const bool tm = more && !bmode;  // tasks on a trip this round''', optional=True)
     rep('''                        int take = 0;
                         SEC_MARK(11)
                         if (tm) {''', '''                        int take = 0;
