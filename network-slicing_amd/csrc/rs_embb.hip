@@ -834,6 +834,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     // (Timing only; no result depends on it.)
     unsigned long long pace_ref = 0ull;
     const unsigned long long pace_t0 = __builtin_amdgcn_s_memtime();
+#ifdef RS_WAVE_LOG
+    if ((tid & 63) == 0) ((unsigned long long*)A.sections)[16 + 16 * (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (RS_DYN_PRIO && A.pace) {
         pace_ref = __builtin_nontemporal_load(&A.pace[2]);
         if (blockIdx.x == 0 && tid == 0) {  // nobody adds to [0], [1] before the end of its 50 slots
@@ -1562,6 +1565,14 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     if (RS_DYN_PRIO && A.pace && (tid & 63) == 0 && wave_worked) {
         atomicAdd(&A.pace[0], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
         atomicAdd(&A.pace[1], 1ull);
+#ifdef RS_WAVE_LOG  // developer build (tools/wave_log.py): when and where every wave of the production kernel ran
+        {
+            unsigned long long* wl_ = (unsigned long long*)A.sections + 16 + 16 * (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6));
+            wl_[0] = __builtin_amdgcn_s_memtime() - pace_t0;
+            wl_[2] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);  // HW_ID, XCC_ID
+            wl_[3] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
+        }
+#endif
 #ifdef RS_PACE_XCC  // developer build (tools/xcc_pace.py): wave paces per XCD through the section-profile buffer
         const unsigned xcc_ = __builtin_amdgcn_s_getreg(63508) & 7u;
         atomicAdd((unsigned long long*)&A.sections[2 * xcc_], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
@@ -1602,6 +1613,10 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             SE.t_ctr[task] = (uint32_t)L_task[tq][2];
             SE.t_serial[task] = (uint32_t)L_task[tq][3];
             SE.t_cost[task] = (int)(stat >> 18);
+#ifdef RS_WAVE_LOG  // [4 + group]: UEs at the end | RBs << 8 | PF rounds of the step << 16 | UE-slots << 32
+            ((unsigned long long*)A.sections)[16 + 16 * (size_t)(blockIdx.x * 4u + (threadIdx.x >> 6)) + 4 + (gbase / G)] =
+                (unsigned long long)n_ue | ((unsigned long long)n_prb << 8) | ((unsigned long long)(stat >> 18) << 16) | ((unsigned long long)(stat & 0xfffu) << 32);
+#endif
             uint64_t* c = A.counters + (size_t)task * 4;
             const unsigned cnt_ue = stat & 0xfffu, n_sched = (stat >> 12) & 0x3fu;
             c[0] += cnt_ue * (unsigned)n_prb;  // every UE reads n_prb fading samples per slot (n_prb is fixed for the step)
