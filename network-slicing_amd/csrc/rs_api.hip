@@ -879,7 +879,7 @@ static int launch_step(rs_handle* h) {
 // the BLOCK instance outright.
 static int auto_hint(const rs_handle* h) {
     const int gran = h->cfg.pf_granularity > 0 ? h->cfg.pf_granularity : 1;
-    return h->cfg.n_prbs / (h->n_slices + 1) >= RS_BLOCK_PAIRS * gran ? 1 : 0;
+    return h->cfg.n_prbs / (h->n_slices + 1) >= RS_HINT_PAIRS * gran ? 1 : 0;
 }
 
 static int check_errors(rs_handle* h) {
@@ -915,7 +915,7 @@ extern "C" int rs_step(rs_handle* h, const int32_t* actions, float* obs, double*
     HIPCHK(h, hipSetDevice(h->device));
     const size_t N = (size_t)h->cfg.n_envs, S = (size_t)h->n_slices;
     size_t wide = 0;  // eMBB slices wide enough for block rounds of the PF allocation
-    const int wide_prbs = RS_BLOCK_PAIRS * (h->cfg.pf_granularity > 0 ? h->cfg.pf_granularity : 1);
+    const int wide_prbs = RS_HINT_PAIRS * (h->cfg.pf_granularity > 0 ? h->cfg.pf_granularity : 1);
     for (size_t r = 0; r < N; ++r) {  // Q9: the reference silently mis-slices; the build rejects
         long tot = 0;
         for (size_t s = 0; s < S; ++s) {

@@ -108,8 +108,11 @@ namespace rs {
 #define RS_BLOCK_MIN 4     // PF: block rounds while a contender's share of the free RB pairs is at least this ...
 #endif
 #ifndef RS_BLOCK_PAIRS
-#define RS_BLOCK_PAIRS 24  // ... in slices of at least this many RB pairs (tools/block_sweep.sh)
-#endif
+#define RS_BLOCK_PAIRS 8   // ... in slices of at least this many RB pairs (tools/block_sweep2.sh: 24 until the shares of a block
+#endif                     //     round lost their run-time branch; with agents in the loop 8 is 4 % faster late in learning)
+#ifndef RS_HINT_PAIRS
+#define RS_HINT_PAIRS 24   // the BLOCK instance is picked for allocations with slices of this many pairs (rs_api.hip: auto_hint,
+#endif                     //     rs_step): on the random script's 12-25-pair slices block rounds lose to the trip loop
 #ifndef RS_PACE_3
 #define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, tools/occ_sweep.sh)
 #define RS_PACE_2 35ull  // > 1.09: 2
