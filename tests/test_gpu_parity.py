@@ -57,6 +57,17 @@ def _wide_actions(rng, n_envs, n_slices, n_prbs, step):
     return a.astype(np.int32)
 
 
+def _mid_actions(rng, n_envs, n_slices, n_prbs, step):
+    """slices around the width at which the BLOCK instances start taking block rounds (RS_BLOCK_PAIRS = 8 RB pairs): 13 to 40
+    RBs each, odd widths (a short last pair) included, one slice of a replica sometimes a single RB pair"""
+    a = rng.integers(13, 41, size=(n_envs, n_slices))
+    a[np.arange(n_envs), rng.integers(0, n_slices, size=n_envs)] = 15 + (step % 4)  # 7 pairs + 1 RB, 8, 8 + 1 RB, 9
+    if step % 5 == 4:
+        a[np.arange(n_envs), rng.integers(0, n_slices, size=n_envs)] = 2
+    assert (a.sum(axis=1) <= n_prbs).all()
+    return a.astype(np.int32)
+
+
 def _compare(scenario, n_envs, steps, fading, churn, seed0, check_trace=True, sample=None, group=None, hint=None,
              actions=None, tweak=None):
     from ranslice.vec_env import VecRanSlice
@@ -129,6 +140,17 @@ def test_block_round_allocations(golden_dir, group):
     for hint in (1, 0):
         _compare(0, n_envs=40, steps=14, fading=_small_fading(golden_dir), churn=True, seed0=4200 + group, group=group,
                  hint=hint, actions=_wide_actions, check_trace=False)
+
+
+@pytest.mark.parametrize('group', [16, 32])
+def test_block_rounds_at_their_threshold(golden_dir, group):
+    """Contested slices of 7, 8 and 9 RB pairs (and up to 20) on the BLOCK instances -- below, at and above the width from
+    which a slice may take block rounds -- per slot and per UE against the oracle's reference loop, then the production
+    (non-tracing) instance's step outputs."""
+    _compare(0, n_envs=48, steps=16, fading=_small_fading(golden_dir), churn=True, seed0=4300 + group, group=group,
+             hint=1, actions=_mid_actions)
+    _compare(0, n_envs=48, steps=16, fading=_small_fading(golden_dir), churn=True, seed0=4400 + group, group=group,
+             hint=1, actions=_mid_actions, check_trace=False)
 
 
 @pytest.mark.parametrize('group', [8, 16, 32])
