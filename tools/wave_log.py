@@ -82,6 +82,21 @@ for k in range(6):
         print('      %.3f : %s' % (end[i_] / span, ' '.join('[%d,%d,%d,%d]' % (x & 0xff, (x >> 8) & 0xff, (x >> 16) & 0xffff, x >> 32) for x in tk)))
     ucu = np.unique(cuid)
     print('   CUs used %d; blocks per CU min %d max %d' % (len(ucu), min((cuid[::4] == c).sum() for c in ucu), max((cuid[::4] == c).sum() for c in ucu)))
+# how the dispatcher deals the blocks of one XCD over its CUs (launch order = cost rank, heaviest first): the CU of each of the
+# XCD's first 48 blocks, and per CU the ranks (within the XCD) of the five blocks it got
+bx = xcc[::4]
+bcu = (cuid[::4] % 256)
+for x_ in (0, 5):
+    ids = np.nonzero(bx == x_)[0]
+    seq = bcu[ids]
+    print('XCD %d: CU of its blocks in launch order (first 48): %s' % (x_, ' '.join('%d' % c for c in seq[:48])))
+    per = {}
+    for r_, c in enumerate(seq):
+        per.setdefault(int(c), []).append(r_)
+    some = sorted(per.items())[:6]
+    print('   ranks of the blocks per CU (first six CUs): %s' % '; '.join('CU %d: %s' % (c, v) for c, v in some))
+    sums = np.array([np.sum(v) for v in per.values()])
+    print('   sum of ranks per CU: min %d max %d (even dealing: all equal %d)' % (sums.min(), sums.max(), 5 * (len(seq) - 1) // 2))
 same = [(place[k] == place[k + 1]).mean() for k in range(len(place) - 1)]
 print('block -> CU placement equal between consecutive launches (share of waves):', np.round(same, 3))
 print('blocks 0..15 of the last launch: XCD', [int(x) for x in ((raw[:W * 16].reshape(W, 16)[::4, 2] >> np.uint64(32)) & np.uint64(7))[:16]])
