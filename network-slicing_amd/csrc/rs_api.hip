@@ -106,6 +106,8 @@ struct rs_handle {
     int block_hint = 0;          // 1: wide contested slices are expected, the 16-lane step uses its BLOCK instance (rs_set_schedule_hint)
     int spread_mode = -1;        // one task per wave (StepArgs::spread): -1 = when the batch has at most spread_max tasks, 0 never, 1 always
     int spread_max = 1024;       // SIMDs of the device (rs_create)
+    int snake_mask = 0x2aaaaaaa;  // the rounds dealt backwards (bit k = round k): every second one; RANSLICE_SNAKE_MASK (developer knob)
+    int snake = 1;               // every second round of waves in reverse cost order (rs_order.hip); RANSLICE_SNAKE=0: off, > 1: the length of a round in waves (developer knob)
     bool hint_auto = true;      // block_hint follows the scenario / the driving agent until the caller sets it
     int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
     bool trace_on = false;
@@ -547,6 +549,8 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->spread_max = cus * 4;
         (void)hipGetLastError();
         if (const char* e = getenv("RANSLICE_SPREAD")) h->spread_mode = atoi(e);  // developer knob
+        if (const char* e = getenv("RANSLICE_SNAKE")) h->snake = atoi(e);
+        if (const char* e = getenv("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
     }
     h->block_hint = auto_hint(h);
     if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
@@ -851,7 +855,8 @@ static int launch_step(rs_handle* h) {
                                h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
-                               h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group);  // modes 4.. = keys 1.. with heavy+light pairing
+                               h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
+                               h->snake == 1 ? h->spread_max : h->snake, h->snake_mask);
             a.order = h->d_order;
         }
         // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict_
 // order[start(bin) + rank] = task; also clears the other parity's counters for the next step
 __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restrict__ D, const int* __restrict__ hist,
                                                             int* hist_next, const uint64_t* __restrict__ slot,
-                                                            int32_t* order, int pair, int tpw) {
+                                                            int32_t* order, int pair, int tpw, int snake, int snake_mask) {
     __shared__ int start[RS_ORDER_BINS];
     __shared__ int part[256];
     constexpr int PER = RS_ORDER_BINS / 256;
@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restr
         } else {
             p = tpw * Hw + (p - Hw);
         }
+    }
+    if (snake > 0 && tpw > 0) {
+        // The dispatcher deals the blocks out round by round: waves w, w + R, w + 2 R, ... (R = SIMDs of the chip) share a
+        // SIMD (tools/wave_log.py: the blocks of an XCD go round its CUs with stride 32).  In plain cost order SIMD 0 then
+        // holds the heaviest wave of EVERY round and SIMD R - 1 the lightest of every round -- a whole wave's cost range
+        // between them.  Every second complete round is therefore dealt backwards (a serpentine): w and 2 R - 1 - w share
+        // a SIMD, and the sums even out.
+        int Wv = p / tpw;
+        const int in = p - Wv * tpw, k = Wv / snake;
+        if (((snake_mask >> (k & 31)) & 1) != 0 && (k + 1) * snake <= n_tasks / tpw) Wv = k * snake + (snake - 1 - (Wv - k * snake));
+        p = Wv * tpw + in;
     }
     order[p] = task;
 }
