@@ -8,7 +8,10 @@
 // the heavy end of the ranking and 64/G - 1 from the light end, heaviest waves first: the dispatcher fills
 // the SIMDs round by round (tools/ubench/placement.hip: every SIMD receives one wave of blocks
 // [256k, 256k + 256)), so each SIMD also gets one wave of each cost stratum, and for batches larger than the
-// chip the order is longest-processing-time-first.  The order only decides which lanes simulate which
+// chip the order is longest-processing-time-first.  Every second round is dealt backwards (a serpentine, end of round 4): in plain
+// cost order one SIMD held the heaviest wave of every round and another the lightest of every round (tools/wave_log.py: the five
+// waves of a SIMD are w, w + 1024 +- 3, w + 2048 +- 3, ...; their last end fell from 0.86 to 0.74 of the launch across w with agents
+// in the loop, 0.85 to 0.82 with the serpentine).  The order only decides which lanes simulate which
 // (replica, slice); results do not depend on it.  RANSLICE_ORDER=0 turns it off, 1-3 sort without pairing
 // (measured slower: homogeneous heavy waves are the slowest of all).
 //

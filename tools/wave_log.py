@@ -36,7 +36,7 @@ def advance(i):
     env.step_resident()
 
 
-for i in range(300 if KBRL else 1500):
+for i in range(int(os.environ.get('WARM', '300')) if KBRL else 1500):
     advance(i)
 env.synchronize()
 T = N * 5
@@ -80,6 +80,18 @@ for k in range(6):
     for i_ in slow:
         tk = w16[i_, 4:8]
         print('      %.3f : %s' % (end[i_] / span, ' '.join('[%d,%d,%d,%d]' % (x & 0xff, (x >> 8) & 0xff, (x >> 16) & 0xffff, x >> 32) for x in tk)))
+    # classes of waves that share a SIMD if the dispatcher deals round by round: wave index mod (number of SIMDs)
+    R_ = len(us)
+    if W % R_ == 0 and W > R_:
+        cls = np.arange(W) % R_
+        blk = np.arange(W) // 4
+        same_simd = np.mean([len(np.unique(blk[sid == s_] % (R_ // 4))) == 1 for s_ in us[::37]])  # the blocks of a SIMD: one residue
+        cend = np.array([end[cls == c_].max() for c_ in range(R_)])
+        oct_ = [cend[i * R_ // 8:(i + 1) * R_ // 8].mean() / span for i in range(8)]
+        print('   SIMDs whose five waves come from blocks b, b + %d, b + 2 x %d, ...: %.0f %% of those sampled; last end of the waves w, w + %d, ... by octile of w (share of the span): %s' % (
+            R_ // 4, R_ // 4, 100 * same_simd, R_, ' '.join('%.3f' % v for v in oct_)))
+    if k == 5:
+        print('   wave indices per SIMD (six SIMDs): %s' % '; '.join(str(sorted(np.nonzero(sid == s_)[0].tolist())) for s_ in us[:3].tolist() + us[500:503].tolist()))
     ucu = np.unique(cuid)
     print('   CUs used %d; blocks per CU min %d max %d' % (len(ucu), min((cuid[::4] == c).sum() for c in ucu), max((cuid[::4] == c).sum() for c in ucu)))
 # how the dispatcher deals the blocks of one XCD over its CUs (launch order = cost rank, heaviest first): the CU of each of the
