@@ -42,7 +42,7 @@ __device__ __forceinline__ int order_key(int mode, int n_ue, int n_prb, int cost
 // block first (LDS atomics), then one global atomic per (block, occupied bin) reserves the block's range.
 __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict__ D, const RsState* __restrict__ Sp,
                                                         const int32_t* __restrict__ actions, int mode, int* hist,
-                                                        uint64_t* slot) {
+                                                        uint64_t* slot, int4 kw) {
     __shared__ int cnt[RS_ORDER_BINS];  // tasks of this block per bin, then the block's base rank in the bin
     for (int k = threadIdx.x; k < RS_ORDER_BINS; k += 256) cnt[k] = 0;
     __syncthreads();
@@ -52,7 +52,30 @@ __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict_
     if (task < n_tasks) {
         const int rep = task / D->n_embb, sl = task - rep * D->n_embb;
         const int n_prb = actions[rep * D->n_slices + sl];
-        bin = RS_ORDER_BINS - 1 - order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);  // heaviest first
+        int key;
+        if (kw.w > 0 || kw.x != 16 || kw.y != 16 || kw.z != 0) {
+            // developer knob RANSLICE_KEY_W = "a,b,c,d" (sixteenths): a x fading samples per slot + b x last step's PF rounds +
+            // c x UEs + d x (slots the backlog needs at this allocation, up to 50) x (UEs + 1)
+            const int n_ue = Sp->t_n_ue[task];
+            int need_rb = 0;
+            if (kw.w > 0) {
+                for (int u = 0; u < n_ue && u < RS_GROUP; ++u) {
+                    const double q = Sp->u_queue[(size_t)task * RS_GROUP + u];
+                    int li = Sp->u_e_snr[(size_t)task * RS_GROUP + u] - D->lut_lo;
+                    li = li < 0 ? 0 : (li >= D->lut_n ? D->lut_n - 1 : li);
+                    const int rate = D->lut_rate[li] > 0 ? D->lut_rate[li] : 1;
+                    const double rb = q / (double)rate;
+                    need_rb += rb < 100000.0 ? (int)rb : 100000;
+                }
+            }
+            int drain = n_prb > 0 ? need_rb / n_prb : 0;
+            drain = drain < 50 ? drain : 50;
+            key = (kw.x * (n_ue * n_prb) + kw.y * Sp->t_cost[task] + kw.z * n_ue + kw.w * drain * (n_ue + 1)) >> 4;
+            key = key < 0 ? 0 : (key < RS_ORDER_BINS ? key : RS_ORDER_BINS - 1);
+        } else {
+            key = order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);
+        }
+        bin = RS_ORDER_BINS - 1 - key;  // heaviest first
         local = atomicAdd(&cnt[bin], 1);
     }
     __syncthreads();
