@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Developer aid: step time and task sets handed over per step (migration in embb_step_kernel) on the bench's random script.
-RANSLICE_MIGRATE=0|1 python tools/mig_probe.py [--kbrl]"""
+(with tools/experiments/step_migration.patch applied) RANSLICE_MIGRATE=0|1 python tools/experiments/mig_probe.py [--kbrl]"""
 import ctypes as C, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, 'network-slicing_amd'))
 import numpy as np
 from ranslice.config import make_config
