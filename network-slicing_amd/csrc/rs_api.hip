@@ -107,6 +107,7 @@ struct rs_handle {
     int spread_mode = -1;        // one task per wave (StepArgs::spread): -1 = when the batch has at most spread_max tasks, 0 never, 1 always
     int spread_max = 1024;       // SIMDs of the device (rs_create)
     int key_w[4] = {16, 16, 0, 0};  // weights of the cost key in sixteenths (RANSLICE_KEY_W, developer knob; rs_order.hip)
+    int rot_mask = 0;             // rounds rotated by half a round (RANSLICE_SNAKE_ROT, developer knob)
     int snake_mask = 0x2aaaaaaa;  // the rounds dealt backwards (bit k = round k): every second one; RANSLICE_SNAKE_MASK (developer knob)
     int snake = 1;               // every second round of waves in reverse cost order (rs_order.hip); RANSLICE_SNAKE=0: off, > 1: the length of a round in waves (developer knob)
     bool hint_auto = true;      // block_hint follows the scenario / the driving agent until the caller sets it
@@ -553,6 +554,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         if (const char* e = getenv("RANSLICE_SNAKE")) h->snake = atoi(e);
         if (const char* e = getenv("RANSLICE_KEY_W")) (void)sscanf(e, "%d,%d,%d,%d", &h->key_w[0], &h->key_w[1], &h->key_w[2], &h->key_w[3]);
         if (const char* e = getenv("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
+        if (const char* e = getenv("RANSLICE_SNAKE_ROT")) h->rot_mask = (int)strtol(e, nullptr, 0);
     }
     h->block_hint = auto_hint(h);
     if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
@@ -858,7 +860,7 @@ static int launch_step(rs_handle* h) {
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
                                h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
-                               h->snake == 1 ? h->spread_max : h->snake, h->snake_mask);
+                               h->snake == 1 ? h->spread_max : h->snake, h->snake_mask, h->rot_mask);
             a.order = h->d_order;
         }
         // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)

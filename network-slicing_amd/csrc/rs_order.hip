@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict_
 // order[start(bin) + rank] = task; also clears the other parity's counters for the next step
 __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restrict__ D, const int* __restrict__ hist,
                                                             int* hist_next, const uint64_t* __restrict__ slot,
-                                                            int32_t* order, int pair, int tpw, int snake, int snake_mask) {
+                                                            int32_t* order, int pair, int tpw, int snake, int snake_mask, int rot_mask) {
     __shared__ int start[RS_ORDER_BINS];
     __shared__ int part[256];
     constexpr int PER = RS_ORDER_BINS / 256;
@@ -144,6 +144,8 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restr
         int Wv = p / tpw;
         const int in = p - Wv * tpw, k = Wv / snake;
         if (((snake_mask >> (k & 31)) & 1) != 0 && (k + 1) * snake <= n_tasks / tpw) Wv = k * snake + (snake - 1 - (Wv - k * snake));
+        // (developer knob: rounds rotated by half a round instead -- evens out a U-shaped cost profile where reversal evens out a slope)
+        if (((rot_mask >> (k & 31)) & 1) != 0 && (k + 1) * snake <= n_tasks / tpw) Wv = k * snake + (Wv - k * snake + snake / 2) % snake;
         p = Wv * tpw + in;
     }
     order[p] = task;
