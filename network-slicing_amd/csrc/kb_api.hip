@@ -664,6 +664,12 @@ static int enqueue_closed_step(kb_handle* k, rs_handle* env) {
 extern "C" int kb_run_resident(kb_handle* k, rs_handle* env, int n_steps, int use_graph) {
     if (!k || !env || n_steps < 0) return RS_EINVAL;
     int done = 0, rc;
+    // rocprofv3 (ROCm 7.2) dies with SIGSEGV inside hipGraphLaunch of this loop's graph (kernels, memory copies, memsets; the
+    // simulator-only graph of rs_run_random is fine under it): with a profiler tool attached the steps are enqueued one by one,
+    // same results.  KBRL_GRAPH_UNDER_PROFILER=1 keeps the graph.
+    static const bool no_graph = getenv("ROCP_TOOL_LIBRARIES") != nullptr &&
+                                 !(getenv("KBRL_GRAPH_UNDER_PROFILER") && atoi(getenv("KBRL_GRAPH_UNDER_PROFILER")) != 0);
+    if (no_graph) use_graph = 0;
     if (use_graph && !k->timing && !env->timing && !k->D.shared && n_steps >= 3) {
         if (!k->gexec || k->g_env != env || k->g_sig != env->launch_sig) {
             // (one plain step first: whatever the loop creates lazily -- events, the schedule hint -- exists before the capture)
