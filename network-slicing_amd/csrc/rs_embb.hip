@@ -113,6 +113,11 @@ namespace rs {
 #ifndef RS_HINT_PAIRS
 #define RS_HINT_PAIRS 24   // the BLOCK instance is picked for allocations with slices of this many pairs (rs_api.hip: auto_hint,
 #endif                     //     rs_step): on the random script's 12-25-pair slices block rounds lose to the trip loop
+#ifndef RS_PACE_3B
+#define RS_PACE_3B 46ull  // the same three thresholds in the BLOCK instances (agents' allocations: a few wide tasks carry the launch, and
+#define RS_PACE_2B 44ull  // a wave that is merely a little behind should not yet take issue slots from them): > 1.44 / 1.375 / 1.31 x the
+#define RS_PACE_1B 42ull  // reference pace (tools/pace_sweep.sh: step kernel 1.30 -> 1.25 ms early, 1.545 -> 1.50 late in learning)
+#endif
 #ifndef RS_PACE_3
 #define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, tools/occ_sweep.sh)
 #define RS_PACE_2 35ull  // > 1.09: 2
@@ -862,9 +867,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
         if (RS_DYN_PRIO && pace_ref != 0ull && t >= 2) {
             const unsigned long long el = (__builtin_amdgcn_s_memtime() - pace_t0) * 32ull;
             const unsigned long long due = (unsigned long long)t * pace_ref;
-            if (el > due * RS_PACE_3) __builtin_amdgcn_s_setprio(3);       // in 32nds of the reference pace
-            else if (el > due * RS_PACE_2) __builtin_amdgcn_s_setprio(2);
-            else if (el > due * RS_PACE_1) __builtin_amdgcn_s_setprio(1);
+            if (el > due * (BLOCK ? RS_PACE_3B : RS_PACE_3)) __builtin_amdgcn_s_setprio(3);       // in 32nds of the reference pace
+            else if (el > due * (BLOCK ? RS_PACE_2B : RS_PACE_2)) __builtin_amdgcn_s_setprio(2);
+            else if (el > due * (BLOCK ? RS_PACE_1B : RS_PACE_1)) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
         }
         const int now = clock0 + t + 1;
