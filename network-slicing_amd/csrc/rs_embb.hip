@@ -592,7 +592,9 @@ __device__ __forceinline__ double team_response(const double* mi, const double* 
 // span would keep 8 lanes busy with 12-23 sigmoids each in a row; here the WHOLE wave evaluates it, one RB per lane
 // and pass, into the wave's LDS buffer `wmi`, and one team adds the buffer up in numpy's order.  Out of line on
 // purpose: random-action batches never come here, and in line its registers cost the hot loop spills.
+#ifndef RS_WIDE_SPAN
 #define RS_WIDE_SPAN 64
+#endif
 #define RS_WIDE_MAX 192   // wider spans (193..256 RBs) take the team path
 __device__ __noinline__ double wide_response(const double* mi, const double* fad, double* wmi, const double* nom_wave,
                                              bool mine, int rbs, int span_col, int mod) {
