@@ -10,29 +10,36 @@ in HBM when the timed region starts; nothing crosses PCIe inside it.
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Replicas are independent, so GPUs shard them with no data-path collective (weak scaling: 4096
-replicas per GPU).  torch is used only for the process group (gloo: barrier, max-over-ranks) and torch.cuda.synchronize.
+No torch here: the library's own rs_device_count / rs_synchronize, and for N > 1 a plain TCP group on 127.0.0.1
+(tools/rank_group.py: barrier, MAX of the elapsed time) found through RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT,
+whoever launched the ranks.  Replicas are independent, so GPUs shard them with no data-path collective (weak scaling:
+4096 replicas per GPU).
+
+OUTPUT.  The LAST stdout line is the compact record (< 4 KB): metric, value, ms_per_step, config, roofline (with the
+kernel's real limiter beside the HBM figure), cpu_baseline, and the summaries `kbrl` (config 3) and `shared_kbrl` (config 4:
+the RCCL exchange).  The full record (every sub-record at length) goes to profiles/bench_full_last.json and is printed on an
+EARLIER line that starts with "# full record: ".
 
 Before the W warm-up steps the environments are advanced until the UE population is stationary: blocks of 500
 steps (25 s of simulated time; the holding times have a 30 s mean) until the mean number of UEs per slice changes
 by less than 0.5 % from one block to the next (every rank runs the same number of blocks).  This is environment
 set-up, not part of the timed work; the line reports the steps it took and the population.
 
-The JSON line also carries
-  roofline     : algorithmic bytes per launch of the dominant kernel (embb_step_kernel) divided by
-                 its mean launch duration measured with HIP events on the launch stream, against
-                 the 8 TB/s HBM peak (DESIGN.md §Measurement states the byte model).  `traffic` is null: this
-                 process does not read PMC counters; the HBM bytes of a separate rocprofv3 --pmc run of this
-                 same command are reported as `profiled_traffic` with the file they come from;
-  cpu_baseline : the CPU oracle (a C port of the reference's numpy path, pinned bit-exact to the
-                 reference on golden tapes) timed on this box's host cores on a bounded sample of
-                 the same workload -- a reported baseline, never the thing measured above;
-  kbrl         : (1 GPU) BASELINE config 3 -- the same 4096 replicas with one KBRL agent each, closed loop on
-                 the device, at two points of learning: steps 100-300 (dictionaries of tens of landmarks) and from
-                 step 3000 (hundreds).  `value` is the LATE one.  Per point: env-steps/s, per-phase kernel times, the HBM
-                 roofline of the two kernels that stream Kinv (bytes from their own work plan / HIP-event launch times),
-                 the MFMA work of select_action, dictionary sizes, the pool in use and the step at which it would run out.
-                 kbrl = the 'tdl' trace profile, kbrl_sos = the fixtures' profile (rounds 1-3 quoted that one).
+  roofline     : algorithmic bytes per launch of the dominant kernel (embb_step_kernel) divided by its mean launch
+                 duration measured with HIP events on the launch stream, against the 8 TB/s HBM peak (DESIGN.md section 4
+                 states the byte model).  `traffic`: HBM bytes per launch from a separate rocprofv3 --pmc run of this
+                 command at the same UE population (profiles/hbm_traffic.json; null when the populations differ);
+                 `limiter`: what actually bounds the kernel (VALU issue slots), from the SQ counters of the same run;
+  cpu_baseline : the CPU oracle (a C port of the reference's numpy path, pinned bit-exact to the reference on golden
+                 tapes) timed on this box's host cores on a bounded sample of the same workload -- a reported
+                 baseline, never the thing measured above;
+  kbrl         : (1 GPU) BASELINE config 3 -- the same 4096 replicas with one KBRL agent each, closed loop on the
+                 device, at two points of learning: steps 100-300 and from step 3000 (`late_value`); HBM fractions of
+                 the kernels that stream Kinv and the landmarks, MFMA work of select_action, the pool's horizon;
+  shared_kbrl  : BASELINE config 4 -- scenario index 2, 4096 replicas per GPU, ONE dictionary per slice shared by all replicas
+                 of all ranks, the exchange = ncclAllGather inside libranslice.so (kb_shared_step_resident).  Runs in a child
+                 process per rank under a timeout: its failure cannot take the headline with it.  `rccl_ranks` is what the
+                 communicator itself reports (kb_comm_info).
   python bench.py --scaling 1,2,4,8 prints ONE line with the curve over N and the CPU baseline.
 """
 import argparse
@@ -134,7 +141,7 @@ def cpu_baseline(burn, timed):
     with ctx.Pool(1, initializer=_init_pool, initargs=(b1,)) as pool:
         one = pool.map(_cpu_worker, [(0, {}, burn, timed, _barrier_wait, [0])], chunksize=1)[0]
     return dict(value=total / (t1 - t0), unit='env-steps/s', cores=cores, kind='port',
-                single_core_value=one[2] / (one[1] - one[0]),
+                single_core_value=one[2] / (one[1] - one[0]), steps=timed, burn_in=burn,
                 sample='%d replicas (one per host core) x %d steps of the same scenario_0 workload and action '
                        'script after a %d-step burn-in; C oracle (oracle/rs_oracle.c), 1 thread per replica; '
                        'single_core_value: one replica alone, same steps' % (cores, timed, burn))
@@ -283,7 +290,7 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
     rec = {
         'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device (%s traces)'
                     % (n_envs, profile),
-        'dictionary_capacity': cap, 'pool_bytes': KBRL_POOL_BYTES,
+        'traces': profile, 'dictionary_capacity': cap, 'pool_bytes': KBRL_POOL_BYTES,
         'value': head['value'], 'unit': 'env-steps/s', 'ms_per_step': head['ms_per_step'], 'value_at_steps': head['steps'],
         'roofline': (head['kinv_streaming'] or {}).get('rank1'),
         'early': early, 'late': late,
@@ -306,8 +313,7 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
 
 def run_scaling(args):
     """--scaling 1,2,4,8: the whole report from one command -- the CPU baseline once, then this script once per N (each
-    an independent launch: N = 1 in a child process, N > 1 through the launcher), one JSON line with the curve.  Ns
-    beyond the devices of the box are listed as skipped."""
+    an independent launch), one JSON line with the curve.  Ns beyond the devices of the box are listed as skipped."""
     from ranslice import _lib
     ns = [int(x) for x in args.scaling.split(',') if x]
     ndev = _lib.device_count()
@@ -319,6 +325,8 @@ def run_scaling(args):
             continue
         cmd = [sys.executable, os.path.abspath(__file__), '--gpus', str(n), '--steps', str(args.steps), '--warmup',
                str(args.warmup), '--envs-per-gpu', str(args.envs_per_gpu), '--no-cpu-baseline', '--no-kbrl']
+        if n == 1 or args.no_shared:
+            cmd += ['--no-shared']
         if args.burn_in >= 0:
             cmd += ['--burn-in', str(args.burn_in)]
         if args.graph:
@@ -332,16 +340,231 @@ def run_scaling(args):
             curve.append({'n_gpus': n, 'error': 'rc %d' % out.returncode})
             continue
         line = json.loads(lines[-1])
-        curve.append({'n_gpus': n, 'value': line['value'], 'ms_per_step': line['ms_per_step'],
-                      'roofline_frac': line['roofline']['frac'], 'kernel_ms': line['roofline']['kernel_ms'],
-                      'global_envs': line['config']['global_envs']})
+        pt = {'n_gpus': n, 'value': line['value'], 'ms_per_step': line['ms_per_step'],
+              'roofline_frac': line['roofline']['frac'], 'kernel_ms': line['roofline']['kernel_ms'],
+              'global_envs': line['config']['global_envs']}
+        sh = line.get('shared_kbrl')
+        if sh:
+            pt['shared_kbrl'] = {k: sh.get(k) for k in ('value', 'ms_per_step', 'rccl_ranks', 'error') if k in sh}
+        curve.append(pt)
     base = next((c['value'] for c in curve if c.get('n_gpus') == 1 and 'value' in c), None)
     for c in curve:
         if base and 'value' in c:
             c['per_gpu_vs_1gpu'] = c['value'] / c['n_gpus'] / base
     print(json.dumps({'metric': 'env-steps/sec (batched RanSlice.step, scenario_0)', 'unit': 'env-steps/s',
-                      'scaling': 'weak', 'curve': curve, 'cpu_baseline': cpu, 'dtype': 'f64', 'data': 'synthetic'}),
+                      'scaling': 'weak', 'curve': curve, 'cpu_baseline': compact_cpu(cpu), 'dtype': 'f64', 'data': 'synthetic'}),
           flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- config 4: the RCCL leg
+SHARED_SCENARIO = 2           # BASELINE config 4: scenario index 2 (100 PRBs, 1 eMBB + 4 mMTC slices)
+SHARED_BUDGET = 256           # proposals per slice and exchange round
+SHARED_CAPACITY = 1024        # landmarks per shared dictionary (config 3/4 capacity)
+SHARED_TIMEOUT_S = 300
+
+
+def shared_leg(args):
+    """One rank of BASELINE config 4 (child process of a bench rank): 4096 scenario_2 replicas on this rank's GPU, ONE KBRL
+    dictionary per slice shared by the replicas of all ranks, closed loop on the device (kb_shared_step_resident).  The exchange
+    is ncclAllGather inside libranslice.so; this script only hands the 128-byte communicator id from rank 0 to the others.
+    Rank 0 prints one JSON line."""
+    import ctypes as C
+    from rank_group import RankGroup
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (('RANK', 0), ('LOCAL_RANK', 0), ('WORLD_SIZE', 1)))
+    from ranslice import _lib
+    from ranslice.config import make_config, EMBB_A, EMBB_SEC, MMTC_A, MMTC_SEC
+    from ranslice.fading import synth_fading
+    from ranslice.kbrl_dev import SharedVecKBRL
+    from ranslice.sharding import shard_range, replica_seeds
+    from ranslice.vec_env import VecRanSlice
+    device = local_rank % _lib.device_count() if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1' else local_rank
+    group = RankGroup(rank, world, timeout=120.0)
+    N = args.envs_per_gpu
+    cfg = make_config(SHARED_SCENARIO, n_envs=N)
+    first, count = shard_range(world * N, rank, world)
+    env = VecRanSlice(n_envs=N, cfg=cfg, fading=[synth_fading(t, FADING_COLS) for t in range(3)], device=device)
+    dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
+    agent = SharedVecKBRL(N, dims, cfg.n_prbs, budget=SHARED_BUDGET, max_rounds=1, capacity=SHARED_CAPACITY, device=device,
+                          first_env=first)
+    # a communicator even for one rank: the exchange then IS ncclAllGather on every box the bench runs on
+    uid = group.bcast_bytes(SharedVecKBRL.unique_id() if rank == 0 else None)
+    agent.comm_init(uid, rank, world)
+    rccl_rank, rccl_ranks = agent.comm_info()
+    rng = np.random.default_rng(1000 + rank)
+    ia = np.concatenate([rng.integers(EMBB_A[0], EMBB_A[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_A[0], MMTC_A[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+    sf = np.concatenate([rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(N, cfg.n_embb)),
+                         rng.integers(MMTC_SEC[0], MMTC_SEC[1], size=(N, cfg.n_mmtc))], axis=1).astype(np.int32)
+    env.reset(seeds=replica_seeds(0, first, count))
+    agent.reset(ia, sf, seeds=replica_seeds(7, first, count))
+    env._check(env.L.rs_step(env.h, np.ascontiguousarray(ia).ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+
+    def run(k):
+        for _ in range(k):
+            agent.step_resident(env)
+            env.step_resident()
+    run(args.shared_warmup)
+    env.synchronize()
+    agent.synchronize()
+    group.barrier()
+    t0 = time.perf_counter()
+    run(args.shared_steps)
+    env.synchronize()
+    agent.synchronize()
+    dt = group.max(time.perf_counter() - t0)
+    sizes = [int(agent.learner(0, s)['m']) for s in range(len(dims))]
+    all_sizes = group.allgather(sizes)
+    all_ranks = group.allgather([rccl_rank, rccl_ranks])
+    if rank == 0:
+        S = len(dims)
+        blk = 8 * S * (1 + SHARED_BUDGET * 18)          # doubles of one rank's proposal block (ranslice.h: KB_PROP_WIDTH)
+        print(json.dumps({
+            'workload': 'scenario index %d (%d PRBs, %d eMBB + %d mMTC slices), %d replicas per GPU x %d GPUs, one KBRL dictionary '
+                        'per slice shared by all replicas, closed loop on the device' % (SHARED_SCENARIO, cfg.n_prbs, cfg.n_embb,
+                                                                                         cfg.n_mmtc, N, world),
+            'value': world * N * args.shared_steps / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / args.shared_steps,
+            'steps': args.shared_steps, 'warmup': args.shared_warmup, 'n_gpus': world,
+            'rccl_ranks': rccl_ranks, 'rccl_rank_of_each_process': [r[0] for r in all_ranks],
+            'collective': 'ncclAllGather (RCCL, bound by libranslice.so: kb_shared_step_resident), one per step on the agent\'s stream',
+            'allgather_bytes_per_rank_per_step': blk, 'allgather_bytes_total_per_step': blk * world,
+            'budget': SHARED_BUDGET, 'capacity': SHARED_CAPACITY, 'dictionary_sizes': sizes,
+            'dictionaries_identical_on_all_ranks': all(x == sizes for x in all_sizes),
+        }), flush=True)
+    env.close()
+    agent.close()
+    group.barrier()
+    group.close()
+
+
+def run_shared_leg(args, rank, local_rank, world, tag):
+    """start this rank's child of the config-4 leg and wait for it (bounded); rank 0 returns the leg's record"""
+    cmd = [sys.executable, os.path.abspath(__file__), '--shared-leg', '--envs-per-gpu', str(args.envs_per_gpu),
+           '--shared-steps', str(args.shared_steps), '--shared-warmup', str(args.shared_warmup)]
+    env = dict(os.environ)
+    env.update({'RANK': str(rank), 'LOCAL_RANK': str(local_rank), 'WORLD_SIZE': str(world),
+                'RANSLICE_RDZV_FILE': os.path.join('/tmp', 'ranslice_shared_%s' % tag)})
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('KBRL_COLLECTIVE_TIMEOUT_S', '60')
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=SHARED_TIMEOUT_S)
+    except subprocess.TimeoutExpired:
+        return {'error': 'the config-4 leg did not finish within %d s (killed)' % SHARED_TIMEOUT_S}
+    if rank != 0:
+        return None
+    lines = [x for x in out.stdout.splitlines() if x.startswith('{')]
+    if out.returncode != 0 or not lines:
+        err = [x for x in out.stderr.strip().splitlines() if x.strip()]
+        return {'error': 'rc %d: %s' % (out.returncode, (err[-1] if err else 'no output')[-300:])}
+    return json.loads(lines[-1])
+
+
+# ---------------------------------------------------------------------------------------------- the compact line
+LINE_LIMIT = 4096      # the driver keeps the tail of stdout: the last line must fit with room to spare
+
+
+def _r(x, nd=4):
+    """round to nd significant digits (None and non-numbers pass through)"""
+    if isinstance(x, bool) or not isinstance(x, (int, float)):
+        return x
+    if x == 0 or x != x or x in (float('inf'), float('-inf')):
+        return x
+    from math import floor, log10
+    return round(x, nd - 1 - int(floor(log10(abs(x)))))
+
+
+def compact_cpu(cpu):
+    if not cpu:
+        return cpu
+    c = {k: _r(cpu.get(k)) for k in ('value', 'unit', 'cores', 'kind', 'single_core_value')}
+    c['sample'] = '%s replicas x %s steps, C oracle, 1 thread/replica, same workload' % (cpu.get('cores'), cpu.get('steps', '?'))
+    return c
+
+
+def compact_kbrl(k):
+    """config 3 in a dozen numbers"""
+    if not k or 'error' in k:
+        return k
+    late, early = k.get('late') or {}, k.get('early') or {}
+    head = late or early
+    st = head.get('kinv_streaming') or {}
+    c = {'workload': 'config 3: 4096 replicas + one KBRL agent each, closed loop on device, %s traces' % k.get('traces', 'tdl'),
+         'early_value': _r(early.get('value')), 'early_steps': early.get('steps'),
+         'late_value': _r(late.get('value')), 'late_steps': late.get('steps'), 'late_ms_per_step': _r(late.get('ms_per_step')),
+         'unit': 'env-steps/s',
+         'late_step_kernel_ms': _r(head.get('embb_kernel_ms')), 'late_update_phase_ms': _r(head.get('kb_update_phase_ms')),
+         'late_select_phase_ms': _r(head.get('kb_select_ms')),
+         'rank1_frac': _r((st.get('rank1') or {}).get('frac')), 'matvec_frac': _r((st.get('matvec') or {}).get('frac')),
+         'select_bin_frac': _r((head.get('select_bin') or {}).get('frac')),
+         'hbm_peak_GBs': HBM_PEAK_GBS,
+         'mfma_instructions': (head.get('select_mfma') or {}).get('instructions_per_launch'),
+         'mfma_kernel': 'select_gemm_kernel (v_mfma_f64_16x16x4)',
+         'dictionary_size_mean': _r(head.get('dictionary_size_mean')), 'dictionary_size_max': head.get('dictionary_size_max'),
+         'pool_GB_used': _r((head.get('pool') or {}).get('used_bytes', 0) / 1e9),
+         'pool_exhausted_near_step': _r((head.get('pool_horizon') or {}).get('exhausted_near_step'))}
+    return c
+
+
+def compact_shared(sh):
+    if not sh or 'error' in sh:
+        return sh
+    keys = ('value', 'unit', 'ms_per_step', 'steps', 'n_gpus', 'rccl_ranks', 'allgather_bytes_total_per_step', 'capacity',
+            'dictionary_sizes', 'dictionaries_identical_on_all_ranks')
+    c = {k: _r(sh.get(k)) for k in keys}
+    c['workload'] = 'config 4: scenario index 2, 4096 replicas/GPU, shared dictionaries, ncclAllGather per step'
+    return c
+
+
+def compact_line(full):
+    """The last stdout line: everything the rules credit, under LINE_LIMIT bytes.  Sub-records that would push it over are
+    dropped in a fixed order (never the headline, the roofline or the CPU baseline)."""
+    roof = dict(full['roofline'])
+    for k in ('profiled_traffic',):
+        roof.pop(k, None)
+    roof = {k: (_r(v, 5) if not isinstance(v, dict) else {kk: _r(vv) for kk, vv in v.items()}) for k, v in roof.items()}
+    line = {k: full[k] for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                 'vs_baseline', 'dtype', 'data')}
+    line['value'] = _r(line['value'], 6)
+    line['ms_per_step'] = _r(line['ms_per_step'], 5)
+    line['config'] = dict(full['config'])
+    line['roofline'] = roof
+    line['cpu_baseline'] = compact_cpu(full.get('cpu_baseline'))
+    if 'kbrl' in full:
+        line['kbrl'] = compact_kbrl(full['kbrl'])
+    if 'shared_kbrl' in full:
+        line['shared_kbrl'] = compact_shared(full['shared_kbrl'])
+    line['full_record'] = 'profiles/bench_full_last.json (also the stdout line before this one)'
+    for victim in ('full_record', 'shared_kbrl', 'kbrl'):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        if victim in line:
+            line[victim] = {'dropped': 'line over %d bytes; see the full record' % LINE_LIMIT} if victim != 'full_record' else None
+    return line
+
+
+def spawn_ranks(args):
+    """python bench.py --gpus N outside any launcher: time the CPU baseline here, then start one rank per GPU (this script
+    again, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment as torch.distributed.run sets them)"""
+    cpu_file = None
+    if not args.no_cpu_baseline:
+        cpu_file = os.path.join('/tmp', 'bench_cpu_%d.json' % os.getpid())
+        with open(cpu_file, 'w') as f:
+            json.dump(cpu_baseline(1000, args.cpu_steps), f)
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({'RANK': str(r), 'LOCAL_RANK': str(r), 'WORLD_SIZE': str(args.gpus), 'MASTER_ADDR': '127.0.0.1',
+                    'MASTER_PORT': str(port)})
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        cmd = [sys.executable, os.path.abspath(__file__)] + list(sys.argv[1:])
+        cmd += ['--cpu-baseline-json', cpu_file] if cpu_file else (['--no-cpu-baseline'] if '--no-cpu-baseline' not in sys.argv else [])
+        procs.append(subprocess.Popen(cmd, env=env))
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+    if cpu_file and os.path.exists(cpu_file):
+        os.remove(cpu_file)
+    return rc
 
 
 def main():
@@ -354,7 +577,12 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=ENVS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kbrl', action='store_true')
+    ap.add_argument('--no-shared', action='store_true', help='skip the config-4 leg (shared dictionaries over RCCL)')
     ap.add_argument('--kbrl-steps', type=int, default=200)
+    ap.add_argument('--kbrl-sos', action='store_true', help="config 3 also on the fixtures' trace profile (full record only)")
+    ap.add_argument('--shared-steps', type=int, default=200)
+    ap.add_argument('--shared-warmup', type=int, default=30)
+    ap.add_argument('--shared-leg', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--graph', action='store_true',
                     help='replay the timed loop from a captured hipGraph (rs_run_random); the kernel time for the '
                          'roofline is then taken from a separate event-timed pass of 100 steps')
@@ -366,6 +594,9 @@ def main():
     if args.scaling:
         run_scaling(args)
         return
+    if args.shared_leg:
+        shared_leg(args)
+        return
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -374,30 +605,12 @@ def main():
     cpu_burn = 1000
 
     if args.gpus > 1 and not under_launcher:
-        # one command for the whole report: time the CPU baseline here, then launch one rank per GPU
-        cpu_file = None
-        if not args.no_cpu_baseline:
-            cpu_file = os.path.join('/tmp', 'bench_cpu_%d.json' % os.getpid())
-            with open(cpu_file, 'w') as f:
-                json.dump(cpu_baseline(cpu_burn, args.cpu_steps), f)
-        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-               '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)]
-        cmd += [a for a in sys.argv[1:]]
-        if cpu_file:
-            cmd += ['--cpu-baseline-json', cpu_file]
-        else:
-            cmd += ['--no-cpu-baseline'] if '--no-cpu-baseline' not in sys.argv else []
-        env = dict(os.environ)
-        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        rc = subprocess.call(cmd, env=env)
-        if cpu_file and os.path.exists(cpu_file):
-            os.remove(cpu_file)
-        sys.exit(rc)
+        sys.exit(spawn_ranks(args))
     if world != args.gpus:
         raise SystemExit('WORLD_SIZE (%d) != --gpus (%d)' % (world, args.gpus))
 
-    # the CPU baseline forks worker processes: do it before any HIP/torch initialisation (rank 0 only; the other
-    # ranks wait for it in the process-group rendezvous)
+    # the CPU baseline forks worker processes: do it before any HIP initialisation (rank 0 only; the other
+    # ranks wait for it in the rendezvous of the rank group)
     cpu_base = None
     if rank == 0:
         if args.cpu_baseline_json and os.path.exists(args.cpu_baseline_json):
@@ -406,36 +619,25 @@ def main():
         elif not args.no_cpu_baseline:
             cpu_base = cpu_baseline(cpu_burn, args.cpu_steps)
 
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
-    # RANSLICE_BENCH_SHARE_GPU=1 (developer check of the N > 1 path on a box with fewer GPUs than ranks): ranks wrap around the
-    # visible devices; the line says so and is NOT a scaling measurement
-    if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1':
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        # The ranks only agree on wall-clock time (barrier, MAX of the elapsed time): a gloo group over 127.0.0.1.  RanSlice.step
-        # has no collective, and the one RCCL communicator of the build (the shared-dictionary exchange) is formed inside
-        # libranslice.so, which binds the RCCL copy the process has already mapped (torch links one) rather than a second one.
-        dist.init_process_group(backend='gloo')
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    from dist_util import max_over_ranks
+    from rank_group import RankGroup
+    from ranslice import _lib
     from ranslice.config import make_config
     from ranslice.fading import synth_fading
     from ranslice.sharding import shard_range, replica_seeds, aggregate_throughput
     from ranslice.vec_env import VecRanSlice
+    ndev = _lib.device_count()
+    if ndev < 1:
+        raise SystemExit('bench.py needs a GPU: the product path has no CPU fallback')
+    # RANSLICE_BENCH_SHARE_GPU=1 (developer check of the N > 1 path on a box with fewer GPUs than ranks): ranks wrap around the
+    # visible devices; the line says so and is NOT a scaling measurement
+    share_gpu = os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1'
+    device = local_rank % ndev if share_gpu else local_rank
+    group = RankGroup(rank, world, timeout=900.0)    # (rank 0 may still be timing the CPU baseline when the others arrive)
 
     n_envs = args.envs_per_gpu
     cfg = make_config(SCENARIO, n_envs=n_envs)
     fading = [synth_fading(t, FADING_COLS) for t in range(3)]
-    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, device=local_rank)
+    env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=fading, device=device)
     # replica ids are global: rank r owns [r*n_envs, (r+1)*n_envs)
     first, count = shard_range(world * n_envs, rank, world)
     assert count == n_envs
@@ -469,8 +671,7 @@ def main():
             burn_hist.append(round(cur, 4))
             done = prev is not None and abs(cur - prev) <= 0.005 * prev
             # every rank must run the same number of blocks: continue while ANY rank is still moving
-            if world > 1:
-                done = max_over_ranks(0.0 if done else 1.0) == 0.0
+            done = group.max(0.0 if done else 1.0) == 0.0
             prev = cur
             if done:
                 break
@@ -480,8 +681,7 @@ def main():
     c0 = env.counters()
     env.set_kernel_timing(True)
 
-    barrier()
-    torch.cuda.synchronize()
+    group.barrier()
     env.synchronize()
     t0 = time.perf_counter()
     if args.graph:
@@ -491,8 +691,7 @@ def main():
     else:
         run(args.steps)
     env.synchronize()
-    torch.cuda.synchronize()
-    barrier()
+    group.barrier()
     t1 = time.perf_counter()
 
     c1 = env.counters()
@@ -505,9 +704,10 @@ def main():
     out = env.fetch()  # also surfaces capacity-overflow errors
     assert np.isfinite(out['reward']).all()
 
-    elapsed = max_over_ranks(t1 - t0)
+    elapsed = group.max(t1 - t0)
     env.close()
 
+    full = None
     if rank == 0:
         value = aggregate_throughput(n_envs * args.steps, world, elapsed)
         # ---- roofline of the dominant kernel (per launch = one step of n_envs replicas)
@@ -524,23 +724,34 @@ def main():
         roof = {
             'bound': 'hbm', 'kernel': 'embb_step_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-            'traffic': None,   # not measured by this process (needs rocprofv3 --pmc); see profiled_traffic
+            'traffic': None,
             'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'launches_timed': launches,
             'bytes_per_env_step': alg_bytes / n_envs, 'mean_ues_per_slice': mean_ue,
             'pf_iterations_per_env_step': (c1[2] - c0[2]) / args.steps / n_envs,
         }
+        # Counters of a separate rocprofv3 --pmc run of this command (tools/profile_round.sh), NOT of this process: the HBM bytes per
+        # launch are comparable with algorithmic_bytes_per_launch only at the same UE population, so `traffic` is filled in only then.
+        # `limiter` is what the SQ counters of that run say bounds the kernel: VALU issue slots, not HBM.
         tpath = os.path.join(ROOT, 'profiles', 'hbm_traffic.json')
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
                     prof = json.load(f)
-                # numbers of a separate rocprofv3 --pmc run of this command, NOT of this process
+                pop = prof.get('mean_ues_per_slice')
+                same = pop is not None and abs(pop - mean_ue) <= 0.03 * mean_ue and n_envs == prof.get('n_envs', ENVS_PER_GPU)
+                if same:
+                    roof['traffic'] = prof.get('embb_step_kernel_bytes_per_launch')
+                    roof['traffic_source'] = prof.get('file', 'profiles/hbm_traffic.json')
                 roof['profiled_traffic'] = {'bytes_per_launch': prof.get('embb_step_kernel_bytes_per_launch'),
-                                            'valu_issue_frac': prof.get('valu_issue_frac'),
+                                            'mean_ues_per_slice': pop, 'same_population_as_this_run': bool(same),
                                             'source': 'profiles/hbm_traffic.json (%s)' % prof.get('source', 'see file')}
+                if prof.get('valu_issue_frac') is not None:
+                    roof['limiter'] = {'bound': 'valu_issue', 'frac': prof['valu_issue_frac'],
+                                       'valu_insts_per_launch': prof.get('valu_insts_per_launch'),
+                                       'source': prof.get('valu_issue_file', 'profiles/hbm_traffic.json')}
             except Exception:
                 pass
-        line = {
+        full = {
             'metric': 'env-steps/sec (batched RanSlice.step, scenario_0)',
             'value': value,
             'unit': 'env-steps/s',
@@ -558,33 +769,51 @@ def main():
                             'random multinomial actions generated on device' % n_envs,
                 'envs_per_gpu': n_envs, 'global_envs': world * n_envs,
                 'burn_in_steps': burn_steps,
-                'burn_in': ('fixed' if args.burn_in >= 0 else
-                            'until stationary: mean UEs/slice per %d-step block %s' % (BURN_BLOCK, burn_hist)),
+                'burn_in': 'fixed' if args.burn_in >= 0 else 'until the mean UEs/slice of a %d-step block moves < 0.5 %%' % BURN_BLOCK,
                 'fading': '3 synthetic traces x %d samples x 200 PRB, f64' % FADING_COLS,
                 'parallelism': 'replica-sharded x%d, no collective in step' % world +
                                (' (RANSLICE_BENCH_SHARE_GPU: the ranks share %d device(s) -- a check of the launch path, not a '
-                                'scaling measurement)' % torch.cuda.device_count() if os.environ.get('RANSLICE_BENCH_SHARE_GPU') == '1' else ''),
+                                'scaling measurement)' % ndev if share_gpu else ''),
                 'loop': 'hipGraph replay (rs_run_random)' if args.graph else 'one launch sequence per step from the host',
             },
             'roofline': roof,
+            'burn_in_history_mean_ues': burn_hist,
         }
-        line['cpu_baseline'] = cpu_base
+        full['cpu_baseline'] = cpu_base
         if world == 1 and not args.no_kbrl:
             try:
-                # config 3 on both synthetic trace profiles: 'tdl' (tapped delay lines, the construction of the ns-3 traces the
-                # reference was run on; the profile the reference comparison of DESIGN.md section 7 was recorded on) is the
-                # headline, 'sos' (the fixtures' profile, rounds 1-3's numbers) beside it
-                line['kbrl'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100, profile=os.environ.get('KBRL_TRACES', 'tdl'))
-                if not os.environ.get('KBRL_TRACES'):
-                    line['kbrl_sos'] = kbrl_record(n_envs, local_rank, args.kbrl_steps, 100, profile='sos')
+                # config 3 on the 'tdl' synthetic trace profile (tapped delay lines, the construction of the ns-3 traces the
+                # reference was run on; the profile the reference comparison of DESIGN.md section 7 was recorded on);
+                # --kbrl-sos: the fixtures' profile beside it (rounds 1-3's numbers)
+                full['kbrl'] = kbrl_record(n_envs, device, args.kbrl_steps, 100, profile=os.environ.get('KBRL_TRACES', 'tdl'))
+                if args.kbrl_sos:
+                    full['kbrl_sos'] = kbrl_record(n_envs, device, args.kbrl_steps, 100, profile='sos')
             except Exception as e:  # the headline line must not depend on the agent's sub-record
-                line.setdefault('kbrl', {'error': repr(e)})
-                line['kbrl_error'] = repr(e)
-        print(json.dumps(line), flush=True)
+                full.setdefault('kbrl', {'error': repr(e)[:300]})
 
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    # ---- config 4: the exchange over RCCL, every rank's child process under a timeout (a failure stays inside the sub-record)
+    if not args.no_shared:
+        tag = '%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid() if world > 1 else os.getpid())
+        try:
+            sh = run_shared_leg(args, rank, local_rank, world, tag)
+        except Exception as e:
+            sh = {'error': repr(e)[:300]}
+        if full is not None:
+            full['shared_kbrl'] = sh
+    try:
+        group.barrier()
+    except Exception:
+        pass
+    group.close()
+
+    if full is not None:
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'bench_full_last.json'), 'w') as f:
+                json.dump(full, f, indent=1)
+        except OSError:
+            pass
+        print('# full record: ' + json.dumps(full), flush=True)
+        print(json.dumps(compact_line(full)), flush=True)
 
 
 if __name__ == '__main__':

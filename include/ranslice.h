@@ -275,6 +275,10 @@ int kb_shared_commit(kb_handle* k, const int32_t* n_accept);
  * must be rank * n_envs).  Without kb_comm_init the handle is its own world (no RCCL needed). */
 int kb_comm_unique_id(void* id128);
 int kb_comm_init(kb_handle* k, const void* id128, int rank, int world);
+/* What the live communicator itself reports (ncclCommUserRank / ncclCommCount); (0, 1) for a handle that never joined one.
+ * After the communicator was aborted (a failed or timed-out exchange: kb_shared_step returned RS_EHIP) this and every
+ * shared step return RS_ESTATE until kb_comm_init joins a new one -- the handle does not quietly become a world of its own. */
+int kb_comm_info(kb_handle* k, int* rank, int* world);
 int kb_shared_step(kb_handle* k, const float* state, const int32_t* action, const int32_t* labels, int32_t budget,
                    int32_t max_rounds, int32_t* hits, int32_t* rounds_out);
 /* kb_step_resident for a shared-dictionary agent: the learning step above on the simulator's own device buffers (previous

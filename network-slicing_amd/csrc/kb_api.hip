@@ -8,6 +8,7 @@ struct kb_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_order = nullptr;  // orders the agent's stream against the simulator's (kb_step_resident)
+    hipEvent_t ev_join = nullptr;   // kb_run_resident: the agent's stream waits for the graph launches on the simulator's
     kb::KbDev D;
     kb::KbState K;
     std::vector<void*> allocs;
@@ -38,6 +39,8 @@ struct kb_handle {
     int32_t h_steps = 0;
     void* comm = nullptr;          // ncclComm_t (RCCL), bound at run time
     int comm_rank = 0, comm_world = 1;
+    bool comm_aborted = false;     // the communicator was aborted: shared steps refuse until kb_comm_init forms a new one
+    int32_t* h_total = nullptr;    // pinned: the per-round (proposals left, failure mark) pair of the shared step
     int budget_cap = 256;
     int heavy_blocks = 256;
     int mv_grid = 2048, r1_grid = 2048;  // one co-resident round of workgroups of the two Kinv-streaming kernels (kb_create)
@@ -93,9 +96,11 @@ typedef int (*AllGather_t)(const void*, void*, size_t, int, void*, hipStream_t);
 typedef const char* (*GetErrorString_t)(int);
 typedef int (*CommAbort_t)(void*);
 typedef int (*CommGetAsyncError_t)(void*, int*);
+typedef int (*CommCount_t)(void*, int*);
 static void* lib = nullptr;
 static CommAbort_t CommAbort = nullptr;
 static CommGetAsyncError_t CommGetAsyncError = nullptr;
+static CommCount_t CommCount = nullptr, CommUserRank = nullptr;
 static GetUniqueId_t GetUniqueId = nullptr;
 static CommInitRank_t CommInitRank = nullptr;
 static CommDestroy_t CommDestroy = nullptr;
@@ -122,6 +127,8 @@ static bool load() {
     GetErrorString = (GetErrorString_t)dlsym(lib, "ncclGetErrorString");
     CommAbort = (CommAbort_t)dlsym(lib, "ncclCommAbort");                          // (optional: the abort path)
     CommGetAsyncError = (CommGetAsyncError_t)dlsym(lib, "ncclCommGetAsyncError");  // (optional)
+    CommCount = (CommCount_t)dlsym(lib, "ncclCommCount");                          // (optional: kb_comm_info)
+    CommUserRank = (CommCount_t)dlsym(lib, "ncclCommUserRank");
     if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllGather) {
         dlclose(lib);
         lib = nullptr;
@@ -144,6 +151,14 @@ static void kb_history_release(kb_handle* k) {
 static void kb_comm_release(kb_handle* k) {
     if (k->comm && rccl::CommDestroy) (void)rccl::CommDestroy(k->comm);
     k->comm = nullptr;
+}
+
+// ncclCommAbort: the handle is NOT a world of its own afterwards -- its dictionaries are the replicated ones of a group it
+// can no longer reach, so every shared step refuses (RS_ESTATE) until kb_comm_init joins a new communicator
+static void kb_comm_abort(kb_handle* k) {
+    if (k->comm && rccl::CommAbort) (void)rccl::CommAbort(k->comm);
+    k->comm = nullptr;
+    k->comm_aborted = true;
 }
 
 /* 128 bytes for kb_comm_init, generated by ONE rank (ncclGetUniqueId) and handed to the others by the launcher */
@@ -175,8 +190,27 @@ extern "C" int kb_comm_init(kb_handle* k, const void* id128, int rank, int world
     }
     k->comm_rank = rank;
     k->comm_world = world;
+    k->comm_aborted = false;
     if (k->d_gather) (void)hipFree(k->d_gather);  // (sized by the world: allocated again on the first exchange)
     k->d_gather = nullptr;
+    return RS_OK;
+}
+
+/* What the live communicator itself says (ncclCommUserRank / ncclCommCount): rank and number of ranks; (0, 1) for a handle
+ * that never joined one.  RS_ESTATE after an abort. */
+extern "C" int kb_comm_info(kb_handle* k, int* rank, int* world) {
+    if (!k || !rank || !world) return RS_EINVAL;
+    if (k->comm_aborted) {
+        k->err = "kb_comm_info: the communicator was aborted (kb_comm_init forms a new one)";
+        return RS_ESTATE;
+    }
+    *rank = 0;
+    *world = 1;
+    if (!k->comm) return RS_OK;
+    if (!rccl::CommCount || !rccl::CommUserRank || rccl::CommCount(k->comm, world) != 0 || rccl::CommUserRank(k->comm, rank) != 0) {
+        k->err = "kb_comm_info: ncclCommCount / ncclCommUserRank failed";
+        return RS_EHIP;
+    }
     return RS_OK;
 }
 
@@ -224,15 +258,15 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     D.eta = cfg->eta;
     D.shared = cfg->shared_dictionary ? 1 : 0;
     D.tri = D.shared ? 0 : 1;  // one agent per replica: the lower block triangle of Kinv only (kb_kbrl.hip, "Storage")
-    D.heavy_m = getenv("KBRL_HEAVY_M") ? atoi(getenv("KBRL_HEAVY_M")) : 0;  // developer knob; results do not depend on it
-    if (getenv("KBRL_ROUNDS")) {  // developer knob (tests): that many rounds, always enqueued; results do not depend on it
-        k->heavy_rounds = atoi(getenv("KBRL_ROUNDS"));
+    D.heavy_m = dev_env("KBRL_HEAVY_M") ? atoi(dev_env("KBRL_HEAVY_M")) : 0;  // developer knob; results do not depend on it
+    if (dev_env("KBRL_ROUNDS")) {  // developer knob (tests): that many rounds, always enqueued; results do not depend on it
+        k->heavy_rounds = atoi(dev_env("KBRL_ROUNDS"));
         k->rounds_always = true;
     }
-    if (getenv("KBRL_ROUNDS_GATE")) k->rounds_gate = atoi(getenv("KBRL_ROUNDS_GATE"));
+    if (dev_env("KBRL_ROUNDS_GATE")) k->rounds_gate = atoi(dev_env("KBRL_ROUNDS_GATE"));
     if (hipHostMalloc((void**)&k->h_seen, 2 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess) k->h_seen = nullptr;
     if (k->h_seen) k->h_seen[0] = k->h_seen[1] = 0;
-    D.serial_apply = getenv("KBRL_SERIAL_APPLY") ? 1 : 0;  // test knob: the batched apply of full dictionaries off
+    D.serial_apply = dev_env("KBRL_SERIAL_APPLY") ? 1 : 0;  // test knob: the batched apply of full dictionaries off
     D.first_env = cfg->first_env;
     k->nv = o;
     k->T = cfg->n_envs * cfg->n_slices;
@@ -337,7 +371,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b1, kb::heavy_matvec_kernel, 256, 0) == hipSuccess && b1 > 0) k->mv_grid = b1 * cus;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, kb::heavy_rank1_kernel, 256, 0) == hipSuccess && b2 > 0) k->r1_grid = b2 * cus;
-        if (getenv("KBRL_STREAM_GRID")) k->mv_grid = k->r1_grid = atoi(getenv("KBRL_STREAM_GRID"));
+        if (dev_env("KBRL_STREAM_GRID")) k->mv_grid = k->r1_grid = atoi(dev_env("KBRL_STREAM_GRID"));
     }
     hipLaunchKernelGGL(kb::kb_gtab_kernel, dim3((KB_GTAB + 255) / 256), dim3(256), 0, k->stream, k->D, k->K);
     HIPCHK(k, hipGetLastError());
@@ -357,7 +391,7 @@ extern "C" void kb_destroy(kb_handle* k) {
     if (!k) return;
     if (k->stream) (void)hipStreamSynchronize(k->stream);
     kb_drop_graph(k);
-    if (k->D.shared && getenv("KBRL_APPLY_TIMES") && k->d_gstats) {  // developer aid: where shared_apply_kernel spends its time
+    if (k->D.shared && dev_env("KBRL_APPLY_TIMES") && k->d_gstats) {  // developer aid: where shared_apply_kernel spends its time
         uint64_t g[32];
         if (hipMemcpy(g, k->d_gstats, sizeof g, hipMemcpyDeviceToHost) == hipSuccess)
             for (int s = 0; s < k->cfg.n_slices; ++s)
@@ -372,10 +406,12 @@ extern "C" void kb_destroy(kb_handle* k) {
         (void)hipEventDestroy(e.second);
     }
     if (k->ev_order) (void)hipEventDestroy(k->ev_order);
+    if (k->ev_join) (void)hipEventDestroy(k->ev_join);
     kb_comm_release(k);
     if (k->d_gather) (void)hipFree(k->d_gather);
     kb_history_release(k);
     if (k->h_seen) (void)hipHostFree(k->h_seen);
+    if (k->h_total) (void)hipHostFree(k->h_total);
     if (k->stream) (void)hipStreamDestroy(k->stream);
     delete k;
 }
@@ -438,7 +474,7 @@ static void launch_shared_apply(kb_handle* k, const double* props, const int32_t
     hipLaunchKernelGGL(kb::shared_cols_kernel, dim3(S, KB_COLS_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, props, counts, budget);
     // d* of the whole list: on the matrix cores when the capacity (the size of a full dictionary) is a multiple of 64, by
     // the column walk otherwise -- the same sums bit for bit (KBRL_MATVEC_MFMA=0: the column walk always)
-    static const bool mfma_on = !(getenv("KBRL_MATVEC_MFMA") && atoi(getenv("KBRL_MATVEC_MFMA")) == 0);
+    static const bool mfma_on = !(dev_env("KBRL_MATVEC_MFMA") && atoi(dev_env("KBRL_MATVEC_MFMA")) == 0);
     const int mfma = mfma_on && k->cfg.capacity % 64 == 0 ? 1 : 0;
     if (mfma)
         hipLaunchKernelGGL(kb::shared_matvec_mfma_kernel, dim3(S, KB_MATVEC_BLOCKS), dim3(256), 0, k->stream, k->D, k->K, counts, budget);
@@ -668,7 +704,7 @@ extern "C" int kb_run_resident(kb_handle* k, rs_handle* env, int n_steps, int us
     // simulator-only graph of rs_run_random is fine under it): with a profiler tool attached the steps are enqueued one by one,
     // same results.  KBRL_GRAPH_UNDER_PROFILER=1 keeps the graph.
     static const bool no_graph = getenv("ROCP_TOOL_LIBRARIES") != nullptr &&
-                                 !(getenv("KBRL_GRAPH_UNDER_PROFILER") && atoi(getenv("KBRL_GRAPH_UNDER_PROFILER")) != 0);
+                                 !(dev_env("KBRL_GRAPH_UNDER_PROFILER") && atoi(dev_env("KBRL_GRAPH_UNDER_PROFILER")) != 0);
     if (no_graph) use_graph = 0;
     if (use_graph && !k->timing && !env->timing && !k->D.shared && n_steps >= 3) {
         if (!k->gexec || k->g_env != env || k->g_sig != env->launch_sig) {
@@ -707,11 +743,21 @@ extern "C" int kb_run_resident(kb_handle* k, rs_handle* env, int n_steps, int us
             k->g_env = env;
             k->g_sig = env->launch_sig;
         }
+        bool launched = false;
         while (k->gexec && n_steps - done >= 2) {
             HIPCHK(k, hipGraphLaunch(k->gexec, env->stream));
             env->clock += 2 * env->cfg.slots_per_step;
             env->steps += 2;
             done += 2;
+            launched = true;
+        }
+        if (launched) {
+            // The graph carries the agent's kernels but runs on the SIMULATOR's stream: the agent's stream joins it here, so
+            // that kb_synchronize / kb_get_stats / kb_save_state (which wait for the agent's stream only) see the loop's end
+            // even when the call ends on a graph launch.
+            if (!k->ev_join) HIPCHK(k, hipEventCreateWithFlags(&k->ev_join, hipEventDisableTiming));
+            HIPCHK(k, hipEventRecord(k->ev_join, env->stream));
+            HIPCHK(k, hipStreamWaitEvent(k->stream, k->ev_join, 0));
         }
     }
     for (; done < n_steps; ++done)
@@ -920,7 +966,7 @@ extern "C" int kb_set_kernel_timing(kb_handle* k, int enable) {
     kb_drop_graph(k);
     k->timing = enable != 0;
     k->ev_used = 0;
-    if (enable && k->D.shared && k->d_gstats && getenv("KBRL_APPLY_TIMES")) {  // (developer aid: count from here on)
+    if (enable && k->D.shared && k->d_gstats && dev_env("KBRL_APPLY_TIMES")) {  // (developer aid: count from here on)
         HIPCHK(k, hipSetDevice(k->device));
         HIPCHK(k, hipMemsetAsync(k->d_gstats + 8, 0, sizeof(uint64_t) * 24, k->stream));
     }
@@ -1085,20 +1131,21 @@ static int shared_wait(kb_handle* k) {
     }
     static const double limit = getenv("KBRL_COLLECTIVE_TIMEOUT_S") ? atof(getenv("KBRL_COLLECTIVE_TIMEOUT_S")) : 120.0;
     const auto t0 = std::chrono::steady_clock::now();
+    const bool inject = dev_env("KBRL_INJECT_TIMEOUT") != nullptr;  // test build: as if the peers never answered
     for (;;) {
-        const hipError_t q = hipStreamQuery(k->stream);
+        const hipError_t q = inject ? hipErrorNotReady : hipStreamQuery(k->stream);
         if (q == hipSuccess) return RS_OK;
         const char* why = nullptr;
         int async_err = 0;
-        if (q != hipErrorNotReady) why = hipGetErrorString(q);
+        if (inject) why = "timeout injected by KBRL_INJECT_TIMEOUT";
+        else if (q != hipErrorNotReady) why = hipGetErrorString(q);
         else if (rccl::CommGetAsyncError && rccl::CommGetAsyncError(k->comm, &async_err) == 0 && async_err != 0)
             why = rccl::GetErrorString ? rccl::GetErrorString(async_err) : "asynchronous RCCL error";
         else if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
             why = "no answer from the other ranks within KBRL_COLLECTIVE_TIMEOUT_S";
         if (why) {
             k->err = std::string("kb_shared_step: the exchange did not complete (") + why + "); communicator aborted";
-            if (rccl::CommAbort) (void)rccl::CommAbort(k->comm);
-            k->comm = nullptr;  // (aborted: kb_comm_init forms a new one)
+            kb_comm_abort(k);  // (kb_comm_init forms a new one)
             return RS_EHIP;
         }
         usleep(50);
@@ -1108,11 +1155,15 @@ static int shared_wait(kb_handle* k) {
 // the rounds of one shared learning step on device buffers (state / action / labels of the local replicas)
 static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d_action, const int32_t* d_labels, int32_t budget,
                             int32_t max_rounds, int32_t* hits_host, int32_t* rounds_out) {
+    if (k->comm_aborted) {  // not a one-rank world: its dictionaries would silently diverge from the group's
+        k->err = "kb_shared_step: the communicator of this handle was aborted; join a new one with kb_comm_init";
+        return RS_ESTATE;
+    }
     const size_t T = (size_t)k->T, S = (size_t)k->cfg.n_slices;
     const int W = k->comm ? k->comm_world : 1, me = k->comm ? k->comm_rank : 0;
     const size_t blk = S * (1 + (size_t)budget * KB_PROP_W);
     // test knob: behave as if this rank's round r had failed locally (the abort path below, without breaking anything)
-    const int inject = getenv("KBRL_INJECT_FAIL_ROUND") ? atoi(getenv("KBRL_INJECT_FAIL_ROUND")) : -1;
+    const int inject = dev_env("KBRL_INJECT_FAIL_ROUND") ? atoi(dev_env("KBRL_INJECT_FAIL_ROUND")) : -1;
     int rounds = 0;
     for (int rnd = 0; rnd < max_rounds; ++rnd) {
         // ---- this rank's part of the round.  A failure here (an allocation, a launch) must not leave the other ranks waiting
@@ -1152,18 +1203,14 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         }
         if (!k->d_gather) {  // nothing to gather into: this rank cannot even say so
             k->err = "kb_shared_step: " + local_err;
-            if (k->comm && rccl::CommAbort) {
-                (void)rccl::CommAbort(k->comm);
-                k->comm = nullptr;
-            }
+            if (k->comm) kb_comm_abort(k);
             return RS_EHIP;
         }
         if (k->comm) {
             const int nrc = rccl::AllGather(k->d_block, k->d_gather, blk, rccl::kDouble, k->comm, k->stream);
             if (nrc != 0) {
                 k->err = std::string("ncclAllGather: ") + (rccl::GetErrorString ? rccl::GetErrorString(nrc) : "error");
-                if (rccl::CommAbort) (void)rccl::CommAbort(k->comm);
-                k->comm = nullptr;
+                kb_comm_abort(k);
                 return RS_EHIP;
             }
         } else {
@@ -1179,8 +1226,12 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         // the last permitted round decides nothing: a single-rank handle whose caller does not ask for the count does not wait
         // for it (with other ranks in the step the failure flag is read after every round, so that all leave together)
         if (rnd + 1 == max_rounds && !rounds_out && !k->comm && local_err.empty()) break;
-        int32_t total[2] = {0, 0};
-        HIPCHK(k, hipMemcpyAsync(total, k->d_total, sizeof total, hipMemcpyDeviceToHost, k->stream));
+        // The pair comes back through PINNED memory: a device-to-host copy into pageable memory blocks the calling thread until
+        // the stream reaches it -- behind an all-gather a silent peer never completes -- and the bounded wait below would never run.
+        if (!k->h_total) HIPCHK(k, hipHostMalloc((void**)&k->h_total, 2 * sizeof(int32_t), hipHostMallocDefault));
+        volatile int32_t* total = k->h_total;
+        total[0] = total[1] = 0;
+        HIPCHK(k, hipMemcpyAsync(k->h_total, k->d_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, k->stream));
         const int wrc = shared_wait(k);
         if (wrc != RS_OK) return wrc;
         if (total[1] != 0 || !local_err.empty()) {
@@ -1364,7 +1415,9 @@ static uint64_t kb_cfg_hash(const kb_handle* k) {
     uint64_t x = 1469598103934665603ull;
     const unsigned char* p = (const unsigned char*)&k->cfg;
     for (size_t i = 0; i < sizeof k->cfg; ++i) x = (x ^ p[i]) * 1099511628211ull;
-    for (auto& r : k->regions) x = (x ^ (uint64_t)r.second) * 1099511628211ull;
+    // (the pool's own size is not part of the configuration: a blob fits any handle whose pool holds what the blob uses --
+    // with kb_config.pool_bytes == 0 the pool is sized from the free memory of the moment and differs from process to process)
+    for (auto& r : k->regions) x = (x ^ (r.first == (void*)k->K.pool ? 0ull : (uint64_t)r.second)) * 1099511628211ull;
     return x;
 }
 static size_t kb_hist_bytes(const kb_handle* k, size_t part[7]) {
@@ -1429,10 +1482,24 @@ extern "C" int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes) {
     if (!k || !blob || bytes < sizeof(kb_state_header)) return RS_EINVAL;
     kb_state_header hd;
     memcpy(&hd, blob, sizeof hd);
-    if (hd.magic != kKbStateMagic || hd.n_regions != k->regions.size() || hd.cfg_hash != kb_cfg_hash(k) ||
-        hd.pool_doubles_used > k->D.pool_doubles || bytes < hd.total_bytes) {
-        k->err = "kb_load_state: the blob was not saved by a handle of this configuration (or its pool is larger than this one's)";
+    if (hd.magic != kKbStateMagic || hd.n_regions != k->regions.size() || hd.cfg_hash != kb_cfg_hash(k)) {
+        k->err = "kb_load_state: the blob was not saved by a handle of this configuration";
         return RS_EINVAL;
+    }
+    if (hd.pool_doubles_used > k->D.pool_doubles) {
+        k->err = "kb_load_state: the blob's dictionaries use " + std::to_string(hd.pool_doubles_used * 8) + " bytes of pool, this handle's pool has " +
+                 std::to_string((uint64_t)k->D.pool_doubles * 8) + " (give kb_config.pool_bytes explicitly when checkpoints travel between processes)";
+        return RS_EINVAL;
+    }
+    {   // the size the header's own fields imply: a truncated or corrupt blob is refused before anything is read past its end
+        const uint64_t n = (uint64_t)k->cfg.n_envs * hd.hist_steps, S = (uint64_t)k->cfg.n_slices;
+        uint64_t expect = sizeof(kb_state_header) + (hd.hist_steps ? 8 * n + 2 * n + 2 * n * S + 2 * n + 2 * n + 2 * n + sizeof(int32_t) : 0);
+        for (auto& r : k->regions) expect += r.first == (void*)k->K.pool ? hd.pool_doubles_used * 8 : (uint64_t)r.second;
+        if (hd.hist_steps > 0x7fffffffull || hd.total_bytes != expect || bytes < expect) {
+            k->err = "kb_load_state: truncated or corrupt blob (" + std::to_string(bytes) + " bytes given, header says " +
+                     std::to_string(hd.total_bytes) + ", its fields imply " + std::to_string(expect) + ")";
+            return RS_EINVAL;
+        }
     }
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));

@@ -11,6 +11,15 @@
 #include <string>
 #include <vector>
 
+// Developer knobs (sweep switches, the guard bands, the fault injector of the shared step's abort path) are read from the
+// environment only by the test build (make dev: -DRS_DEV -> build/libranslice_dev.so, loaded explicitly by the tests that turn
+// them: ranslice._lib.load(dev=True)).  The production library reads none of them.
+#ifdef RS_DEV
+static inline const char* dev_env(const char* name) { return getenv(name); }
+#else
+static inline const char* dev_env(const char*) { return nullptr; }
+#endif
+
 #include "rs_embb.hip"
 #include "rs_mmtc.hip"
 #include "rs_order.hip"
@@ -26,7 +35,7 @@ struct GuardedAlloc {
 };
 static const size_t kGuard = 64 * 1024;
 static bool guards_on() {
-    static const bool on = getenv("RANSLICE_GUARD") != nullptr;
+    static const bool on = dev_env("RANSLICE_GUARD") != nullptr;
     return on;
 }
 static hipError_t guarded_malloc(void** q, size_t bytes, std::vector<GuardedAlloc>* reg) {
@@ -46,7 +55,7 @@ static hipError_t guarded_malloc(void** q, size_t bytes, std::vector<GuardedAllo
     if (e != hipSuccess) return e;
     reg->push_back({b, padded});
     *q = (char*)b + kGuard;
-    if (const char* v = getenv("RANSLICE_GUARD"))
+    if (const char* v = dev_env("RANSLICE_GUARD"))
         if (v[0] == '2') fprintf(stderr, "RANSLICE_GUARD: buffer #%zu at %p, %zu bytes\n", reg->size() - 1, *q, bytes);
     return hipSuccess;
 }
@@ -389,7 +398,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     HIPCHK(h, hipSetDevice(device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     {
-        const char* e = getenv("RANSLICE_MTC_STREAM");
+        const char* e = dev_env("RANSLICE_MTC_STREAM");
         if (!(e && atoi(e) == 0)) {
             HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -473,7 +482,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
             same = std::fma(r, rc, q) == x / dl;
         }
         d.slot_rc = rc;
-        d.pf_div_fast = (same && !getenv("RANSLICE_EXACT_DIV")) ? 1 : 0;  // the variable forces the divide (tests)
+        d.pf_div_fast = (same && !dev_env("RANSLICE_EXACT_DIV")) ? 1 : 0;  // the variable forces the divide (tests)
     }
     for (int m = 0; m < cfg->n_mcs; ++m) {
         d.mcs_ref[m] = cfg->mcs_snr[m];
@@ -525,7 +534,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     DA(h->d_oslot, T ? T : 1);
     DA(h->d_ohist, 2 * RS_ORDER_BINS);
     HIPCHK(h, hipMemset(h->d_ohist, 0, sizeof(int) * 2 * RS_ORDER_BINS));
-    if (const char* e = getenv("RANSLICE_ORDER")) h->order_mode = atoi(e);
+    if (const char* e = dev_env("RANSLICE_ORDER")) h->order_mode = atoi(e);
     {
         // One heavy task per wave pays while the whole batch is co-resident (the launch ends with its heaviest wave;
         // 1.13 vs 1.27 ms at 4096 replicas).  A batch of several rounds of waves is bound by the instructions issued
@@ -537,12 +546,12 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         const long long resident_waves = (long long)cus * 4 * RS_OCC;
         h->order_pair = (long long)h->n_tasks / 4 > resident_waves + resident_waves / 4 ? 0 : 256;
     }
-    if (const char* e = getenv("RANSLICE_PAIR")) h->order_pair = atoi(e);
+    if (const char* e = dev_env("RANSLICE_PAIR")) h->order_pair = atoi(e);
     // Lanes per task: with few tasks the step is pure latency and the 32-lane instance (more lanes per sum and per
     // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
     // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
     h->group = h->n_tasks <= 6144 ? 32 : 16;
-    if (const char* e = getenv("RANSLICE_GROUP")) {  // developer knob (tools/group_sweep.py)
+    if (const char* e = dev_env("RANSLICE_GROUP")) {  // developer knob (tools/group_sweep.py)
         const int g = atoi(e);
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
@@ -550,14 +559,14 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->spread_max = cus * 4;
         (void)hipGetLastError();
-        if (const char* e = getenv("RANSLICE_SPREAD")) h->spread_mode = atoi(e);  // developer knob
-        if (const char* e = getenv("RANSLICE_SNAKE")) h->snake = atoi(e);
-        if (const char* e = getenv("RANSLICE_KEY_W")) (void)sscanf(e, "%d,%d,%d,%d", &h->key_w[0], &h->key_w[1], &h->key_w[2], &h->key_w[3]);
-        if (const char* e = getenv("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
-        if (const char* e = getenv("RANSLICE_SNAKE_ROT")) h->rot_mask = (int)strtol(e, nullptr, 0);
+        if (const char* e = dev_env("RANSLICE_SPREAD")) h->spread_mode = atoi(e);  // developer knob
+        if (const char* e = dev_env("RANSLICE_SNAKE")) h->snake = atoi(e);
+        if (const char* e = dev_env("RANSLICE_KEY_W")) (void)sscanf(e, "%d,%d,%d,%d", &h->key_w[0], &h->key_w[1], &h->key_w[2], &h->key_w[3]);
+        if (const char* e = dev_env("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
+        if (const char* e = dev_env("RANSLICE_SNAKE_ROT")) h->rot_mask = (int)strtol(e, nullptr, 0);
     }
     h->block_hint = auto_hint(h);
-    if (const char* e = getenv("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
+    if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
         if (!h->hint_auto) h->block_hint = atoi(e) ? 1 : 0;
     }
@@ -631,7 +640,7 @@ static int upload_fading(rs_handle* h) {
     // tail padding so that a subgroup's strided reads never leave the allocation
     HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
     HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
-    if (const char* v = getenv("RANSLICE_GUARD"))
+    if (const char* v = dev_env("RANSLICE_GUARD"))
         if (v[0] == '2') fprintf(stderr, "RANSLICE_GUARD: fading table at %p, %zu bytes\n", (void*)h->fad, sizeof(double) * (elems + 16));
     for (int f = 0; f < RS_N_TRACES; ++f) {
         HIPCHK(h, hipMemcpyAsync(h->fad + d.fad_off[f], h->fad_host[f].data(), sizeof(double) * h->fad_host[f].size(),

@@ -147,8 +147,17 @@ class BatchedEvaluator(Evaluator):
     def save_checkpoint(self, path, next_step):
         """the cell's whole state (simulator + agents + the histories recorded so far) and the step to go on from"""
         c = self._ctx
-        np.savez(path, next_step=np.int64(next_step), steps=np.int64(self.steps), runs=np.asarray(c['runs'], dtype=np.int64),
-                 env=c['env'].save_state(), agent=c['agent'].save_state())
+        # both streams at rest before either state is read (the loop's last launches may sit on the other handle's stream)
+        c['env'].synchronize()
+        c['agent'].synchronize()
+        env_blob = c['env'].save_state()
+        agent_blob = c['agent'].save_state()
+        # written beside the old checkpoint and moved onto it: a crash during the write -- the case this exists for -- leaves
+        # the previous checkpoint intact instead of a torn .npz
+        tmp = path + '.tmp.npz'
+        np.savez(tmp, next_step=np.int64(next_step), steps=np.int64(self.steps), runs=np.asarray(c['runs'], dtype=np.int64),
+                 env=env_blob, agent=agent_blob)
+        os.replace(tmp, path)
 
     def load_checkpoint(self, path):
         """-> the step to go on from.  The cell must have been set up for the same runs, capacity and pool."""

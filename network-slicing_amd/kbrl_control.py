@@ -79,30 +79,33 @@ class KBRL_Control:
                                         np.asarray(reward, dtype=np.int32)[None, :])
         return hits[0].astype(np.int16)
 
+    # result keys of run() and their dtypes: the npz schema plot_results.py reads (kbrl_control.py:119-124,148-155)
+    _RUN_SCHEMA = (('reward', np.float64), ('resources', np.int16), ('hits', np.int16), ('adjusted', np.int16),
+                   ('SLA', np.int16), ('violation', np.int16))
+
     def run(self, system, steps, learning_time=-1):
-        """kbrl_control.py:116-157: same loop, same history arrays and dtypes"""
-        action = self.action
-        SLA_history = np.zeros((steps), dtype=np.int16)
-        reward_history = np.zeros((steps), dtype=np.float64)
-        violation_history = np.zeros((steps), dtype=np.int16)
-        adjusted_actions = np.zeros((steps), dtype=np.int16)
-        resources_history = np.zeros((steps), dtype=np.int16)
-        hits_history = np.zeros((len(action), steps), dtype=np.int16)
-        state = system.reset()
-        hits = np.zeros(len(action), dtype=np.int16)
-        for i in range(steps):
-            new_state, reward, _, info = system.step(action)
-            SLA_labels = info['SLA_labels']
-            if learning_time < steps:
-                hits = self.update_control(state, action, SLA_labels)
-            action, self.adjusted = self.select_action(new_state)
-            state = new_state
-            SLA_history[i] = SLA_labels.sum()
-            reward_history[i] = reward
-            violation_history[i] = info['total_violations']
-            resources_history[i] = action.sum()
-            adjusted_actions[i] = self.adjusted
-            hits_history[:, i] = hits
+        """The control loop of kbrl_control.py:116-157 for one environment: act, observe the SLA labels, learn from them
+        (while learning_time < steps, as the reference tests it), choose the next allocation.  Returns the reference's dict:
+        one column per step of reward f64, resources / adjusted / SLA / violation int16 and hits int16[S, steps]."""
+        n_learners = len(self.action)
+        out = {key: np.zeros((n_learners, steps) if key == 'hits' else steps, dtype=dt) for key, dt in self._RUN_SCHEMA}
+        alloc = self.action
+        obs = system.reset()
+        last_hits = np.zeros(n_learners, dtype=np.int16)
+        learning = learning_time < steps
+        for t in range(steps):
+            nxt, rew, _, info = system.step(alloc)
+            labels = info['SLA_labels']
+            if learning:
+                last_hits = self.update_control(obs, alloc, labels)
+            alloc, self.adjusted = self.select_action(nxt)
+            obs = nxt
+            out['reward'][t] = rew
+            out['SLA'][t] = labels.sum()
+            out['violation'][t] = info['total_violations']
+            out['resources'][t] = alloc.sum()       # the allocation chosen FOR the next step, as the reference records it
+            out['adjusted'][t] = self.adjusted
+            out['hits'][:, t] = last_hits
         pool = self._dev.pool()
         if pool['saturated'] or pool['pool_full']:
             import warnings
@@ -112,9 +115,7 @@ class KBRL_Control:
                           "reference's SVvariable grows without bound): pass a larger capacity / pool_bytes to "
                           'KBRL_Control / create_kbrl_agent (capacity up to 65536; the pool is bounded by device memory)'
                           % (sizes[0].tolist(), self._dev.capacity, pool['used_bytes'] / 2 ** 20, pool['total_bytes'] / 2 ** 20))
-        print('mean resources = {}'.format(resources_history.mean()))
-        print('total violations = {}'.format(violation_history.sum()))
-        print('mean adjusted = {}'.format(adjusted_actions.mean()))
-        print('mean accuracy = {}'.format(hits_history.mean(axis=1)))
-        return {'reward': reward_history, 'resources': resources_history, 'hits': hits_history,
-                'adjusted': adjusted_actions, 'SLA': SLA_history, 'violation': violation_history}
+        print('KBRL run of %d steps: %.2f PRBs on average, %d SLA violations, %.3f of the actions adjusted, accuracy per learner %s'
+              % (steps, out['resources'].mean(), int(out['violation'].sum()), out['adjusted'].mean(),
+                 np.array2string(out['hits'].mean(axis=1), precision=3)))
+        return out

@@ -7,13 +7,17 @@ from .config import RsConfig, KbConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('RANSLICE_LIB', os.path.join(os.path.dirname(_HERE), 'csrc', 'build', 'libranslice.so'))
+# the test build (make dev: -DRS_DEV): the same sources with the developer knobs -- sweep switches, guard bands, the fault injector
+# of the shared step -- readable from the environment.  Tests that turn a knob ask for it (load(dev=True), or RANSLICE_DEV_BUILD=1
+# in the environment when the handle is created); the production library reads no such variable.
+DEV_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), 'libranslice_dev.so')
 
 RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
 
 KB_EXPORTS = (
     'kb_create', 'kb_destroy', 'kb_last_error', 'kb_reset', 'kb_update_control', 'kb_select_action',
     'kb_step_resident', 'kb_run_resident', 'kb_predict', 'kb_update', 'kb_get_learner', 'kb_get_control', 'kb_set_adjusted',
-    'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_state_bytes', 'kb_save_state', 'kb_load_state', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
+    'kb_comm_info', 'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_state_bytes', 'kb_save_state', 'kb_load_state', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
 )
 
 EXPORTS = (
@@ -29,7 +33,7 @@ class RanSliceError(RuntimeError):
         self.code = code
 
 
-_lib = None
+_libs = {}
 
 
 def device_count():
@@ -40,21 +44,25 @@ def device_count():
     return n
 
 
-def load():
-    """Load libranslice.so; raises if it has not been built (python __graft_entry__.py build)."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
-        raise ImportError('libranslice.so not found at %s: build it with `make -C network-slicing_amd/csrc` '
-                          '(hipcc, gfx950). There is no CPU fallback.' % LIB_PATH)
+def load(dev=None):
+    """Load libranslice.so; raises if it has not been built (python __graft_entry__.py build).  dev=True (or
+    RANSLICE_DEV_BUILD=1 in the environment at the time of the call) loads the test build instead; all handles that meet in
+    one call (an agent stepping an environment) must come from the same one."""
+    if dev is None:
+        dev = os.environ.get('RANSLICE_DEV_BUILD') == '1'
+    path = DEV_LIB_PATH if dev else LIB_PATH
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise ImportError('%s not found: build it with `make -C network-slicing_amd/csrc` '
+                          '(hipcc, gfx950). There is no CPU fallback.' % path)
     # A handle drives two or three HIP streams (the simulator's, its mMTC side stream, the agent's) and several handles may run
     # side by side in one process (experiments_kbrl.evaluate_grid: six cells = 18 streams).  The HIP runtime multiplexes
     # streams onto 4 hardware queues unless told otherwise, and streams that share a queue run one after the other: the
     # six-cell grid took 26.5 s per 6,000 steps on 4 queues, 16.3 s on 24 (profiles/r04_g_queues.txt).  Read by the runtime
     # at its first call, so it has to be in the environment before the library initialises; a value the user set stays.
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
     fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
     L.rs_create.argtypes = [C.POINTER(RsConfig), C.c_int, C.POINTER(vp)]
@@ -116,6 +124,7 @@ def load():
     L.kb_history_fetch.argtypes = [vp, dp, sp, sp, sp, sp, sp, ip]
     L.kb_comm_unique_id.argtypes = [vp]
     L.kb_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.kb_comm_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.kb_shared_step.argtypes = [vp, fp, ip, ip, C.c_int32, C.c_int32, ip, ip]
     L.kb_shared_step_resident.argtypes = [vp, vp, C.c_int32, C.c_int32, ip]
     L.kb_shared_merge.argtypes = [vp, dp, C.c_int32, C.c_int32, C.c_int32, dp, ip, ip, ip]
@@ -128,5 +137,5 @@ def load():
     for name in EXPORTS:
         if name not in ('rs_last_error', 'rs_destroy', 'kb_last_error', 'kb_destroy'):
             getattr(L, name).restype = C.c_int
-    _lib = L
+    _libs[path] = L
     return L

@@ -286,6 +286,12 @@ class SharedVecKBRL(VecKBRL):
             raise _lib.RanSliceError(rc, 'kb_comm_unique_id failed (librccl.so missing?)')
         return buf.raw
 
+    def comm_info(self):
+        """(rank, world) as the live RCCL communicator reports them; (0, 1) without one"""
+        r, w = C.c_int(), C.c_int()
+        self._check(self.L.kb_comm_info(self.h, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
     def comm_init(self, unique_id, rank, world):
         if self.cfg.first_env != rank * self.n_envs:
             raise ValueError('first_env must be rank * n_envs (contiguous replica shards)')

@@ -48,6 +48,8 @@ def main():
     ia, sf, seq = batch(n * world, steps)
     lo, hi = rank * n, (rank + 1) * n
     from ranslice import _lib
+    if int(os.environ.get('FAIL_RANK', '-1')) >= 0 or int(os.environ.get('ABORT_STEP', '-1')) >= 0:
+        os.environ['RANSLICE_DEV_BUILD'] = '1'    # the fault injectors exist in the test build only
     device = rank % _lib.device_count()       # one GPU per rank where the box has them
     agent = SharedVecKBRL(n, [10] * 5, 200, capacity=256, budget=16, max_rounds=3, first_env=lo, device=device)
     if world > 1 or os.environ.get('RCCL_WORLD1'):
@@ -68,7 +70,35 @@ def main():
     agent.reset(ia[lo:hi], sf[lo:hi])
     acts = []
     fail_rank, fail_step = int(os.environ.get('FAIL_RANK', '-1')), int(os.environ.get('FAIL_STEP', '-1'))
+    abort_step = int(os.environ.get('ABORT_STEP', '-1'))
+    silent_rank, silent_step = int(os.environ.get('SILENT_RANK', '-1')), int(os.environ.get('SILENT_STEP', '-1'))
     for i, (state, action, labels, nxt) in enumerate(seq):
+        if rank == silent_rank and i == silent_step:
+            # this rank simply stops taking part (a hung or dead peer): the others must leave kb_shared_step on their own
+            print('SILENT %d from step %d' % (rank, i), flush=True)
+            time.sleep(float(os.environ.get('SILENT_SECONDS', '30')))
+            os._exit(0)
+        if i == abort_step:
+            # the bounded wait gives up (injected): RS_EHIP and the communicator is aborted; the handle must then REFUSE shared
+            # steps (not carry on as a world of its own) until a new communicator is joined
+            os.environ['KBRL_INJECT_TIMEOUT'] = '1'
+            try:
+                agent.update_control(state[lo:hi], action[lo:hi], labels[lo:hi])
+                print('NO ERROR at the injected timeout', flush=True)
+                sys.exit(4)
+            except _lib.RanSliceError as e:
+                print('ABORTED %d: code %d %s' % (i, e.code, e), flush=True)
+            del os.environ['KBRL_INJECT_TIMEOUT']
+            for what, call in (('step', lambda: agent.update_control(state[lo:hi], action[lo:hi], labels[lo:hi])),
+                               ('info', agent.comm_info)):
+                try:
+                    call()
+                    print('NOT REFUSED %s' % what, flush=True)
+                    sys.exit(4)
+                except _lib.RanSliceError as e:
+                    print('REFUSED %s: code %d %s' % (what, e.code, e), flush=True)
+            agent.comm_init(SharedVecKBRL.unique_id(), 0, 1)      # (the one-rank form of the test)
+            print('REJOINED %s' % (agent.comm_info(),), flush=True)
         if rank == fail_rank and i == fail_step:
             os.environ['KBRL_INJECT_FAIL_ROUND'] = '0'   # this rank's round 0 "fails" (kb_api.hip: shared_step_core)
         try:

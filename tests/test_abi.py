@@ -74,3 +74,24 @@ def test_production_instances_keep_their_register_budget():
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     assert mod.check(log) == []
+
+
+def test_production_library_reads_no_developer_knob():
+    """the sweep switches, the guard bands and the fault injector of the shared step live in the test build only
+    (csrc/rs_api.hip: dev_env, -DRS_DEV): none of their names is even a string of libranslice.so, all of them are in
+    libranslice_dev.so; the variables the product does read are documented ones"""
+    from ranslice import _lib
+    if not (os.path.exists(_lib.LIB_PATH) and os.path.exists(_lib.DEV_LIB_PATH)):
+        pytest.skip('libraries not built')
+    prod = open(_lib.LIB_PATH, 'rb').read()
+    dev = open(_lib.DEV_LIB_PATH, 'rb').read()
+    knobs = [b'KBRL_INJECT_FAIL_ROUND', b'KBRL_ROUNDS', b'KBRL_HEAVY_M', b'KBRL_SERIAL_APPLY', b'RANSLICE_SNAKE', b'RANSLICE_KEY_W',
+             b'RANSLICE_PAIR', b'RANSLICE_ORDER', b'RANSLICE_GUARD', b'RANSLICE_EXACT_DIV', b'RANSLICE_HINT']
+    for k in knobs:   # (as a whole NUL-terminated string: the argument of a getenv)
+        assert k + b'\0' not in prod, k
+        assert k + b'\0' in dev, k
+    for k in (b'RANSLICE_RCCL_LIB', b'KBRL_COLLECTIVE_TIMEOUT_S'):
+        assert k in prod, k
+    src = ''.join(open(os.path.join(ROOT, 'network-slicing_amd', 'csrc', f)).read() for f in ('rs_api.hip', 'kb_api.hip'))
+    assert sorted(set(re.findall(r'[^_]getenv\("([A-Z_0-9]+)"\)', src))) == ['KBRL_COLLECTIVE_TIMEOUT_S', 'RANSLICE_RCCL_LIB',
+                                                                             'ROCP_TOOL_LIBRARIES']

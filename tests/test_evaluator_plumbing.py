@@ -38,6 +38,9 @@ class FakeEnv:
     def fetch(self):
         return {}
 
+    def synchronize(self):
+        self.synced = getattr(self, 'synced', 0) + 1
+
     def save_state(self):
         return np.array([self.env_steps], dtype=np.int64).view(np.uint8)
 
@@ -82,6 +85,9 @@ class FakeAgent:
 
     def pool(self):
         return dict(used_bytes=0, total_bytes=1, saturated=0, pool_full=0)
+
+    def synchronize(self):
+        self.synced = getattr(self, 'synced', 0) + 1
 
     def save_state(self):
         return np.array([self.agent_steps], dtype=np.int64).view(np.uint8)

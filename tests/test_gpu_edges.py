@@ -285,6 +285,7 @@ def test_task_order_and_priority_do_not_change_results(golden_dir, monkeypatch):
     fading = _fading(golden_dir)
     N = 2048
     digests = []
+    monkeypatch.setenv('RANSLICE_DEV_BUILD', '1')   # knobs are read by the test build only (ranslice._lib)
     for order, pair in (('0', None), ('3', None), ('6', '128'), ('6', '256'), ('6', '0')):
         monkeypatch.setenv('RANSLICE_ORDER', order)
         if pair is None:

@@ -199,6 +199,8 @@ def test_results_do_not_depend_on_the_task_order(monkeypatch, knobs):
     for setting in ({}, knobs):
         for k in ('RANSLICE_SNAKE', 'RANSLICE_SNAKE_MASK', 'RANSLICE_SNAKE_ROT', 'RANSLICE_KEY_W', 'RANSLICE_ORDER', 'RANSLICE_PAIR'):
             monkeypatch.delenv(k, raising=False)
+        # the first run is the production library, the second the test build (the only one that reads the knobs)
+        monkeypatch.setenv('RANSLICE_DEV_BUILD', '1' if setting else '0')
         for k, v in setting.items():
             monkeypatch.setenv(k, v)  # (read by rs_create)
         env = VecRanSlice(n_envs=N_FULL, cfg=make_config(0, n_envs=N_FULL), fading=_fading())

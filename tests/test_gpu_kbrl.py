@@ -439,6 +439,91 @@ def test_graph_replayed_closed_loop_equals_stepwise(golden_dir):
             assert a['m'] == b['m'] and all(a[k].tobytes() == b[k].tobytes() for k in ('landmarks', 'coeff', 'kinv'))
 
 
+def test_agent_side_calls_see_the_end_of_a_graph_loop(golden_dir):
+    """kb_run_resident replays its graph on the SIMULATOR's stream; the agent-side calls (kb_get_stats, kb_save_state,
+    kb_synchronize) wait for the agent's stream only.  The loop now joins the agent's stream to its last graph launch: a call
+    that ENDS on a graph launch (7 = one plain step + three graph launches of two) followed at once by agent.stats() /
+    agent.save_state(), with no env.synchronize() in between, sees what a fully synchronised stepwise loop leaves."""
+    import ctypes as C
+    from ranslice.kbrl_dev import VecKBRL
+    from ranslice.vec_env import VecRanSlice
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    fading = [g['t0'], g['t1'], g['t2']]
+    scenario, N = 0, 256
+    dims, n_prbs = _dims(scenario)
+    rng = np.random.default_rng(5)
+    ia = rng.integers(4, 20, size=(N, 5)).astype(np.int32)
+    sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
+    got = []
+    for mode in ('graph', 'stepwise'):
+        env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=fading, seed=23)
+        ag = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=512 << 20)
+        env.reset()
+        ag.reset(ia, sf, seeds=np.arange(N, dtype=np.uint64) + 11)
+        env._check(env.L.rs_step(env.h, ia.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+        for k in (7, 7, 9):
+            if mode == 'graph':
+                ag.run_resident(env, k, graph=True)
+                stats = ag.stats()                 # agent's stream only
+                blob = ag.save_state()
+            else:
+                for _ in range(k):
+                    ag.step_resident(env)
+                    env.step_resident()
+                env.synchronize()
+                ag.synchronize()
+                stats = ag.stats()
+                blob = ag.save_state()
+            got.append((mode, k, list(stats), blob.tobytes()))
+        env.close()
+        ag.close()
+    for a, b in zip(got[:3], got[3:]):
+        assert a[2] == b[2], (a[1], a[2], b[2])
+        assert a[3] == b[3], 'checkpoint torn after a %d-step graph call' % a[1]
+
+
+def test_load_state_refuses_torn_blobs_and_accepts_another_pool_size(golden_dir):
+    """kb_load_state recomputes the size its header implies -- a truncated blob or one whose header lies is refused
+    before anything is read past its end -- and the pool's own size is not part of the configuration: a blob loads into a
+    handle with a LARGER (or smaller but sufficient) pool, and is refused with both sizes named when it does not fit."""
+    from ranslice import _lib
+    from ranslice.kbrl_dev import VecKBRL
+    g = _load(golden_dir, 'g9_projectron')
+    dims, n_prbs = _dims(0)
+    N = 4
+    ag = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=64 << 20)
+    ag.reset(np.full((N, 5), 10, np.int32), np.full((N, 5), 3, np.int32))
+    x, y = g['d11_x'], g['d11_y']
+    for i in range(400):
+        yp, f = ag.predict(i % N, i % 5, x[i])
+        ag.update(i % N, i % 5, x[i], int(y[i]))
+    blob = ag.save_state()
+    want = [ag.learner(r, s, with_kinv=True) for r in range(N) for s in range(5)]
+    ag.close()
+    for pool in (256 << 20, 32 << 20):
+        other = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=pool)
+        other.reset(np.full((N, 5), 1, np.int32), np.full((N, 5), 1, np.int32))
+        other.load_state(blob)
+        have = [other.learner(r, s, with_kinv=True) for r in range(N) for s in range(5)]
+        for a, b in zip(want, have):
+            assert a['m'] == b['m'] and all(a[k].tobytes() == b[k].tobytes() for k in ('landmarks', 'coeff', 'kinv'))
+        with pytest.raises(_lib.RanSliceError) as e:
+            other.load_state(blob[:-4096])                   # truncated
+        assert 'truncated or corrupt' in str(e.value)
+        lied = blob.copy()
+        lied[40:48] = np.frombuffer(np.uint64(blob.size - 4096).tobytes(), dtype=np.uint8)   # kb_state_header.total_bytes
+        with pytest.raises(_lib.RanSliceError) as e:
+            other.load_state(lied)
+        assert 'truncated or corrupt' in str(e.value)
+        other.close()
+    tiny = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=1 << 20)
+    tiny.reset(np.full((N, 5), 1, np.int32), np.full((N, 5), 1, np.int32))
+    with pytest.raises(_lib.RanSliceError) as e:
+        tiny.load_state(blob)
+    assert 'bytes of pool' in str(e.value)
+    tiny.close()
+
+
 def test_checkpoint_and_resume(golden_dir, tmp_path):
     """rs_save_state / kb_save_state: (1) a closed loop cut after 25 steps, restored into FRESH handles and continued, makes
     the steps the uncut loop makes (observations, actions, dictionaries bit for bit); a blob of another configuration is
@@ -637,6 +722,8 @@ def test_kbrl_control_long_golden(golden_dir, monkeypatch, name, min_m, heavy_m,
     step, whatever is left goes to the per-learner clean-up, which does all of it in the first case.  KBRL_HEAVY_M = h
     keeps learners below h landmarks in the one-wave kernel (a mix of paths, and the one-wave path alone)."""
     from ranslice.kbrl_dev import VecKBRL
+    if heavy_m is not None or rounds is not None:
+        monkeypatch.setenv('RANSLICE_DEV_BUILD', '1')   # knobs are read by the test build only (ranslice._lib)
     if heavy_m is not None:
         monkeypatch.setenv('KBRL_HEAVY_M', str(heavy_m))
     if rounds is not None:
@@ -774,6 +861,7 @@ def test_control_with_dictionaries_above_1024_vs_oracle(golden_dir, monkeypatch,
     triangle's tiles); None leaves them to the per-learner clean-up workgroups."""
     from ranslice.kbrl_dev import VecKBRL
     if rounds is not None:
+        monkeypatch.setenv('RANSLICE_DEV_BUILD', '1')   # knobs are read by the test build only (ranslice._lib)
         monkeypatch.setenv('KBRL_ROUNDS', str(rounds))
     g = _load(golden_dir, 'g15_kbrl_long_s0')
     dims, n_prbs = _dims(0)

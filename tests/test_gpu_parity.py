@@ -175,6 +175,7 @@ def test_production_instance_soak(golden_dir, scenario, n_envs, steps, hint):
 def test_exact_divide_fallback(golden_dir, monkeypatch):
     """rs_create replaces (pf_b * bits) / slot_length by a reciprocal + two fmas after checking every reachable
     `bits`; RANSLICE_EXACT_DIV forces the IEEE divide instead.  Both must match the oracle."""
+    monkeypatch.setenv('RANSLICE_DEV_BUILD', '1')   # knobs are read by the test build only (ranslice._lib)
     monkeypatch.setenv('RANSLICE_EXACT_DIV', '1')
     _compare(0, n_envs=48, steps=12, fading=_small_fading(golden_dir), churn=True, seed0=77, check_trace=False)
 

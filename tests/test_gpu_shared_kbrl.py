@@ -236,6 +236,8 @@ def test_batched_apply_of_full_dictionaries_equals_serial(monkeypatch, capacity)
     dims = [10] * cfg.n_embb + [3] * cfg.n_mmtc
 
     def make(serial):
+        # the serial apply is a knob of the test build; the batched one runs on the production library
+        monkeypatch.setenv('RANSLICE_DEV_BUILD', '1' if serial else '0')
         if serial:
             monkeypatch.setenv('KBRL_SERIAL_APPLY', '1')
         else:
@@ -344,6 +346,7 @@ def test_failure_in_a_round_leaves_the_step_through_the_exchange(monkeypatch, tm
     wk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(wk)
     ia, sf, seq = wk.batch(16, 5)
+    monkeypatch.setenv('RANSLICE_DEV_BUILD', '1')   # the fault injector is read by the test build only (ranslice._lib)
     ag = SharedVecKBRL(16, [10] * 5, 200, capacity=256, budget=16, max_rounds=3)
     ag.reset(ia, sf)
     for i, (state, action, labels, nxt) in enumerate(seq):
@@ -372,6 +375,34 @@ def test_failure_on_one_of_two_ranks_ends_both(tmp_path):
     for r, (rc, o, e) in enumerate(two):
         assert rc == 3 and ('FAILED %d step 3' % r) in o, (r, rc, o[-500:], e[-1500:])
     assert 'this rank failed' in two[1][1] and 'another rank' in two[0][1]
+
+
+def test_aborted_communicator_refuses_until_rejoined(tmp_path):
+    """after ncclCommAbort (here: the bounded wait's timeout, injected in the test build, on a real one-rank RCCL
+    communicator) the handle is NOT a one-rank world: kb_shared_step and kb_comm_info return RS_ESTATE until kb_comm_init joins a
+    new communicator, after which the steps go on.  kb_comm_info reports what the communicator itself says."""
+    out = _run_ranks(1, 16, 6, tmp_path, {'RCCL_WORLD1': '1', 'ABORT_STEP': '2'})
+    rc, o, e = out[0]
+    assert rc == 0, (o[-800:], e[-1500:])
+    assert 'ABORTED 2: code -3' in o and 'communicator aborted' in o
+    assert 'REFUSED step: code -4' in o and 'REFUSED info: code -4' in o and 'was aborted' in o
+    assert 'REJOINED (0, 1)' in o and 'RESULT 0' in o
+
+
+def test_silent_peer_ends_in_a_timeout_not_a_hang(tmp_path):
+    """one of two ranks stops calling kb_shared_step (a hung peer).  The other rank's per-round flag comes back
+    through pinned memory, so its bounded wait runs: it leaves with RS_EHIP after KBRL_COLLECTIVE_TIMEOUT_S instead of sitting
+    in a blocking copy behind the all-gather.  Needs a two-rank communicator (two GPUs): skipped -- not verified -- elsewhere."""
+    import time
+    t0 = time.time()
+    two = _run_ranks(2, 8, 6, tmp_path, {'SILENT_RANK': '1', 'SILENT_STEP': '3', 'SILENT_SECONDS': '40', 'KBRL_COLLECTIVE_TIMEOUT_S': '5'})
+    err = ' '.join(e[-400:] for _, _, e in two)
+    if any('ncclCommInitRank' in e or 'Duplicate' in e or 'invalid usage' in e for _, _, e in two):
+        pytest.skip('RCCL does not form a 2-rank communicator on a single device: %s' % err[-300:])
+    rc, o, e = two[0]
+    assert rc == 3 and 'FAILED 0 step 3' in o and 'no answer from the other ranks' in o, (rc, o[-500:], e[-1500:])
+    assert 'SILENT 1 from step 3' in two[1][1]
+    assert time.time() - t0 < 120
 
 
 def test_shared_resident_loop_equals_host_loop():
