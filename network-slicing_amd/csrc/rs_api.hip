@@ -81,6 +81,12 @@ struct rs_handle {
     hipStream_t side = nullptr;      // the mMTC slices' kernel of a step runs here, beside the eMBB kernels (they share nothing but
                                      // the step's inputs; finalize_kernel waits for both).  RANSLICE_MTC_STREAM=0: one stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // The split step: the head of the cost ranking (and every task with more UEs than eight lanes hold) on the 16-lane instance,
+    // one task per wave, on a stream of its own BESIDE the 8-lane launch that takes the rest eight tasks to a wave.
+    int mixed = 0;                   // 0 off; n: the first 1/n of the ranking goes to the 16-lane launch
+    int mixed_ue = 8;                // tasks with this many UEs or more lead the ranking
+    hipStream_t side2 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     RsDev hdev;            // host copy of the device constants
     RsDev* ddev = nullptr;
     RsState st;
@@ -405,6 +411,9 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
     }
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
     h->mux = cfg->l1_multiplex != 0;
     h->n_ran = cfg->n_embb + cfg->n_mmtc;
     h->n_slices = h->mux ? (cfg->n_embb > 0) + (cfg->n_mmtc > 0) : h->n_ran;
@@ -565,6 +574,8 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         if (const char* e = dev_env("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
         if (const char* e = dev_env("RANSLICE_SNAKE_ROT")) h->rot_mask = (int)strtol(e, nullptr, 0);
     }
+    if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
+    if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
     h->block_hint = auto_hint(h);
     if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
@@ -595,6 +606,9 @@ extern "C" void rs_destroy(rs_handle* h) {
         (void)hipEventDestroy(e.second);
     }
     if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
+    if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -818,6 +832,8 @@ static int launch_step(rs_handle* h) {
         a.replay = 0;
         a.order = nullptr;
         a.spread = 0;
+        a.order_off = 0;
+        a.order_cnt = -1;
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (h->timing) {
             if (h->ev_used == h->ev.size()) {
@@ -830,28 +846,31 @@ static int launch_step(rs_handle* h) {
             e1 = h->ev[h->ev_used].second;
             h->ev_used++;
         }
+        hipStream_t lstream = h->stream;
         auto launch = [&](int g) {
             // at most one wave per SIMD of the chip: one task per wave (StepArgs::spread)
-            a.spread = (h->spread_mode == 1 || (h->spread_mode < 0 && h->n_tasks <= h->spread_max)) ? 1 : 0;
+            if (a.order_cnt < 0) a.spread = (h->spread_mode == 1 || (h->spread_mode < 0 && h->n_tasks <= h->spread_max)) ? 1 : 0;
             const int per_block = a.spread ? 4 : 256 / g;
-            dim3 grid((h->n_tasks + per_block - 1) / per_block), block(256);
+            const int n_mine = a.order_cnt >= 0 ? a.order_cnt : h->n_tasks;
+            dim3 grid((n_mine + per_block - 1) / per_block), block(256);
             const bool tr = h->trace_on;
             // BLOCK instances hand out the RB pairs of wide contested slices in block rounds; the plain 16-lane one
             // carries the trip loop alone (rs_set_schedule_hint)
 #define RS_LAUNCH_STEP(G_, TR_, BL_)                                                                              \
     do {                                                                                                          \
         if (h->hdev.pf_div_fast)                                                                                  \
-            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, true>), grid, block, 0, h->stream, a);             \
+            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, true>), grid, block, 0, lstream, a);             \
         else                                                                                                      \
-            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, false>), grid, block, 0, h->stream, a);            \
+            hipLaunchKernelGGL((embb_step_kernel<G_, TR_, BL_, false>), grid, block, 0, lstream, a);            \
     } while (0)
             if (g == 8) {
                 if (tr) RS_LAUNCH_STEP(8, true, true);
-                else RS_LAUNCH_STEP(8, false, true);
+                else if (h->block_hint) RS_LAUNCH_STEP(8, false, true);
+                else hipLaunchKernelGGL((embb_step_kernel<8, false, false, true>), grid, block, 0, lstream, a);
             } else if (g == 16) {
                 if (tr) RS_LAUNCH_STEP(16, true, true);
                 else if (h->block_hint) RS_LAUNCH_STEP(16, false, true);
-                else hipLaunchKernelGGL((embb_step_kernel<16, false, false, true>), grid, block, 0, h->stream, a);  // (run-time flag inside)
+                else hipLaunchKernelGGL((embb_step_kernel<16, false, false, true>), grid, block, 0, lstream, a);  // (run-time flag inside)
             } else {
                 if (tr) RS_LAUNCH_STEP(32, true, true);
                 else RS_LAUNCH_STEP(32, false, true);
@@ -864,17 +883,40 @@ static int launch_step(rs_handle* h) {
             const int par = h->order_par;
             h->order_par ^= 1;
             const unsigned nb = (unsigned)((h->n_tasks + 255) / 256);
+            const bool split = h->mixed > 0 && !h->trace_on && h->group == 16;
             hipLaunchKernelGGL(order_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev, h->d_st, h->d_actions,
-                               h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot, make_int4(h->key_w[0], h->key_w[1], h->key_w[2], h->key_w[3]));
+                               h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot, make_int4(h->key_w[0], h->key_w[1], h->key_w[2], h->key_w[3]),
+                               split ? h->mixed_ue : 0);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
-                               h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
-                               h->snake == 1 ? h->spread_max : h->snake, h->snake_mask, h->rot_mask);
+                               h->d_order, (h->order_mode > 3 && !split) ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
+                               split ? 0 : (h->snake == 1 ? h->spread_max : h->snake), h->snake_mask, h->rot_mask);
             a.order = h->d_order;
         }
+        const bool split = a.order && h->mixed > 0 && !h->trace_on && h->group == 16 && h->n_tasks >= 64 * h->mixed;
         // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)
         if (h->timing) HIPCHK(h, hipEventRecord(e0, h->stream));
-        launch(h->group);
+        if (split) {
+            const int head = h->n_tasks / h->mixed;
+            HIPCHK(h, hipEventRecord(h->ev_fork2, h->stream));
+            HIPCHK(h, hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
+            lstream = h->side2;
+            a.order_off = 0;
+            a.order_cnt = head;
+            a.spread = 1;
+            launch(16);
+            HIPCHK(h, hipEventRecord(h->ev_join2, h->side2));
+            lstream = h->stream;
+            a.order_off = head;
+            a.order_cnt = h->n_tasks - head;
+            a.spread = 0;
+            launch(8);
+            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join2, 0));
+            a.order_off = 0;
+            a.order_cnt = -1;
+        } else {
+            launch(h->group);
+        }
         if (h->timing) HIPCHK(h, hipEventRecord(e1, h->stream));
         a.order = nullptr;
         if (h->group < 32) {
@@ -1201,6 +1243,7 @@ extern "C" int rs_save_state(rs_handle* h, void* blob, uint64_t bytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side2) HIPCHK(h, hipStreamSynchronize(h->side2));
     rs_state_header hd = {kRsStateMagic, (uint64_t)h->regions.size(), need, rs_cfg_hash(h), (int64_t)h->clock, (int64_t)h->steps,
                           h->order_par, h->graph_par, h->block_hint, h->hint_auto ? 1 : 0, h->is_reset ? 1 : 0, 0};
     memcpy(blob, &hd, sizeof hd);
@@ -1225,6 +1268,7 @@ extern "C" int rs_load_state(rs_handle* h, const void* blob, uint64_t bytes) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
+    if (h->side2) HIPCHK(h, hipStreamSynchronize(h->side2));
     drop_graph(h);
     const char* o = (const char*)blob + sizeof hd;
     for (auto& r : h->regions) {

@@ -521,6 +521,8 @@ struct StepArgs {
     int32_t spread;           // 1: ONE task per wave (its first group; the other groups idle).  For batches of at most one wave
                               // per SIMD of the chip: groups of a wave run their loops in lockstep, so a wave costs the maximum
                               // over its tasks loop by loop, and a batch this small gains nothing from packing them.
+    int32_t order_off, order_cnt;  // this launch takes order[order_off .. order_off + order_cnt) (order_cnt < 0: every task) --
+                              // the split step: the head of the cost ranking on the 16-lane instance, the rest on the 8-lane one
 };
 
 // select among three wave-uniform values by a per-lane index 0..2
@@ -675,9 +677,10 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const int tq = tid / G;              // my group's index in the block
     const int n_tasks = D->n_envs * D->n_embb;
     int task = A.spread ? (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6) : (int)blockIdx.x * TPB + (int)(threadIdx.x / G);
-    const bool in_range = task < n_tasks && (!A.spread || gbase == 0);
-    if (!in_range) task = n_tasks - 1;
-    if (A.order) task = A.order[task];
+    const int n_mine = A.order_cnt >= 0 ? A.order_cnt : n_tasks;  // tasks of this launch
+    const bool in_range = task < n_mine && (!A.spread || gbase == 0);
+    if (!in_range) task = n_mine - 1;
+    if (A.order) task = A.order[A.order_off + task];
     const bool selected = in_range && (!A.replay || A.redo[task] != 0);
     if (!wave_any(selected)) return;  // replay launch: nothing flagged in this wave
     const int rep = task / D->n_embb;

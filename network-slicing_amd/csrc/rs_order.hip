@@ -42,7 +42,7 @@ __device__ __forceinline__ int order_key(int mode, int n_ue, int n_prb, int cost
 // block first (LDS atomics), then one global atomic per (block, occupied bin) reserves the block's range.
 __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict__ D, const RsState* __restrict__ Sp,
                                                         const int32_t* __restrict__ actions, int mode, int* hist,
-                                                        uint64_t* slot, int4 kw) {
+                                                        uint64_t* slot, int4 kw, int split_ue) {
     __shared__ int cnt[RS_ORDER_BINS];  // tasks of this block per bin, then the block's base rank in the bin
     for (int k = threadIdx.x; k < RS_ORDER_BINS; k += 256) cnt[k] = 0;
     __syncthreads();
@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict_
         } else {
             key = order_key(mode, Sp->t_n_ue[task], n_prb, Sp->t_cost[task]);
         }
+        // split step (rs_api.hip): tasks with split_ue UEs or more lead the ranking whatever their cost -- they do not fit the
+        // 8-lane instance -- and the cost key orders each class at half its resolution
+        if (split_ue > 0) key = (Sp->t_n_ue[task] >= split_ue ? RS_ORDER_BINS / 2 : 0) + ((key >> 1) < RS_ORDER_BINS / 2 ? (key >> 1) : RS_ORDER_BINS / 2 - 1);
         bin = RS_ORDER_BINS - 1 - key;  // heaviest first
         local = atomicAdd(&cnt[bin], 1);
     }
