@@ -466,6 +466,10 @@ def test_agent_side_calls_see_the_end_of_a_graph_loop(golden_dir):
                 ag.run_resident(env, k, graph=True)
                 stats = ag.stats()                 # agent's stream only
                 blob = ag.save_state()
+                env.synchronize()                  # everything at rest: the checkpoint taken above must already be this one
+                ag.synchronize()
+                assert ag.save_state().tobytes() == blob.tobytes(), 'checkpoint torn after a %d-step graph call' % k
+                assert list(ag.stats()) == list(stats)
             else:
                 for _ in range(k):
                     ag.step_resident(env)
@@ -474,12 +478,17 @@ def test_agent_side_calls_see_the_end_of_a_graph_loop(golden_dir):
                 ag.synchronize()
                 stats = ag.stats()
                 blob = ag.save_state()
-            got.append((mode, k, list(stats), blob.tobytes()))
+            # (the blobs of the two modes are not compared: scratch rows of the repair rounds, which the captured sequence always
+            # carries, travel in them; the dictionaries and the control state are)
+            d = [ag.learner(r, s_, with_kinv=True) for r in (0, N - 1) for s_ in range(5)]
+            got.append((mode, k, list(stats), d, ag.dictionary_sizes().copy()))
         env.close()
         ag.close()
     for a, b in zip(got[:3], got[3:]):
         assert a[2] == b[2], (a[1], a[2], b[2])
-        assert a[3] == b[3], 'checkpoint torn after a %d-step graph call' % a[1]
+        assert (a[4] == b[4]).all()
+        for x, y in zip(a[3], b[3]):
+            assert x['m'] == y['m'] and all(x[k].tobytes() == y[k].tobytes() for k in ('landmarks', 'coeff', 'kinv'))
 
 
 def test_load_state_refuses_torn_blobs_and_accepts_another_pool_size(golden_dir):
