@@ -126,7 +126,7 @@ struct rs_handle {
     int snake_mask = 0x2aaaaaaa;  // the rounds dealt backwards (bit k = round k): every second one; RANSLICE_SNAKE_MASK (developer knob)
     int snake = 1;               // every second round of waves in reverse cost order (rs_order.hip); RANSLICE_SNAKE=0: off, > 1: the length of a round in waves (developer knob)
     bool hint_auto = true;      // block_hint follows the scenario / the driving agent until the caller sets it
-    int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (tools/group_sweep.py)
+    int group = 16;              // lanes per task of the primary launch: 8, 16 or 32 (profiles/HISTORY.md)
     bool trace_on = false;
     int n_slices = 0, n_vars = 0, n_tasks = 0;   // n_slices = action / label entries per replica
     int n_ran = 0;                                // RAN slices (info rows): n_embb + n_mmtc
@@ -548,7 +548,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         // One heavy task per wave pays while the whole batch is co-resident (the launch ends with its heaviest wave;
         // 1.13 vs 1.27 ms at 4096 replicas).  A batch of several rounds of waves is bound by the instructions issued
         // instead, and waves of like tasks issue a sixth fewer (3.9 vs 3.4 M env-steps/s at 8192 replicas, 4.3 vs 3.6
-        // at 16384; tools/pair_sweep.sh).
+        // at 16384; profiles/HISTORY.md).
         int cus = 256;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) != hipSuccess) cus = 256;
         (void)hipGetLastError();
@@ -558,9 +558,9 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     if (const char* e = dev_env("RANSLICE_PAIR")) h->order_pair = atoi(e);
     // Lanes per task: with few tasks the step is pure latency and the 32-lane instance (more lanes per sum and per
     // RB pass, all its waves co-resident at 3 per SIMD up to 6144 tasks) is faster; from there on 16 lanes
-    // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (tools/group_sweep.py).
+    // (4 tasks per wave, 5 waves per SIMD) carry more tasks in flight (profiles/HISTORY.md).
     h->group = h->n_tasks <= 6144 ? 32 : 16;
-    if (const char* e = dev_env("RANSLICE_GROUP")) {  // developer knob (tools/group_sweep.py)
+    if (const char* e = dev_env("RANSLICE_GROUP")) {  // developer knob (profiles/HISTORY.md)
         const int g = atoi(e);
         if (g == 8 || g == 16 || g == 32) h->group = g;
     }
@@ -577,7 +577,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
     h->block_hint = auto_hint(h);
-    if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (tools/block_sweep.sh): as rs_set_schedule_hint
+    if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (profiles/HISTORY.md): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
         if (!h->hint_auto) h->block_hint = atoi(e) ? 1 : 0;
     }

@@ -99,7 +99,7 @@ namespace rs {
 #define RS_LOADS 4  // column sums: fading samples a lane has in flight (4 or 8)
 #endif
 #ifndef RS_OCC_OTHER
-#define RS_OCC_OTHER 3  // waves per SIMD the tracing / 8- and 32-lane instances are compiled for (5: tools/spill_repro.sh)
+#define RS_OCC_OTHER 3  // waves per SIMD the tracing / 8- and 32-lane instances are compiled for (5: profiles/HISTORY.md)
 #endif
 #ifndef RS_DYN_PRIO
 #define RS_DYN_PRIO 1
@@ -108,7 +108,7 @@ namespace rs {
 #define RS_BLOCK_MIN 4     // PF: block rounds while a contender's share of the free RB pairs is at least this ...
 #endif
 #ifndef RS_BLOCK_PAIRS
-#define RS_BLOCK_PAIRS 8   // ... in slices of at least this many RB pairs (tools/block_sweep2.sh: 24 until the shares of a block
+#define RS_BLOCK_PAIRS 8   // ... in slices of at least this many RB pairs (profiles/HISTORY.md: 24 until the shares of a block
 #endif                     //     round lost their run-time branch; with agents in the loop 8 is 4 % faster late in learning)
 #ifndef RS_HINT_PAIRS
 #define RS_HINT_PAIRS 24   // the BLOCK instance is picked for allocations with slices of this many pairs (rs_api.hip: auto_hint,
@@ -116,10 +116,10 @@ namespace rs {
 #ifndef RS_PACE_3B
 #define RS_PACE_3B 46ull  // the same three thresholds in the BLOCK instances (agents' allocations: a few wide tasks carry the launch, and
 #define RS_PACE_2B 44ull  // a wave that is merely a little behind should not yet take issue slots from them): > 1.44 / 1.375 / 1.31 x the
-#define RS_PACE_1B 42ull  // reference pace (tools/pace_sweep.sh: step kernel 1.30 -> 1.25 ms early, 1.545 -> 1.50 late in learning)
+#define RS_PACE_1B 42ull  // reference pace (profiles/HISTORY.md: step kernel 1.30 -> 1.25 ms early, 1.545 -> 1.50 late in learning)
 #endif
 #ifndef RS_PACE_3
-#define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, tools/occ_sweep.sh)
+#define RS_PACE_3 40ull  // > 1.25 x the reference pace: priority 3 (the plateau of a sweep, profiles/HISTORY.md)
 #define RS_PACE_2 35ull  // > 1.09: 2
 #define RS_PACE_1 28ull  // > 0.875: 1
 #endif
@@ -1586,7 +1586,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             wl_[3] = (unsigned long long)__builtin_amdgcn_s_memrealtime();
         }
 #endif
-#ifdef RS_PACE_XCC  // developer build (tools/xcc_pace.py): wave paces per XCD through the section-profile buffer
+#ifdef RS_PACE_XCC  // developer build (profiles/HISTORY.md): wave paces per XCD through the section-profile buffer
         const unsigned xcc_ = __builtin_amdgcn_s_getreg(63508) & 7u;
         atomicAdd((unsigned long long*)&A.sections[2 * xcc_], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
         atomicAdd((unsigned long long*)&A.sections[2 * xcc_ + 1], 1ull);

@@ -112,6 +112,72 @@ def test_bench_path_steady_state_vs_oracle():
             assert h[5][k].tobytes() == info.tobytes(), ('info', r, i)
 
 
+def _oracle_script_chunk(args):
+    """oracle replicas [lo, hi) driven by the bench action script: `skip` steps inside the C loop (rso_bench_run returns the
+    running sum of the rewards, added in step order), then `tail` steps one at a time with every output"""
+    scenario, lo, hi, skip, tail, cols = args
+    cfg = make_config(scenario, n_envs=1)
+    fading = [synth_fading(t, cols) for t in range(3)]
+    out = []
+    for r in range(lo, hi):
+        o = po.OracleEnv(cfg, fading)
+        o.set_seed(replica_seed(0, r))
+        o.reset()
+        acc = o.bench_run(ACTION_SEED, r, 0, skip) if skip else 0.0
+        rows = []
+        for i in range(skip, skip + tail):
+            a = po.random_actions(cfg, ACTION_SEED, i, r)
+            q = o.step(a)
+            rows.append((a, q['obs'].copy(), q['reward'], q['labels'].copy(), q['violations'].copy(), q['info'].copy()))
+        out.append((acc, rows))
+    return out
+
+
+@pytest.mark.parametrize('scenario,skip,tail', [(0, 0, 12), (0, 150, 4), (2, 60, 4)])
+def test_every_replica_at_baseline_size_vs_oracle(scenario, skip, tail):
+    """the bench path (device action script + resident step, 10,000-column traces, default order and instance)
+    with EVERY one of the 4096 replicas followed by an oracle replica.  (0, 12): the first twelve steps, every output of every
+    step.  (skip, 4): the oracle runs `skip` steps inside its C loop and hands back the sum of the rewards, which must equal,
+    bit for bit, the sum of the device's per-step rewards added in the same order; then four steps with every output
+    (actions, observations as f32 bits, rewards, labels, violations, the ten info sums per slice as f64 bits) -- the state after
+    `skip` steps of arrivals, departures and bursts has to be right in every replica for those to match."""
+    from ranslice.vec_env import VecRanSlice
+    cfg = make_config(scenario, n_envs=N_FULL)
+    workers = min(16, os.cpu_count() or 1)
+    per = 64
+    jobs = [(scenario, lo, min(lo + per, N_FULL), skip, tail, COLS) for lo in range(0, N_FULL, per)]
+    with ProcessPoolExecutor(max_workers=workers, mp_context=_SPAWN) as ex:
+        fut = ex.map(_oracle_script_chunk, jobs, chunksize=1)
+        env = VecRanSlice(n_envs=N_FULL, cfg=cfg, fading=_fading())
+        env.reset()
+        acc = np.zeros(N_FULL)
+        hip = []
+        for i in range(skip + tail):
+            env.random_actions(ACTION_SEED, i)
+            env.step_resident()
+            f = env.fetch()
+            if i < skip:
+                acc += f['reward']
+            else:
+                hip.append((f['actions'].copy(), f['obs'].copy(), f['reward'].copy(), f['labels'].copy(), f['violations'].copy(),
+                            env.l1_info().copy()))
+        env.close()
+        bad = []
+        r = 0
+        for chunk in fut:
+            for o_acc, rows in chunk:
+                ok = o_acc == acc[r]
+                for i, (a, obs, rew, lab, viol, info) in enumerate(rows):
+                    h = hip[i]
+                    ok = ok and (h[0][r] == a).all() and h[1][r].tobytes() == obs.tobytes() and h[2][r] == rew
+                    ok = ok and (h[3][r] == lab).all() and (h[4][r] == viol).all() and h[5][r].tobytes() == info.tobytes()
+                if not ok:
+                    bad.append(r)
+                r += 1
+    assert r == N_FULL
+    assert not bad, '%d of %d replicas differ from the oracle, first %s' % (len(bad), N_FULL, bad[:10])
+
+
 def _oracle_acts_run(args):
     scenario, seed, acts, churn = args
     cfg = make_config(scenario, n_envs=1)

@@ -217,12 +217,17 @@ def test_drop_in_experiment_plumbing(golden_dir):
     assert set(info['l1_info'][0][0]) == set(sc.state_variables_embb)
 
 
+_ORACLE_FADING = {}
+
+
 def _oracle_closed_loop(args):
     """oracle env + oracle agent of one replica, closed loop (KBRL_Control.run body, kbrl_control.py:128-141)"""
     scenario, env_seed, ag_seed, ia, sf, steps, cols, capacity = args
     from ranslice.fading import synth_fading
     dims, n_prbs = _dims(scenario)
-    e = po.OracleEnv(make_config(scenario), [synth_fading(t, cols) for t in range(3)])
+    if cols not in _ORACLE_FADING:     # (a pool worker follows many replicas: the tables are made once per process)
+        _ORACLE_FADING[cols] = [synth_fading(t, cols) for t in range(3)]
+    e = po.OracleEnv(make_config(scenario), _ORACLE_FADING[cols])
     e.set_seed(env_seed)
     e.reset()
     a = po.OracleKBRL(dims, n_prbs, ia, sf, capacity=capacity)
@@ -243,7 +248,7 @@ def _oracle_closed_loop(args):
 def test_full_size_closed_loop_vs_oracle():
     """BASELINE config 3's loop at its size: 4096 replicas of scenario_0 with one KBRL agent each, closed on the
     device (kb_step_resident: update_control + select_action write the next action into the simulator's buffer),
-    10,000-column traces; 24 sampled replicas against oracle env + oracle agent on the same streams: executed
+    10,000-column traces; 272 replicas against oracle env + oracle agent on the same streams: executed
     actions, observations (bits), labels and the selected actions, every step; dictionary sizes at the end."""
     import ctypes as C
     from concurrent.futures import ProcessPoolExecutor
@@ -256,11 +261,13 @@ def test_full_size_closed_loop_vs_oracle():
     rng = np.random.default_rng(11)
     ia = rng.integers(10, 35, size=(N, 5)).astype(np.int32)
     sf = rng.integers(2, 8, size=(N, 5)).astype(np.int32)
-    sample = [0, 1, 2, 3, 15, 16, 63, 64, 100, 255, 256, 777, 1023, 1024, 2000, 2047, 2048, 3000, 3333, 4000, 4093,
-              4094, 4095, 1234]
+    # 272 replicas (at least 256): the edges of blocks, waves and the batch, and every 16th replica
+    sample = sorted(set([0, 1, 2, 3, 15, 16, 63, 64, 100, 255, 256, 777, 1023, 1024, 2000, 2047, 2048, 3000, 3333, 4000, 4093,
+                         4094, 4095, 1234] + list(range(5, N, 16))))
+    assert len(sample) >= 256
     with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
         fut = ex.map(_oracle_closed_loop, [(scenario, replica_seed(300, r), 7 + r, ia[r], sf[r], steps, cols, cap) for r in sample],
-                     chunksize=1)
+                     chunksize=4)
         env = VecRanSlice(n_envs=N, cfg=make_config(scenario, n_envs=N), fading=[synth_fading(t, cols) for t in range(3)],
                           seed=300)
         ag = VecKBRL(N, dims, n_prbs, capacity=cap)

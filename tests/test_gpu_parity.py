@@ -229,7 +229,8 @@ def test_ragged_batch(golden_dir):
 def test_full_size_sampled():
     """BASELINE config 2 shape: 4096 replicas, 10,000-sample traces; oracle follows a sample."""
     fading = [synth_fading(t, 10000) for t in range(3)]
-    sample = [0, 1, 7, 8, 63, 64, 1000, 2047, 2048, 4095]
+    sample = sorted(set([0, 1, 7, 8, 63, 64, 1000, 2047, 2048, 4095] + list(range(3, 4096, 32))))   # 138 replicas, in process;
+    # EVERY replica of this shape is followed by tests/test_gpu_fullsize.py::test_every_replica_at_baseline_size_vs_oracle
     _compare(0, n_envs=4096, steps=12, fading=fading, churn=False, seed0=0, check_trace=False, sample=sample)
 
 

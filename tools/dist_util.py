@@ -1,4 +1,4 @@
-"""torch.distributed helpers of the measurement harness (bench.py, tools/run_shared_kbrl.py and the gloo tests).
+"""torch.distributed helpers of the measurement harness (the world_size-2 gloo tests on CPU; bench.py itself uses tools/rank_group.py).
 They live outside the product package on purpose: network-slicing_amd/ never imports torch.  The process group is
 only used to agree on wall-clock time (barrier, MAX over ranks) and to add up scalar reports."""
 import numpy as np

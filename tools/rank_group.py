@@ -1,7 +1,7 @@
 """A process group without torch: the ranks of one node agree on wall-clock time (barrier, MAX over ranks), add up
 small reports and pass a few bytes around (the 128-byte RCCL communicator id) over a plain TCP socket on 127.0.0.1.
 
-bench.py and tools/run_shared_kbrl.py use it for everything that is not the data path: RanSlice.step has no collective,
+bench.py and its config-4 leg use it for everything that is not the data path: RanSlice.step has no collective,
 and the one collective of the build (the shared-dictionary exchange) is ncclAllGather inside libranslice.so.
 
 Topology: rank 0 listens on an ephemeral port and publishes (port, token) in a rendezvous file; the other ranks poll the
