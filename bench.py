@@ -266,7 +266,19 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
             'pool': pool,
             'kinv_streaming': {'rank1': stream_roof('rank1', 'rank1_launch_ms', 'n_rank1'),
                                'matvec': stream_roof('matvec', 'matvec_launch_ms', 'n_matvec')},
+            'per_step_ms': {'heavy_matvec': ph['matvec_launch_ms'] * ph['n_matvec'] / k, 'heavy_rank1': ph['rank1_launch_ms'] * ph['n_rank1'] / k,
+                            'heavy_finish': ph['finish_launch_ms'] * ph['n_finish'] / k, 'update_small': ph['update_small_launch_ms'] * ph['n_update_small'] / k,
+                            'select_bin': ph['select_bin_launch_ms'] * ph['n_select_bin'] / k,
+                            'select_gemm': ph['select_gemm_launch_ms'] * ph['n_select_gemm'] / k},
         }
+        # select_bin_kernel: ONE pass over every landmark of every learner -- ten coordinate rows, the coefficient and the grid index
+        # in (92 B per landmark of an eMBB learner), the D0 and E rows out (16 B); bytes from the dictionary sizes at the window's end
+        if ph['select_bin_launch_ms']:
+            sb_bytes = float(np.sum(sizes)) * (8.0 * (d - 1) + 8.0 + 4.0 + 16.0)
+            gbs = sb_bytes / (ph['select_bin_launch_ms'] * 1e-3) / 1e9
+            rec['select_bin'] = {'bound': 'hbm', 'kernel': 'select_bin_kernel', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                 'frac': gbs / HBM_PEAK_GBS, 'bytes_per_launch': sb_bytes, 'launch_ms_mean': ph['select_bin_launch_ms'],
+                                 'landmarks': int(np.sum(sizes))}
         # the memory horizon: the pool never frees before kb_reset; at the growth of this window it is exhausted at ...
         grow = (pool['used_bytes'] - p0['used_bytes']) / float(k)
         if grow > 0:

@@ -61,10 +61,11 @@ struct kb_handle {
     bool is_reset = false;
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
-    std::vector<int> ev_kind;  // 0 update phase, 1 select, 2 one launch of heavy_matvec_kernel, 3 one of heavy_rank1_kernel
+    std::vector<int> ev_kind;  // 0 update phase, 1 select phase; ONE launch of: 2 heavy_matvec_kernel, 3 heavy_rank1_kernel, 4 select_bin_kernel,
+                               // 5 heavy_finish_kernel, 6 select_gemm_kernel, 7 update_small_kernel
     size_t ev_used = 0;
-    double repair_ms[2] = {0.0, 0.0};  // mean launch of the two (kb_phase_times_ms computes them, kb_repair_times_ms hands them out)
-    int64_t repair_n[2] = {0, 0};
+    double kind_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // mean per kind over the span the last kb_phase_times_ms call summed up
+    int64_t kind_n[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::string err;
 };
 
@@ -533,7 +534,10 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         // the learners with a mistake to repair: small dictionaries one wave each, all at once; large ones a workgroup
         // each, taken by persistent workgroups
         const unsigned blocks = (unsigned)(k->T < k->heavy_blocks ? k->T : k->heavy_blocks);
+        hipEvent_t es;
+        if ((rc = kb_time_begin(k, &es, 7)) != RS_OK) return rc;
         hipLaunchKernelGGL(kb::update_small_kernel, dim3((unsigned)(k->T < 4096 ? k->T : 4096)), dim3(256), 0, k->stream, a);
+        if (es) HIPCHK(k, hipEventRecord(es, k->stream));
         // The rounds are nine launches that do nothing while no dictionary is large (early in learning): they are
         // enqueued only once a recent step has queued a few large learners.  The host reads that count from pinned memory
         // without waiting for the device, so it lags by the depth of the launch queue; until it catches up the clean-up
@@ -545,7 +549,10 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
             if ((rc = kb_time_begin(k, &em, 2)) != RS_OK) return rc;
             hipLaunchKernelGGL(kb::heavy_matvec_kernel, dim3((unsigned)k->mv_grid), dim3(256), 0, k->stream, k->D, k->K);
             if (em) HIPCHK(k, hipEventRecord(em, k->stream));
+            hipEvent_t ef;
+            if ((rc = kb_time_begin(k, &ef, 5)) != RS_OK) return rc;
             hipLaunchKernelGGL(kb::heavy_finish_kernel, dim3(1024), dim3(256), 0, k->stream, a);
+            if (ef) HIPCHK(k, hipEventRecord(ef, k->stream));
             hipLaunchKernelGGL(kb::heavy_plan_kernel, dim3(1), dim3(1024), 0, k->stream, k->D, k->K);
             if ((rc = kb_time_begin(k, &er, 3)) != RS_OK) return rc;
             hipLaunchKernelGGL(kb::heavy_rank1_kernel, dim3((unsigned)k->r1_grid), dim3(256), 0, k->stream, k->D, k->K);
@@ -575,8 +582,13 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
     } else {  // one agent per replica: a wave per learner bins its landmarks, then sixteen learners per workgroup are scored
               // as one product on the matrix cores
         const unsigned slots = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
+        hipEvent_t eb, eg;
+        if ((rc = kb_time_begin(k, &eb, 4)) != RS_OK) return rc;
         hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a);
+        if (eb) HIPCHK(k, hipEventRecord(eb, k->stream));
+        if ((rc = kb_time_begin(k, &eg, 6)) != RS_OK) return rc;
         hipLaunchKernelGGL(kb::select_gemm_kernel, dim3((slots + KB_SEL_WAVES - 1) / KB_SEL_WAVES), dim3(256), 0, k->stream, a);
+        if (eg) HIPCHK(k, hipEventRecord(eg, k->stream));
     }
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));
     hipLaunchKernelGGL(kb::adjust_kernel, dim3((unsigned)((k->cfg.n_envs + 255) / 256)), dim3(256), 0, k->stream, k->D,
@@ -979,21 +991,35 @@ extern "C" int kb_phase_times_ms(kb_handle* k, double ms[2], int64_t n[2]) {
     if (!k || !ms || !n) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
     HIPCHK(k, hipStreamSynchronize(k->stream));
-    double tot[4] = {0.0, 0.0, 0.0, 0.0};
-    int64_t cnt[4] = {0, 0, 0, 0};
+    double tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (size_t i = 0; i < k->ev_used; ++i) {
         float t = 0.f;
         HIPCHK(k, hipEventElapsedTime(&t, k->ev[i].first, k->ev[i].second));
-        tot[k->ev_kind[i]] += t;
-        cnt[k->ev_kind[i]] += 1;
+        tot[k->ev_kind[i] & 7] += t;
+        cnt[k->ev_kind[i] & 7] += 1;
+    }
+    for (int q = 0; q < 8; ++q) {
+        k->kind_n[q] = cnt[q];
+        k->kind_ms[q] = cnt[q] ? tot[q] / (double)cnt[q] : 0.0;
     }
     for (int q = 0; q < 2; ++q) {
-        n[q] = cnt[q];
-        ms[q] = cnt[q] ? tot[q] / (double)cnt[q] : 0.0;
-        k->repair_n[q] = cnt[2 + q];
-        k->repair_ms[q] = cnt[2 + q] ? tot[2 + q] / (double)cnt[2 + q] : 0.0;
+        n[q] = k->kind_n[q];
+        ms[q] = k->kind_ms[q];
     }
     k->ev_used = 0;
+    return RS_OK;
+}
+
+// mean duration of ONE launch, per kernel, over the span the last kb_phase_times_ms / kb_kernel_time_ms call summed up (HIP events
+// on the agent's stream around every launch, kb_set_kernel_timing): [2] heavy_matvec_kernel, [3] heavy_rank1_kernel,
+// [4] select_bin_kernel, [5] heavy_finish_kernel, [6] select_gemm_kernel, [7] update_small_kernel ([0], [1]: the two phases)
+extern "C" int kb_kernel_times_ms(kb_handle* k, double ms[8], int64_t n[8]) {
+    if (!k || !ms || !n) return RS_EINVAL;
+    for (int q = 0; q < 8; ++q) {
+        ms[q] = k->kind_ms[q];
+        n[q] = k->kind_n[q];
+    }
     return RS_OK;
 }
 
@@ -1002,8 +1028,8 @@ extern "C" int kb_phase_times_ms(kb_handle* k, double ms[2], int64_t n[2]) {
 extern "C" int kb_repair_times_ms(kb_handle* k, double ms[2], int64_t n[2]) {
     if (!k || !ms || !n) return RS_EINVAL;
     for (int q = 0; q < 2; ++q) {
-        ms[q] = k->repair_ms[q];
-        n[q] = k->repair_n[q];
+        ms[q] = k->kind_ms[2 + q];
+        n[q] = k->kind_n[2 + q];
     }
     return RS_OK;
 }
@@ -1413,8 +1439,10 @@ struct kb_state_header {
 static const uint64_t kKbStateMagic = 0x4b42534c49434534ull;
 static uint64_t kb_cfg_hash(const kb_handle* k) {
     uint64_t x = 1469598103934665603ull;
-    const unsigned char* p = (const unsigned char*)&k->cfg;
-    for (size_t i = 0; i < sizeof k->cfg; ++i) x = (x ^ p[i]) * 1099511628211ull;
+    kb_config c = k->cfg;
+    c.pool_bytes = 0;  // (see below: the pool's size is not part of the configuration)
+    const unsigned char* p = (const unsigned char*)&c;
+    for (size_t i = 0; i < sizeof c; ++i) x = (x ^ p[i]) * 1099511628211ull;
     // (the pool's own size is not part of the configuration: a blob fits any handle whose pool holds what the blob uses --
     // with kb_config.pool_bytes == 0 the pool is sized from the free memory of the moment and differs from process to process)
     for (auto& r : k->regions) x = (x ^ (r.first == (void*)k->K.pool ? 0ull : (uint64_t)r.second)) * 1099511628211ull;

@@ -83,10 +83,11 @@ struct rs_handle {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // The split step: the head of the cost ranking (and every task with more UEs than eight lanes hold) on the 16-lane instance,
     // one task per wave, on a stream of its own BESIDE the 8-lane launch that takes the rest eight tasks to a wave.
-    int mixed = 0;                   // 0 off; n: the first 1/n of the ranking goes to the 16-lane launch
+    int mixed = 0;                   // 0 off; n: the first 1/n of the ranking goes to a 16-lane launch of one task per wave
+    int mixed_light = 256;           // the last mixed_light/256 of the ranking go to the 8-lane launch (256: all but the head)
     int mixed_ue = 8;                // tasks with this many UEs or more lead the ranking
-    hipStream_t side2 = nullptr;
-    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipStream_t side2 = nullptr, side3 = nullptr;
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr, ev_join3 = nullptr;
     RsDev hdev;            // host copy of the device constants
     RsDev* ddev = nullptr;
     RsState st;
@@ -414,6 +415,8 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     HIPCHK(h, hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
     HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     h->mux = cfg->l1_multiplex != 0;
     h->n_ran = cfg->n_embb + cfg->n_mmtc;
     h->n_slices = h->mux ? (cfg->n_embb > 0) + (cfg->n_mmtc > 0) : h->n_ran;
@@ -576,6 +579,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     }
     if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
+    if (const char* e = dev_env("RANSLICE_MIXED_LIGHT")) h->mixed_light = atoi(e);
     h->block_hint = auto_hint(h);
     if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (profiles/HISTORY.md): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
@@ -607,6 +611,8 @@ extern "C" void rs_destroy(rs_handle* h) {
     }
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->side2) (void)hipStreamDestroy(h->side2);
+    if (h->side3) (void)hipStreamDestroy(h->side3);
+    if (h->ev_join3) (void)hipEventDestroy(h->ev_join3);
     if (h->ev_fork2) (void)hipEventDestroy(h->ev_fork2);
     if (h->ev_join2) (void)hipEventDestroy(h->ev_join2);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -879,39 +885,65 @@ static int launch_step(rs_handle* h) {
         };
         // primary launch with h->group lanes per task; tasks that do not fit raise their redo flag and are
         // replayed from their untouched state by the 32-lane instance (waves without flagged tasks exit)
+        int seg_head = 0, seg_light = 0;
         if (h->order_mode > 0) {
             const int par = h->order_par;
             h->order_par ^= 1;
             const unsigned nb = (unsigned)((h->n_tasks + 255) / 256);
-            const bool split = h->mixed > 0 && !h->trace_on && h->group == 16;
+            const bool split = (h->mixed > 0 || h->mixed_light < 256) && !h->trace_on && h->group == 16 && h->n_tasks >= 4096;
+            // the three stretches of the ranking (heaviest first): [0, head) one task per 16-lane wave, [head, n - light) four per
+            // 16-lane wave, composed among themselves as without a split, [n - light, n) eight per 8-lane wave
+            if (split) {
+                seg_head = h->mixed > 0 ? (h->n_tasks / h->mixed) & ~3 : 0;
+                seg_light = h->mixed_light >= 256 ? h->n_tasks - seg_head : ((int)(((long long)h->n_tasks * h->mixed_light) >> 8)) & ~7;
+                if (((h->n_tasks - seg_head - seg_light) & 3) != 0) seg_light += (h->n_tasks - seg_head - seg_light) & 3;
+            }
+            const int seg_mid = h->n_tasks - seg_head - seg_light;
             hipLaunchKernelGGL(order_key_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev, h->d_st, h->d_actions,
                                h->order_mode, h->d_ohist + par * RS_ORDER_BINS, h->d_oslot, make_int4(h->key_w[0], h->key_w[1], h->key_w[2], h->key_w[3]),
                                split ? h->mixed_ue : 0);
             hipLaunchKernelGGL(order_scatter_kernel, dim3(nb), dim3(256), 0, h->stream, h->ddev,
                                h->d_ohist + par * RS_ORDER_BINS, h->d_ohist + (1 - par) * RS_ORDER_BINS, h->d_oslot,
-                               h->d_order, (h->order_mode > 3 && !split) ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
-                               split ? 0 : (h->snake == 1 ? h->spread_max : h->snake), h->snake_mask, h->rot_mask);
+                               h->d_order, h->order_mode > 3 ? h->order_pair : 0, 64 / h->group,  // modes 4.. = keys 1.. with heavy+light pairing
+                               h->snake == 1 ? h->spread_max : h->snake, h->snake_mask, h->rot_mask, seg_head, seg_head + seg_mid);
             a.order = h->d_order;
         }
-        const bool split = a.order && h->mixed > 0 && !h->trace_on && h->group == 16 && h->n_tasks >= 64 * h->mixed;
-        // the event pair brackets the primary step launch alone (what rocprofv3 lists as embb_step_kernel<G,...>)
+        // the event pair brackets the step launches of the step (without a split: what rocprofv3 lists as embb_step_kernel<G,...>)
         if (h->timing) HIPCHK(h, hipEventRecord(e0, h->stream));
-        if (split) {
-            const int head = h->n_tasks / h->mixed;
+        if (a.order && seg_head + seg_light > 0) {
+            const int seg_mid = h->n_tasks - seg_head - seg_light;
             HIPCHK(h, hipEventRecord(h->ev_fork2, h->stream));
-            HIPCHK(h, hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
-            lstream = h->side2;
-            a.order_off = 0;
-            a.order_cnt = head;
-            a.spread = 1;
-            launch(16);
-            HIPCHK(h, hipEventRecord(h->ev_join2, h->side2));
+            if (seg_head > 0) {
+                HIPCHK(h, hipStreamWaitEvent(h->side2, h->ev_fork2, 0));
+                lstream = h->side2;
+                a.order_off = 0;
+                a.order_cnt = seg_head;
+                a.spread = 1;
+                launch(16);
+                HIPCHK(h, hipEventRecord(h->ev_join2, h->side2));
+            }
+            if (seg_mid > 0 && seg_light > 0) {
+                HIPCHK(h, hipStreamWaitEvent(h->side3, h->ev_fork2, 0));
+                lstream = h->side3;
+                a.order_off = seg_head + seg_mid;
+                a.order_cnt = seg_light;
+                a.spread = 0;
+                launch(8);
+                HIPCHK(h, hipEventRecord(h->ev_join3, h->side3));
+            }
             lstream = h->stream;
-            a.order_off = head;
-            a.order_cnt = h->n_tasks - head;
             a.spread = 0;
-            launch(8);
-            HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join2, 0));
+            if (seg_mid > 0) {
+                a.order_off = seg_head;
+                a.order_cnt = seg_mid;
+                launch(16);
+            } else {
+                a.order_off = seg_head;
+                a.order_cnt = seg_light;
+                launch(8);
+            }
+            if (seg_head > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join2, 0));
+            if (seg_mid > 0 && seg_light > 0) HIPCHK(h, hipStreamWaitEvent(h->stream, h->ev_join3, 0));
             a.order_off = 0;
             a.order_cnt = -1;
         } else {
@@ -1244,6 +1276,7 @@ extern "C" int rs_save_state(rs_handle* h, void* blob, uint64_t bytes) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     if (h->side2) HIPCHK(h, hipStreamSynchronize(h->side2));
+    if (h->side3) HIPCHK(h, hipStreamSynchronize(h->side3));
     rs_state_header hd = {kRsStateMagic, (uint64_t)h->regions.size(), need, rs_cfg_hash(h), (int64_t)h->clock, (int64_t)h->steps,
                           h->order_par, h->graph_par, h->block_hint, h->hint_auto ? 1 : 0, h->is_reset ? 1 : 0, 0};
     memcpy(blob, &hd, sizeof hd);
@@ -1269,6 +1302,7 @@ extern "C" int rs_load_state(rs_handle* h, const void* blob, uint64_t bytes) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (h->side) HIPCHK(h, hipStreamSynchronize(h->side));
     if (h->side2) HIPCHK(h, hipStreamSynchronize(h->side2));
+    if (h->side3) HIPCHK(h, hipStreamSynchronize(h->side3));
     drop_graph(h);
     const char* o = (const char*)blob + sizeof hd;
     for (auto& r : h->regions) {

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void order_key_kernel(const RsDev* __restrict_
 // order[start(bin) + rank] = task; also clears the other parity's counters for the next step
 __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restrict__ D, const int* __restrict__ hist,
                                                             int* hist_next, const uint64_t* __restrict__ slot,
-                                                            int32_t* order, int pair, int tpw, int snake, int snake_mask, int rot_mask) {
+                                                            int32_t* order, int pair, int tpw, int snake, int snake_mask, int rot_mask,
+                                                            int seg_lo, int seg_hi) {
     __shared__ int start[RS_ORDER_BINS];
     __shared__ int part[256];
     constexpr int PER = RS_ORDER_BINS / 256;
@@ -118,11 +119,20 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restr
     __syncthreads();
     if (blockIdx.x == 0)
         for (int k = threadIdx.x; k < RS_ORDER_BINS; k += 256) hist_next[k] = 0;
-    const int n_tasks = D->n_envs * D->n_embb;
+    const int n_all = D->n_envs * D->n_embb;
     const int task = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (task >= n_tasks) return;
+    if (task >= n_all) return;
     const uint64_t v = slot[task];
     int p = start[(int)(v & (RS_ORDER_BINS - 1))] + (int)(v >> 11);  // rank, heaviest first
+    // The split step (rs_api.hip) deals the ranking out to several launches: ranks [seg_lo, seg_hi) are the packed 16-lane
+    // launch's and get the wave composition below among themselves; the ranks before (one task per wave) and after (the
+    // 8-lane instance, eight like tasks per wave) keep their place.  Without a split the segment is the whole ranking.
+    if (p < seg_lo || p >= seg_hi) {
+        order[p] = task;
+        return;
+    }
+    const int n_tasks = seg_hi - seg_lo;
+    p -= seg_lo;
     if (pair > 0 && tpw > 1 && n_tasks % tpw == 0) {
         // The heaviest `pair`/256 of the waves get ONE task from the heavy end of the ranking, filled up with
         // tpw - 1 from the light end: the heavy task's trip counts then set the wave's pace alone instead of adding
@@ -151,7 +161,7 @@ __global__ __launch_bounds__(256) void order_scatter_kernel(const RsDev* __restr
         if (((rot_mask >> (k & 31)) & 1) != 0 && (k + 1) * snake <= n_tasks / tpw) Wv = k * snake + (Wv - k * snake + snake / 2) % snake;
         p = Wv * tpw + in;
     }
-    order[p] = task;
+    order[seg_lo + p] = task;
 }
 
 }  // namespace rs

@@ -17,7 +17,7 @@ RS_OK, RS_EINVAL, RS_EOVERFLOW, RS_EHIP, RS_ESTATE = 0, -1, -2, -3, -4
 KB_EXPORTS = (
     'kb_create', 'kb_destroy', 'kb_last_error', 'kb_reset', 'kb_update_control', 'kb_select_action',
     'kb_step_resident', 'kb_run_resident', 'kb_predict', 'kb_update', 'kb_get_learner', 'kb_get_control', 'kb_set_adjusted',
-    'kb_comm_info', 'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_state_bytes', 'kb_save_state', 'kb_load_state', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
+    'kb_comm_info', 'kb_get_stats', 'kb_get_sizes', 'kb_get_pool', 'kb_state_bytes', 'kb_save_state', 'kb_load_state', 'kb_get_flags', 'kb_get_repair_work', 'kb_get_kernel_row', 'kb_shared_scan', 'kb_shared_apply', 'kb_shared_commit', 'kb_comm_unique_id', 'kb_comm_init', 'kb_shared_step', 'kb_shared_step_resident', 'kb_shared_merge', 'kb_history_begin', 'kb_history_fetch', 'kb_kernel_time_ms', 'kb_phase_times_ms', 'kb_repair_times_ms', 'kb_kernel_times_ms', 'kb_set_kernel_timing', 'kb_synchronize',
 )
 
 EXPORTS = (
@@ -132,6 +132,7 @@ def load(dev=None):
     L.kb_kernel_time_ms.argtypes = [vp, dp, i64p]
     L.kb_phase_times_ms.argtypes = [vp, dp, i64p]
     L.kb_repair_times_ms.argtypes = [vp, dp, i64p]
+    L.kb_kernel_times_ms.argtypes = [vp, dp, i64p]
     L.kb_set_kernel_timing.argtypes = [vp, C.c_int]
     L.kb_synchronize.argtypes = [vp]
     for name in EXPORTS:

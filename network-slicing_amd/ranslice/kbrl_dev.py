@@ -208,8 +208,13 @@ class VecKBRL:
         rm = (C.c_double * 2)()
         rn = (C.c_int64 * 2)()
         self._check(self.L.kb_repair_times_ms(self.h, rm, rn))
+        km = (C.c_double * 8)()
+        kn = (C.c_int64 * 8)()
+        self._check(self.L.kb_kernel_times_ms(self.h, km, kn))
         return dict(update_ms=ms[0], select_ms=ms[1], n_update=n[0], n_select=n[1],
-                    matvec_launch_ms=rm[0], rank1_launch_ms=rm[1], n_matvec=rn[0], n_rank1=rn[1])
+                    matvec_launch_ms=rm[0], rank1_launch_ms=rm[1], n_matvec=rn[0], n_rank1=rn[1],
+                    select_bin_launch_ms=km[4], n_select_bin=kn[4], finish_launch_ms=km[5], n_finish=kn[5],
+                    select_gemm_launch_ms=km[6], n_select_gemm=kn[6], update_small_launch_ms=km[7], n_update_small=kn[7])
 
     def save_state(self):
         """the handle's whole state as one uint8 array (kb_save_state): feed it to load_state of a handle of the same

@@ -256,7 +256,8 @@ def test_run_to_run_determinism_full_size(scenario):
 
 @pytest.mark.parametrize('knobs', [{'RANSLICE_SNAKE': '0'}, {'RANSLICE_SNAKE_MASK': '0x16', 'RANSLICE_SNAKE_ROT': '0x08'},
                                    {'RANSLICE_KEY_W': '16,8,4,32'}, {'RANSLICE_ORDER': '0'}, {'RANSLICE_PAIR': '128'},
-                                   {'RANSLICE_MIXED': '16'}, {'RANSLICE_MIXED': '4', 'RANSLICE_MIXED_UE': '4'}])
+                                   {'RANSLICE_MIXED': '16'}, {'RANSLICE_MIXED': '4', 'RANSLICE_MIXED_UE': '4'},
+                                   {'RANSLICE_MIXED_LIGHT': '96'}, {'RANSLICE_MIXED': '32', 'RANSLICE_MIXED_LIGHT': '128'}])
 def test_results_do_not_depend_on_the_task_order(monkeypatch, knobs):
     """The launch order of the step tasks (cost key, heavy-led waves, serpentine dealing of the rounds: csrc/rs_order.hip) only
     decides which lanes simulate which (replica, slice): the same 4096-replica run with the order's knobs set differently
@@ -265,7 +266,7 @@ def test_results_do_not_depend_on_the_task_order(monkeypatch, knobs):
     hs = []
     for setting in ({}, knobs):
         for k in ('RANSLICE_SNAKE', 'RANSLICE_SNAKE_MASK', 'RANSLICE_SNAKE_ROT', 'RANSLICE_KEY_W', 'RANSLICE_ORDER', 'RANSLICE_PAIR',
-                  'RANSLICE_MIXED', 'RANSLICE_MIXED_UE'):
+                  'RANSLICE_MIXED', 'RANSLICE_MIXED_UE', 'RANSLICE_MIXED_LIGHT'):
             monkeypatch.delenv(k, raising=False)
         # the first run is the production library, the second the test build (the only one that reads the knobs)
         monkeypatch.setenv('RANSLICE_DEV_BUILD', '1' if setting else '0')

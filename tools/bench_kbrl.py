@@ -28,6 +28,9 @@ def main():
     ap.add_argument('--capacity', type=int, default=4096)
     ap.add_argument('--pool-gb', type=float, default=64.0)
     ap.add_argument('--profile', default='sos', help='synthetic trace profile: sos | tdl')
+    ap.add_argument('--save-state', default='', help='after the warm-up: write the environment and agent checkpoints to this directory and exit')
+    ap.add_argument('--load-state', default='', help='instead of the warm-up: restore the checkpoints of --save-state (same --envs / --capacity / '
+                                                     '--pool-gb / --profile): profilers then see the late point of learning only')
     ap.add_argument('--random', action='store_true',
                     help="no agent: the on-device random script drives the same environment (the step kernel's workload beside the agent's)")
     args = ap.parse_args()
@@ -54,8 +57,20 @@ def main():
             else:
                 agent.step_resident(env)
             env.step_resident()
-    run(args.warmup)
+    if args.load_state:
+        env.load_state(np.load(os.path.join(args.load_state, 'env.npy'), mmap_mode='r'))
+        agent.load_state(np.load(os.path.join(args.load_state, 'agent.npy'), mmap_mode='r'))
+    elif args.random:
+        run(args.warmup)
+    else:
+        agent.run_resident(env, args.warmup, graph=True)   # (the graph-replayed loop: same results, a third faster to get there)
     env.synchronize(); agent.synchronize()
+    if args.save_state:
+        os.makedirs(args.save_state, exist_ok=True)
+        np.save(os.path.join(args.save_state, 'env.npy'), env.save_state())
+        np.save(os.path.join(args.save_state, 'agent.npy'), agent.save_state())
+        print(json.dumps({'saved': args.save_state, 'after_steps': args.warmup, 'dictionary_size_mean': float(agent.dictionary_sizes().mean())}))
+        return
     s0 = agent.stats()
     w0 = agent.repair_work()
     c0 = env.counters()
@@ -100,6 +115,8 @@ def main():
         'action_per_slice_p10_p50_p90_max': [float(np.percentile(out['actions'], q)) for q in (10, 50, 90, 100)],
         'step_workload_per_env_step': {'fading_samples': per(0), 'pf_iterations': per(2), 'ue_slots': per(3)},
         'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
+        'per_step_ms': {k2: ph[k2 + '_launch_ms'] * ph['n_' + k2] / args.steps for k2 in ('matvec', 'rank1', 'finish', 'update_small', 'select_bin', 'select_gemm')},
+        'select_bin_GBs': (float(sizes.sum()) * 108.0 / (ph['select_bin_launch_ms'] * 1e-3) / 1e9) if ph['select_bin_launch_ms'] else None,
         'kinv_streaming': {'heavy_matvec_kernel': roof('matvec', 'matvec_launch_ms', 'n_matvec'), 'heavy_rank1_kernel': roof('rank1', 'rank1_launch_ms', 'n_rank1')},
         'direct_passes_per_step': (w1['direct_passes'] - w0['direct_passes']) / args.steps,
         'direct_landmarks_per_step': (w1['direct_landmarks'] - w0['direct_landmarks']) / args.steps,

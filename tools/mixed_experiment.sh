@@ -1,6 +1,8 @@
 #!/bin/bash
-# the split step (8-lane instance for the tasks that fit it, the head of the cost ranking on the 16-lane instance one
-# task per wave beside it) against the 16-lane step, same command, test build.  usage: bash tools/mixed_experiment.sh <tag>
+# the split step against the 16-lane step, same command, test build.  The cost ranking is dealt out to up to
+# three launches side by side: its head one task per 16-lane wave (RANSLICE_MIXED = n: the first 1/n), its light end eight tasks per
+# 8-lane wave (RANSLICE_MIXED_LIGHT = l: the last l/256), the middle four per 16-lane wave as without a split.
+# usage: bash tools/mixed_experiment.sh <tag>
 TAG=${1:-r05_mix}
 OUT=gpurun_out/${TAG}_mixed.txt
 mkdir -p gpurun_out
@@ -12,14 +14,19 @@ run() {  # label, envs-per-gpu, env assignments...
 }
 echo "# $(date) split-step experiment (kernel_ms = HIP events around the step launches of one step)" > $OUT
 python -m pytest tests/test_gpu_fullsize.py -q -x -k "task_order" 2>&1 | tail -2 | tee -a $OUT
-for n in 4096 16384; do
-  run base $n A=0
-  run mixed16 $n RANSLICE_MIXED=16
-  run mixed32 $n RANSLICE_MIXED=32
-  run mixed8 $n RANSLICE_MIXED=8
-  run mixed16_ue7 $n RANSLICE_MIXED=16 RANSLICE_MIXED_UE=7
-  run mixed64 $n RANSLICE_MIXED=64
+run base 4096 A=0
+for l in 32 64 96 128 160; do
+  run light$l 4096 RANSLICE_MIXED_LIGHT=$l
 done
-run base 65536 A=0
-run mixed16 65536 RANSLICE_MIXED=16
-run mixed32 65536 RANSLICE_MIXED=32
+run head64_light64 4096 RANSLICE_MIXED=64 RANSLICE_MIXED_LIGHT=64
+run head32_light128 4096 RANSLICE_MIXED=32 RANSLICE_MIXED_LIGHT=128
+run base 8192 A=0
+run light128 8192 RANSLICE_MIXED_LIGHT=128
+run light192 8192 RANSLICE_MIXED_LIGHT=192
+run head32 8192 RANSLICE_MIXED=32
+run head32_light192 8192 RANSLICE_MIXED=32 RANSLICE_MIXED_LIGHT=192
+run base 16384 A=0
+run head32 16384 RANSLICE_MIXED=32
+run head24 16384 RANSLICE_MIXED=24
+run head32_light192 16384 RANSLICE_MIXED=32 RANSLICE_MIXED_LIGHT=192
+run light224 16384 RANSLICE_MIXED_LIGHT=224
