@@ -20,7 +20,12 @@ DB=$(find /tmp/kt_${TAG} -name '*.db' | head -1)
   python $GRAFT_REPO_ROOT/tools/rocpd_summary.py $DB --last 200 --steps 200 --anchor kb::adjust_kernel
 } > $OUT/${TAG}_kbrl_late_kernel_trace.txt
 grep -A24 'the last 200 steps' $OUT/${TAG}_kbrl_late_kernel_trace.txt | head -28
-[ -n "$KONLY" ] && exit 0   # KONLY=1: the kernel trace only
+# where the step kernel's cycles go under the agents' allocations (s_memtime marks of the -DRS_SECTION_PROFILE build: make profile)
+if [ -f $GRAFT_REPO_ROOT/network-slicing_amd/csrc/build/libranslice_prof.so ]; then
+  ( cd $GRAFT_REPO_ROOT && RANSLICE_LIB=network-slicing_amd/csrc/build/libranslice_prof.so timeout 600 python tools/section_profile.py --load-state $ST --traces $PROF > $OUT/${TAG}_late_sections.txt 2>&1 )
+  head -24 $OUT/${TAG}_late_sections.txt
+fi
+[ -n "$KONLY" ] && { rm -rf $ST; exit 0; }   # KONLY=1: the kernel trace and the section profile only
 PCMD="python tools/bench_kbrl.py --profile $PROF --load-state $ST --steps 12"
 echo "# rocprofv3 --pmc passes (one counter group per run) of: $PCMD ; means per launch over the last launches of each kb:: kernel (steps $LATE.. of learning)" > $OUT/${TAG}_kbrl_late_pmc.txt
 i=0

@@ -13,9 +13,24 @@ from ranslice.vec_env import VecRanSlice  # noqa: E402
 
 N = int(os.environ.get('PROFILE_ENVS', '4096'))
 KBRL = '--kbrl' in sys.argv  # drive the env with one KBRL agent per replica instead of random actions
-env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
-env.reset()
-if KBRL:
+# --load-state DIR [--traces tdl|sos]: the closed loop from a checkpoint of tools/bench_kbrl.py --save-state (the late point of learning)
+LOAD = sys.argv[sys.argv.index('--load-state') + 1] if '--load-state' in sys.argv else ''
+TRACES = sys.argv[sys.argv.index('--traces') + 1] if '--traces' in sys.argv else 'sos'
+if LOAD:
+    import numpy as np
+    from ranslice.fading import synth_traces
+    from ranslice.kbrl_dev import VecKBRL
+    KBRL = True
+    env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=synth_traces(10000, TRACES))
+    agent = VecKBRL(N, [10] * 5, 200, accuracy_range=(0.99, 0.999), capacity=4096, pool_bytes=64 << 30)
+    env.reset()
+    agent.reset(np.full((N, 5), 10, np.int32), np.full((N, 5), 3, np.int32))
+    env.load_state(np.load(os.path.join(LOAD, 'env.npy'), mmap_mode='r'))
+    agent.load_state(np.load(os.path.join(LOAD, 'agent.npy'), mmap_mode='r'))
+else:
+    env = VecRanSlice(n_envs=N, cfg=make_config(0, n_envs=N), fading=[synth_fading(t, 10000) for t in range(3)])
+    env.reset()
+if KBRL and not LOAD:
     env.set_schedule_hint(1)  # what kb_step_resident selects: the BLOCK instance
     import numpy as np
     from ranslice.kbrl_dev import VecKBRL
@@ -34,7 +49,7 @@ def advance(i):
     env.step_resident()
 
 
-for i in range(300 if KBRL else 1000):
+for i in range(20 if LOAD else (300 if KBRL else 1000)):
     advance(i)
 env.synchronize()
 a = (C.c_uint64 * 16)()
