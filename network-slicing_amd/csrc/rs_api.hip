@@ -577,6 +577,12 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         if (const char* e = dev_env("RANSLICE_SNAKE_MASK")) h->snake_mask = (int)strtol(e, nullptr, 0);
         if (const char* e = dev_env("RANSLICE_SNAKE_ROT")) h->rot_mask = (int)strtol(e, nullptr, 0);
     }
+    // The split step pays where the batch is several rounds of waves -- the launch is then bound by the instructions issued, and
+    // eight like tasks per wave issue a sixth fewer than four -- and loses where every wave is resident at once and the launch ends
+    // with its slowest wave, whose chain eight tasks in lockstep lengthen (round 5, 4096 / 8192 / 16384 / 65536 replicas: step
+    // kernel 1.08 -> 1.19-1.31 ms, 1.98 -> 1.95, 3.55 -> 2.96, 13.2 -> 11.5 with a head; profiles/r05_c_mixed.txt).  From 12,288
+    // replicas of five slices on: the lightest 7/8 of the ranking on the 8-lane instance.
+    if (h->group == 16 && h->n_tasks >= 61440) h->mixed_light = 224;
     if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_LIGHT")) h->mixed_light = atoi(e);
