@@ -598,6 +598,10 @@ def main():
     ap.add_argument('--graph', action='store_true',
                     help='replay the timed loop from a captured hipGraph (rs_run_random); the kernel time for the '
                          'roofline is then taken from a separate event-timed pass of 100 steps')
+    ap.add_argument('--state-file', default='',
+                    help='profiling aid: if the file exists the burn-in is replaced by restoring the environments from it (rs_load_state), '
+                         'otherwise it is written after the burn-in -- counter passes of rocprofv3 (20 ms per dispatch) then run at the '
+                         'population of the timed run without repeating 3500 burn-in steps each')
     ap.add_argument('--cpu-steps', type=int, default=3000)
     ap.add_argument('--cpu-baseline-json', default=None, help=argparse.SUPPRESS)
     ap.add_argument('--scaling', default='', help='e.g. 1,2,4,8: run every N in turn and print ONE line with the curve and '
@@ -674,7 +678,13 @@ def main():
 
     # ---- burn-in to the stationary UE population
     burn_hist = []
-    if args.burn_in >= 0:
+    state_file = args.state_file + ('.rank%d' % rank if world > 1 else '') if args.state_file else ''
+    if state_file and os.path.exists(state_file + '.npz'):
+        z = np.load(state_file + '.npz')
+        env.load_state(z['env'])
+        step_idx = int(z['step_idx'])
+        burn_hist = [float(x) for x in z['burn_hist']]
+    elif args.burn_in >= 0:
         run(args.burn_in)
     else:
         prev = None
@@ -688,6 +698,9 @@ def main():
             if done:
                 break
     burn_steps = step_idx
+    if state_file and not os.path.exists(state_file + '.npz'):
+        env.synchronize()
+        np.savez(state_file, env=env.save_state(), step_idx=np.int64(step_idx), burn_hist=np.asarray(burn_hist, dtype=np.float64))
     run(args.warmup)
     env.synchronize()
     c0 = env.counters()

@@ -476,18 +476,49 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // many take it -- their (coeff, last coordinate, D0) are listed in dlist, in increasing j, the first KB_DLIST of them (a state
 // far from everything the dictionary holds leaves a handful of landmarks in the band where E_j is 1e-300 .. 5e-324: common
 // enough -- thousands of learners per step in BASELINE config 3 -- that walking the rows a second time for them showed).
+#ifndef KB_BIN_DEPTH
+#define KB_BIN_DEPTH 2  // chunks of landmark rows a wave of bin_pass has requested ahead of the one it works on
+#endif
+// the pool offsets of a dictionary's first 64 shells, one per lane, in ONE coalesced load: the address of chunk b's page then
+// comes out of a register (readlane) and the rows of the next chunks are requested without a dependent pointer load per chunk
+// (round 5: a wave of select_bin_kernel lived 28 us for 3.3 chunks -- a chain of dependent loads, 76 % of its cycles waiting)
+__device__ __forceinline__ uint64_t shell_vector(const KbDev& D, const uint64_t* sh) {
+    const int lane = threadIdx.x & 63;
+    return lane < D.max_shells ? sh[lane] : 0ull;
+}
+__device__ __forceinline__ double* page_of(const KbState& K, const uint64_t* sh, uint64_t shv, int b) {
+#ifdef KB_BIN_NO_SHV  // (experiment builds: the pointer load per chunk, as until round 5)
+    return vec_page(K, sh, b);
+#endif
+    if (b >= 64) return vec_page(K, sh, b);  // (dictionaries beyond 4,096 landmarks: the pointer load)
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)shv, b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(shv >> 32), b);
+    return K.pool + (((uint64_t)hi << 32) | lo);
+}
+
 template <int MODE>
 __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
-                                         double* W, double* dlist) {
+                                         double* W, double* dlist, uint64_t shv) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
     int flags = 0, ndir = 0;
     ChunkRows<MODE> R, Rn;
-    load_chunk<MODE>(vec_page(K, sh, 0), lane, d, Rn);
+#if KB_BIN_DEPTH >= 2
+    ChunkRows<MODE> Rnn;
+    load_chunk<MODE>(page_of(K, sh, shv, 0), lane, d, Rn);
+    if (nch > 1) load_chunk<MODE>(page_of(K, sh, shv, 1), lane, d, Rnn);
+#else
+    load_chunk<MODE>(page_of(K, sh, shv, 0), lane, d, Rn);
+#endif
     for (int b = 0; b < nch; ++b) {
-        double* P = vec_page(K, sh, b);
+        double* P = page_of(K, sh, shv, b);
         R = Rn;
-        if (b + 1 < nch) load_chunk<MODE>(vec_page(K, sh, b + 1), lane, d, Rn);
+#if KB_BIN_DEPTH >= 2
+        Rn = Rnn;
+        if (b + 2 < nch) load_chunk<MODE>(page_of(K, sh, shv, b + 2), lane, d, Rnn);
+#else
+        if (b + 1 < nch) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
+#endif
         const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
         double E, d0 = 0.0;
         if (MODE == 1) {
@@ -635,7 +666,7 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.dl);
+        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.dl, shell_vector(D, sh));
         chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
         if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, direct, (const double*)sm.dl, f);
     }
@@ -1193,7 +1224,7 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (threadIdx.x < 64) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.dl);
+            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.dl, shell_vector(D, sh));
             if (lane == 0) sm.ired[4] = direct;
         }
         __syncthreads();
@@ -1504,7 +1535,10 @@ __device__ __forceinline__ int stretch_of(const long long* base, int count, long
     return a;
 }
 
-__global__ __launch_bounds__(256) void heavy_matvec_kernel(KbDev D, KbState K) {
+#ifndef KB_MV_OCC
+#define KB_MV_OCC 4  // waves per SIMD heavy_matvec_kernel is built for (102 registers unconstrained: four)
+#endif
+__global__ __launch_bounds__(256, KB_MV_OCC) void heavy_matvec_kernel(KbDev D, KbState K) {
     const int count = K.heavy[0];
     if (count == 0) return;
     if (blockIdx.x == 0 && threadIdx.x == 0 && K.hv_mvbase[count] > 0) {  // (the roofline's byte count: kb_get_repair_work)
@@ -1803,7 +1837,10 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 //                       accepted candidate, in order, exact ties drawing (kernel.py:26-27).
 // Per learner: one pass over the landmarks plus 208 x 204 multiply-adds on the matrix pipe, whatever m is.  Round 3 walked
 // every landmark for every group of 64 candidates, here and again in update_control.
-__global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
+#ifndef KB_BIN_OCC
+#define KB_BIN_OCC KB_OCC
+#endif
+__global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ double W[256];
@@ -1814,8 +1851,10 @@ __global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
     const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1;
     const int dict = dict_of(D, task);
-    const int m = K.m[dict];
     const int lane = threadIdx.x;
+    const uint64_t* sh = shells_of(D, K, dict);
+    const uint64_t shv = shell_vector(D, sh);  // (requested together with m: one round trip, not two)
+    const int m = K.m[dict];
     if (A.big_par >= 0 && lane == 0) {  // the next step's list (the other of the two)
         const int pw = 1 - A.big_par;
         int listed = 0;
@@ -1837,7 +1876,7 @@ __global__ __launch_bounds__(64, KB_OCC) void select_bin_kernel(SelArgs A) {
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const int direct = bin_pass<0>(D, K, shells_of(D, K, dict), m, d, x, W, K.dlist + (size_t)task * (KB_DLIST * 3));
+    const int direct = bin_pass<0>(D, K, sh, m, d, x, W, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
     __syncthreads();
     double* Wg = K.Wg + (size_t)task * 256;
 #pragma unroll
