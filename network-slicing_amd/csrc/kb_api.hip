@@ -584,7 +584,12 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
         const unsigned slots = (unsigned)k->T + (a.big_par >= 0 ? KB_BIG_MAX : 0);
         hipEvent_t eb, eg;
         if ((rc = kb_time_begin(k, &eb, 4)) != RS_OK) return rc;
-        hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a);
+        if (a.big_par >= 0) {  // the listed large learners several waves each, the others a wave each
+            hipLaunchKernelGGL(kb::select_bin_big_kernel, dim3(KB_BIG_MAX), dim3(64 * KB_BINBIG_WAVES), 0, k->stream, a);
+            hipLaunchKernelGGL(kb::select_bin_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a, (int)KB_BIG_MAX);
+        } else {
+            hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a, 0);
+        }
         if (eb) HIPCHK(k, hipEventRecord(eb, k->stream));
         if ((rc = kb_time_begin(k, &eg, 6)) != RS_OK) return rc;
         hipLaunchKernelGGL(kb::select_gemm_kernel, dim3((slots + KB_SEL_WAVES - 1) / KB_SEL_WAVES), dim3(256), 0, k->stream, a);

@@ -215,6 +215,7 @@ struct Lds {
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
     double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned)
+    double Wseg[256];  //   the segment in progress of a dictionary of more than KB_BIN_SEG chunks (bin_pass)
     double dl[KB_DLIST * 3];  //   and the (coeff, last coordinate, D0) of the landmarks that take the direct evaluation (bin_pass)
     int ired[8];
 };
@@ -477,7 +478,7 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // far from everything the dictionary holds leaves a handful of landmarks in the band where E_j is 1e-300 .. 5e-324: common
 // enough -- thousands of learners per step in BASELINE config 3 -- that walking the rows a second time for them showed).
 #ifndef KB_BIN_DEPTH
-#define KB_BIN_DEPTH 2  // chunks of landmark rows a wave of bin_pass has requested ahead of the one it works on
+#define KB_BIN_DEPTH 1  // chunks of landmark rows a wave of bin_pass has requested ahead of the one it works on
 #endif
 // the pool offsets of a dictionary's first 64 shells, one per lane, in ONE coalesced load: the address of chunk b's page then
 // comes out of a register (readlane) and the rows of the next chunks are requested without a dependent pointer load per chunk
@@ -496,28 +497,29 @@ __device__ __forceinline__ double* page_of(const KbState& K, const uint64_t* sh,
     return K.pool + (((uint64_t)hi << 32) | lo);
 }
 
+// chunks [b0, b1) of the dictionary, by ONE wave, into Wacc (LDS, 256 doubles, zeroed by the caller); the landmarks that take
+// the direct evaluation are listed from position `pos0` of dlist on.  Returns flags | (how many of them) << 8.
 template <int MODE>
-__device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
-                                         double* W, double* dlist, uint64_t shv) {
+__device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, const uint64_t* sh, uint64_t shv, int m, int d, const double* x,
+                                           int b0, int b1, double* Wacc, double* dlist, int pos0) {
     const int lane = threadIdx.x & 63;
-    const int nch = (m + 63) >> 6;
     int flags = 0, ndir = 0;
     ChunkRows<MODE> R, Rn;
 #if KB_BIN_DEPTH >= 2
     ChunkRows<MODE> Rnn;
-    load_chunk<MODE>(page_of(K, sh, shv, 0), lane, d, Rn);
-    if (nch > 1) load_chunk<MODE>(page_of(K, sh, shv, 1), lane, d, Rnn);
+    load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
+    if (b0 + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + 1), lane, d, Rnn);
 #else
-    load_chunk<MODE>(page_of(K, sh, shv, 0), lane, d, Rn);
+    load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
 #endif
-    for (int b = 0; b < nch; ++b) {
+    for (int b = b0; b < b1; ++b) {
         double* P = page_of(K, sh, shv, b);
         R = Rn;
 #if KB_BIN_DEPTH >= 2
         Rn = Rnn;
-        if (b + 2 < nch) load_chunk<MODE>(page_of(K, sh, shv, b + 2), lane, d, Rnn);
+        if (b + 2 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 2), lane, d, Rnn);
 #else
-        if (b + 1 < nch) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
+        if (b + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
 #endif
         const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
         double E, d0 = 0.0;
@@ -542,7 +544,7 @@ __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const 
         const unsigned long long dmask = __ballot(direct);
         if (dmask) {
             flags |= 1 | (__ballot(offg) != 0ull ? 2 : 0);
-            const int pos = ndir + __builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+            const int pos = pos0 + ndir + __builtin_popcountll(dmask & ((1ull << lane) - 1ull));
             if (direct && pos < KB_DLIST) {
                 dlist[3 * pos] = R.co;
                 dlist[3 * pos + 1] = P[(d - 1) * KB_CH + lane];
@@ -551,7 +553,33 @@ __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const 
             ndir += __builtin_popcountll(dmask);
         }
         const double w = R.co * E;
-        if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(W + R.a, w);  // ds_add_f64
+        if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(Wacc + R.a, w);  // ds_add_f64
+    }
+    return flags | (ndir << 8);
+}
+
+// The whole dictionary by ONE wave.  The order of W[a]'s sum is fixed for every kernel: the landmarks of a SEGMENT of
+// KB_BIN_SEG chunks add up in increasing j (as above), and the segments' sums are added in increasing order, starting from
+// zero -- W[a] = ((0 + S_0[a]) + S_1[a]) + ... .  A dictionary of at most one segment (256 landmarks) is summed exactly as
+// until round 5; a larger one can be walked by several waves at once, a segment each (select_bin_big_kernel), and comes out
+// with the same bits as from this one wave.  Wseg: 256 doubles of LDS scratch (used beyond one segment).
+#define KB_BIN_SEG 4
+template <int MODE>
+__device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
+                                         double* W, double* Wseg, double* dlist, uint64_t shv) {
+    const int lane = threadIdx.x & 63;
+    const int nch = (m + 63) >> 6;
+    if (nch <= KB_BIN_SEG) return bin_chunks<MODE>(D, K, sh, shv, m, d, x, 0, nch, W, dlist, 0);
+    int flags = 0, ndir = 0;
+    for (int b0 = 0; b0 < nch; b0 += KB_BIN_SEG) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Wseg[lane + 64 * k] = 0.0;
+        const int b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
+        const int r = bin_chunks<MODE>(D, K, sh, shv, m, d, x, b0, b1, Wseg, dlist, ndir);
+        flags |= r & 3;
+        ndir += r >> 8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) W[lane + 64 * k] += Wseg[lane + 64 * k];  // (the LDS executes a wave's instructions in order)
     }
     return flags | (ndir << 8);
 }
@@ -666,7 +694,7 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.dl, shell_vector(D, sh));
+        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.Wseg, sm.dl, shell_vector(D, sh));
         chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
         if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, direct, (const double*)sm.dl, f);
     }
@@ -1224,7 +1252,7 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (threadIdx.x < 64) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.dl, shell_vector(D, sh));
+            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.Wseg, sm.dl, shell_vector(D, sh));
             if (lane == 0) sm.ired[4] = direct;
         }
         __syncthreads();
@@ -1840,13 +1868,102 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 #ifndef KB_BIN_OCC
 #define KB_BIN_OCC KB_OCC
 #endif
-__global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A) {
+// the next step's list of large learners (the other of the two): who is on it is decided by whoever bins the learner
+__device__ __forceinline__ void note_big(const KbState& K, int T, int big_par, int task, int m) {
+    const int pw = 1 - big_par;
+    int listed = 0;
+    if (m >= KB_BIG_M) {
+        int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
+        const int slot = atomicAdd(&L[0], 1);
+        if (slot < KB_BIG_MAX) {
+            L[1 + slot] = task;
+            listed = 1;
+        }
+    }
+    K.isbig[(size_t)pw * T + task] = listed;
+}
+
+// The learners of the large-learner list, a workgroup of KB_BINBIG_WAVES waves each: wave w bins segments w, w + waves, ... of
+// the dictionary (KB_BIN_SEG chunks each) into its own LDS array, and the segments' sums are added up in increasing order after
+// every round -- the order bin_pass keeps on one wave, so both give the same bits.  One wave walking a dictionary of 1,645
+// landmarks chunk after chunk was select_bin_kernel's whole duration at step 3000 of config 3 (26 chunks x 7.6 us: round 5,
+// tools/stamps_probe.sh); its mean learner has 3.5 chunks.
+#define KB_BINBIG_WAVES 8
+__global__ __launch_bounds__(64 * KB_BINBIG_WAVES) void select_bin_big_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ double W[256];
+    __shared__ double Ws[KB_BINBIG_WAVES][256];
+    __shared__ double dls[KB_BINBIG_WAVES][KB_DLIST * 3];
+    __shared__ double x[KB_DMAX];
+    __shared__ int res[KB_BINBIG_WAVES];
+    const int T = D.n_envs * D.S;
+    const int task = learner_of_slot(K, T, A.big_par, (int)blockIdx.x);  // (slots below KB_BIG_MAX: the list)
+    if (task < 0) return;
+    const int env = task / D.S, s = task - env * D.S;
+    const int d = D.dims[s] + 1;
+    const int dict = dict_of(D, task);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint64_t* sh = shells_of(D, K, dict);
+    const uint64_t shv = shell_vector(D, sh);
+    const int m = K.m[dict];
+    if (threadIdx.x == 0) note_big(K, T, A.big_par, task, m);
+    if (m < 2) {
+        if (threadIdx.x == 0) K.fdirect[task] = 0;
+        return;
+    }
+    if (threadIdx.x < 256) W[threadIdx.x] = 0.0;
+    if (threadIdx.x < d - 1) x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
+    __syncthreads();
+    const int nch = (m + 63) >> 6, nseg = (nch + KB_BIN_SEG - 1) / KB_BIN_SEG;
+    double* dlist = K.dlist + (size_t)task * (KB_DLIST * 3);
+    int flags = 0, ndir = 0;
+    for (int s0 = 0; s0 < nseg; s0 += KB_BINBIG_WAVES) {
+        const int sg = s0 + wv;
+        int r = 0;
+        if (sg < nseg) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) Ws[wv][lane + 64 * k] = 0.0;
+            const int b0 = sg * KB_BIN_SEG, b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
+            r = bin_chunks<0>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
+        }
+        if (lane == 0) res[wv] = r;
+        __syncthreads();
+        const int here = nseg - s0 < KB_BINBIG_WAVES ? nseg - s0 : KB_BINBIG_WAVES;
+        if (threadIdx.x < 256) {  // the segments of this round, in order
+            double acc = W[threadIdx.x];
+            for (int q = 0; q < here; ++q) acc += Ws[q][threadIdx.x];
+            W[threadIdx.x] = acc;
+        }
+        // the direct-evaluation lists of the round's segments, in order, behind what earlier rounds listed (all threads walk the
+        // same counts; the first KB_DLIST entries overall are kept, as bin_pass keeps them)
+        for (int q = 0; q < here; ++q) {
+            const int rq = res[q], nq = rq >> 8;
+            flags |= rq & 3;
+            const int keep = nq < KB_DLIST ? nq : KB_DLIST;
+            for (int e = threadIdx.x; e < 3 * keep; e += blockDim.x)
+                if (ndir + e / 3 < KB_DLIST) dlist[3 * ndir + e] = dls[q][e];
+            ndir += nq;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 256) K.Wg[(size_t)task * 256 + threadIdx.x] = W[threadIdx.x];
+    if (threadIdx.x == 0) K.fdirect[task] = flags | (ndir << 8);
+}
+
+// every other learner (and, on a handle without the list, every learner): a wave each.  slot0: KB_BIG_MAX when the list's
+// places are select_bin_big_kernel's, else 0
+__global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, int slot0) {
+    const KbDev& D = A.D;
+    const KbState& K = A.K;
+    __shared__ double W[256];
+    __shared__ double Wseg[256];
     __shared__ double x[KB_DMAX];
     const int T = D.n_envs * D.S;
-    const int task = learner_of_block(K, T, A.big_par);
+#ifdef KB_BIN_STAMPS  // experiment build: where a wave's time goes (every 16th wave adds its s_memtime differences to hv_work[4..7])
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+#endif
+    const int task = learner_of_slot(K, T, A.big_par, slot0 + (int)blockIdx.x);
     if (task < 0) return;
     const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1;
@@ -1855,19 +1972,11 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A) {
     const uint64_t* sh = shells_of(D, K, dict);
     const uint64_t shv = shell_vector(D, sh);  // (requested together with m: one round trip, not two)
     const int m = K.m[dict];
-    if (A.big_par >= 0 && lane == 0) {  // the next step's list (the other of the two)
-        const int pw = 1 - A.big_par;
-        int listed = 0;
-        if (m >= KB_BIG_M) {
-            int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
-            const int slot = atomicAdd(&L[0], 1);
-            if (slot < KB_BIG_MAX) {
-                L[1 + slot] = task;
-                listed = 1;
-            }
-        }
-        K.isbig[(size_t)pw * T + task] = listed;
-    }
+#ifdef KB_BIN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime();
+#endif
+    if (A.big_par >= 0 && lane == 0) note_big(K, T, A.big_par, task, m);
     if (m < 2) {  // (nothing to bin: select_gemm_kernel scores the single landmark in float32, kernel.py:16)
         if (lane == 0) K.fdirect[task] = 0;
         return;
@@ -1876,7 +1985,17 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A) {
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const int direct = bin_pass<0>(D, K, sh, m, d, x, W, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
+    const int direct = bin_pass<0>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
+#ifdef KB_BIN_STAMPS
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    const unsigned long long st2 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && (blockIdx.x & 15) == 0) {
+        atomicAdd(&K.hv_work[4], st1 - st0);                        // entry -> task, m, shell offsets known
+        atomicAdd(&K.hv_work[5], st2 - st1);                        // the landmarks (all chunks, stores drained)
+        atomicAdd(&K.hv_work[6], (unsigned long long)((m + 63) >> 6));  // chunks
+        atomicAdd(&K.hv_work[7], 1ull);                             // waves recorded
+    }
+#endif
     __syncthreads();
     double* Wg = K.Wg + (size_t)task * 256;
 #pragma unroll

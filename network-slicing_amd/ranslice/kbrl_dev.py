@@ -191,6 +191,11 @@ class VecKBRL:
         return dict(matvec_bytes=int(w[0]) * (32768 + 1024), rank1_bytes=int(w[1]) * 16384, matvec_launches=int(w[2]),
                     rank1_launches=int(w[3]), direct_passes=int(w[4]), direct_landmarks=int(w[5]))
 
+    def _repair_raw(self):
+        w = (C.c_uint64 * 8)()
+        self._check(self.L.kb_get_repair_work(self.h, w))
+        return list(w)
+
     def set_kernel_timing(self, enable=True):
         self._check(self.L.kb_set_kernel_timing(self.h, int(bool(enable))))
 
