@@ -477,8 +477,8 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // many take it -- their (coeff, last coordinate, D0) are listed in dlist, in increasing j, the first KB_DLIST of them (a state
 // far from everything the dictionary holds leaves a handful of landmarks in the band where E_j is 1e-300 .. 5e-324: common
 // enough -- thousands of learners per step in BASELINE config 3 -- that walking the rows a second time for them showed).
-#ifndef KB_BIN_DEPTH
-#define KB_BIN_DEPTH 1  // chunks of landmark rows a wave of bin_pass has requested ahead of the one it works on
+#ifndef KB_BIN_SEG
+#define KB_BIN_SEG 4  // chunks per segment of a binning pass (below); changes the bits of W for dictionaries beyond a segment
 #endif
 // the pool offsets of a dictionary's first 64 shells, one per lane, in ONE coalesced load: the address of chunk b's page then
 // comes out of a register (readlane) and the rows of the next chunks are requested without a dependent pointer load per chunk
@@ -499,61 +499,75 @@ __device__ __forceinline__ double* page_of(const KbState& K, const uint64_t* sh,
 
 // chunks [b0, b1) of the dictionary, by ONE wave, into Wacc (LDS, 256 doubles, zeroed by the caller); the landmarks that take
 // the direct evaluation are listed from position `pos0` of dlist on.  Returns flags | (how many of them) << 8.
+// one chunk's landmarks: D0 / E (MODE 0: computed and left in the dictionary's rows), the direct-evaluation list, W[a] += coeff_j E_j
 template <int MODE>
+__device__ __forceinline__ void bin_one_chunk(const KbDev& D, const ChunkRows<MODE>& R, double* P, int lane, int cnt, int d, const double* x,
+                                              double* Wacc, double* dlist, int pos0, int& flags, int& ndir) {
+    double E, d0 = 0.0;
+    if (MODE == 1) {
+        E = R.v[0];
+    } else {
+        if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82)
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const double t = R.v[q] - x[q];
+                d0 += t * t;
+            }
+        } else {
+            d0 = dist0(P, lane, d, x);
+        }
+        E = rs_exp_nonpos(-D.gamma * d0);
+        P[KB_ROW_D0 * KB_CH + lane] = d0;
+        P[KB_ROW_E * KB_CH + lane] = E;
+    }
+    const bool offg = lane < cnt && R.a < 0;
+    const bool direct = offg || (lane < cnt && !(E >= KB_E_TINY) && E > 0.0);
+    const unsigned long long dmask = __ballot(direct);
+    if (dmask) {
+        flags |= 1 | (__ballot(offg) != 0ull ? 2 : 0);
+        const int pos = pos0 + ndir + __builtin_popcountll(dmask & ((1ull << lane) - 1ull));
+        if (direct && pos < KB_DLIST) {
+            dlist[3 * pos] = R.co;
+            dlist[3 * pos + 1] = P[(d - 1) * KB_CH + lane];
+            dlist[3 * pos + 2] = MODE == 1 ? P[KB_ROW_D0 * KB_CH + lane] : d0;
+        }
+        ndir += __builtin_popcountll(dmask);
+    }
+    const double w = R.co * E;
+    if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(Wacc + R.a, w);  // ds_add_f64
+}
+
+// DEEP (the two select_bin kernels): the rows of ALL chunks of the segment are requested before the first is used, every chunk
+// in registers of its own (fully unrolled; 160 registers).  With one chunk requested ahead -- the other kernels, whose register
+// budget has no room for four -- the rotation at the end of an iteration waits for the loads issued at its top: a chunk costs a
+// full loaded memory latency (7.6 us at step 3000 of config 3: a wave of select_bin_kernel lived 32 us for 3.5 chunks;
+// tools/stamps_probe.sh and the kernel's ISA, round 5).
+template <int MODE, bool DEEP>
 __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, const uint64_t* sh, uint64_t shv, int m, int d, const double* x,
                                            int b0, int b1, double* Wacc, double* dlist, int pos0) {
     const int lane = threadIdx.x & 63;
     int flags = 0, ndir = 0;
-    ChunkRows<MODE> R, Rn;
-#if KB_BIN_DEPTH >= 2
-    ChunkRows<MODE> Rnn;
-    load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
-    if (b0 + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + 1), lane, d, Rnn);
-#else
-    load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
-#endif
-    for (int b = b0; b < b1; ++b) {
-        double* P = page_of(K, sh, shv, b);
-        R = Rn;
-#if KB_BIN_DEPTH >= 2
-        Rn = Rnn;
-        if (b + 2 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 2), lane, d, Rnn);
-#else
-        if (b + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
-#endif
-        const int cnt = m - 64 * b < 64 ? m - 64 * b : 64;
-        double E, d0 = 0.0;
-        if (MODE == 1) {
-            E = R.v[0];
-        } else {
-            if (d - 1 == 10) {  // eMBB learners (scenario_creator.py:80-82)
+    if (DEEP) {
+        ChunkRows<MODE> Rs[KB_BIN_SEG];
 #pragma unroll
-                for (int q = 0; q < 10; ++q) {
-                    const double t = R.v[q] - x[q];
-                    d0 += t * t;
-                }
-            } else {
-                d0 = dist0(P, lane, d, x);
+        for (int i = 0; i < KB_BIN_SEG; ++i)
+            if (b0 + i < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + i), lane, d, Rs[i]);
+#pragma unroll
+        for (int i = 0; i < KB_BIN_SEG; ++i) {
+            if (b0 + i < b1) {  // (wave-uniform)
+                const int b = b0 + i;
+                bin_one_chunk<MODE>(D, Rs[i], page_of(K, sh, shv, b), lane, m - 64 * b < 64 ? m - 64 * b : 64, d, x, Wacc, dlist, pos0, flags, ndir);
             }
-            E = rs_exp_nonpos(-D.gamma * d0);
-            P[KB_ROW_D0 * KB_CH + lane] = d0;
-            P[KB_ROW_E * KB_CH + lane] = E;
         }
-        const bool offg = lane < cnt && R.a < 0;
-        const bool direct = offg || (lane < cnt && !(E >= KB_E_TINY) && E > 0.0);
-        const unsigned long long dmask = __ballot(direct);
-        if (dmask) {
-            flags |= 1 | (__ballot(offg) != 0ull ? 2 : 0);
-            const int pos = pos0 + ndir + __builtin_popcountll(dmask & ((1ull << lane) - 1ull));
-            if (direct && pos < KB_DLIST) {
-                dlist[3 * pos] = R.co;
-                dlist[3 * pos + 1] = P[(d - 1) * KB_CH + lane];
-                dlist[3 * pos + 2] = MODE == 1 ? P[KB_ROW_D0 * KB_CH + lane] : d0;
-            }
-            ndir += __builtin_popcountll(dmask);
+    } else {
+        ChunkRows<MODE> R, Rn;
+        load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
+        for (int b = b0; b < b1; ++b) {
+            double* P = page_of(K, sh, shv, b);
+            R = Rn;
+            if (b + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
+            bin_one_chunk<MODE>(D, R, P, lane, m - 64 * b < 64 ? m - 64 * b : 64, d, x, Wacc, dlist, pos0, flags, ndir);
         }
-        const double w = R.co * E;
-        if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(Wacc + R.a, w);  // ds_add_f64
     }
     return flags | (ndir << 8);
 }
@@ -563,19 +577,18 @@ __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, cons
 // zero -- W[a] = ((0 + S_0[a]) + S_1[a]) + ... .  A dictionary of at most one segment (256 landmarks) is summed exactly as
 // until round 5; a larger one can be walked by several waves at once, a segment each (select_bin_big_kernel), and comes out
 // with the same bits as from this one wave.  Wseg: 256 doubles of LDS scratch (used beyond one segment).
-#define KB_BIN_SEG 4
-template <int MODE>
+template <int MODE, bool DEEP = false>
 __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
                                          double* W, double* Wseg, double* dlist, uint64_t shv) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
-    if (nch <= KB_BIN_SEG) return bin_chunks<MODE>(D, K, sh, shv, m, d, x, 0, nch, W, dlist, 0);
+    if (nch <= KB_BIN_SEG) return bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, 0, nch, W, dlist, 0);
     int flags = 0, ndir = 0;
     for (int b0 = 0; b0 < nch; b0 += KB_BIN_SEG) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) Wseg[lane + 64 * k] = 0.0;
         const int b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
-        const int r = bin_chunks<MODE>(D, K, sh, shv, m, d, x, b0, b1, Wseg, dlist, ndir);
+        const int r = bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, b0, b1, Wseg, dlist, ndir);
         flags |= r & 3;
         ndir += r >> 8;
 #pragma unroll
@@ -1866,7 +1879,7 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 // Per learner: one pass over the landmarks plus 208 x 204 multiply-adds on the matrix pipe, whatever m is.  Round 3 walked
 // every landmark for every group of 64 candidates, here and again in update_control.
 #ifndef KB_BIN_OCC
-#define KB_BIN_OCC KB_OCC
+#define KB_BIN_OCC 3  // (four chunks of rows in flight per wave: 162 registers)
 #endif
 // the next step's list of large learners (the other of the two): who is on it is decided by whoever bins the learner
 __device__ __forceinline__ void note_big(const KbState& K, int T, int big_par, int task, int m) {
@@ -1925,7 +1938,7 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES) void select_bin_big_kernel(Se
 #pragma unroll
             for (int k = 0; k < 4; ++k) Ws[wv][lane + 64 * k] = 0.0;
             const int b0 = sg * KB_BIN_SEG, b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
-            r = bin_chunks<0>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
+            r = bin_chunks<0, true>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
         }
         if (lane == 0) res[wv] = r;
         __syncthreads();
@@ -1985,7 +1998,7 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, i
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const int direct = bin_pass<0>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
+    const int direct = bin_pass<0, true>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
 #ifdef KB_BIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();

@@ -511,7 +511,7 @@ def test_load_state_refuses_torn_blobs_and_accepts_another_pool_size(golden_dir)
     ag.reset(np.full((N, 5), 10, np.int32), np.full((N, 5), 3, np.int32))
     x, y = g['d11_x'], g['d11_y']
     for i in range(700):     # learner (0, 0) grows past its first shell of 64 landmarks; the others take a few samples each
-        e, sl = (0, 0) if i < 600 else (i % N, 1 + i % 4)
+        e, sl = (0, 0) if i < 600 else (i % N, i % 5)      # (every one of the 20 dictionaries takes its first shell)
         yp, f = ag.predict(e, sl, x[i])
         ag.update(e, sl, x[i], int(y[i]))
     assert ag.learner(0, 0)['m'] > 64
