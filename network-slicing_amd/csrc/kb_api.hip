@@ -587,6 +587,7 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
         if (a.big_par >= 0) {  // the listed large learners several waves each, the others a wave each
             hipLaunchKernelGGL(kb::select_bin_big_kernel, dim3(KB_BIG_MAX), dim3(64 * KB_BINBIG_WAVES), 0, k->stream, a);
             hipLaunchKernelGGL(kb::select_bin_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a, (int)KB_BIG_MAX);
+            hipLaunchKernelGGL(kb::big_list_kernel, dim3((unsigned)((k->T + 255) / 256)), dim3(256), 0, k->stream, k->D, k->K, a.big_par);
         } else {
             hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a, 0);
         }

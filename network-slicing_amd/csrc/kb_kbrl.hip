@@ -477,6 +477,10 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 // many take it -- their (coeff, last coordinate, D0) are listed in dlist, in increasing j, the first KB_DLIST of them (a state
 // far from everything the dictionary holds leaves a handful of landmarks in the band where E_j is 1e-300 .. 5e-324: common
 // enough -- thousands of learners per step in BASELINE config 3 -- that walking the rows a second time for them showed).
+#ifndef KB_BIN_DEEP
+#define KB_BIN_DEEP 0  // chunks whose rows a wave of the select_bin kernels requests together (0: one ahead, rotating registers;
+                       // 2 and 4 measured no faster: profiles/r05_kbrl_variants.txt)
+#endif
 #ifndef KB_BIN_SEG
 #define KB_BIN_SEG 4  // chunks per segment of a binning pass (below); changes the bits of W for dictionaries beyond a segment
 #endif
@@ -488,9 +492,6 @@ __device__ __forceinline__ uint64_t shell_vector(const KbDev& D, const uint64_t*
     return lane < D.max_shells ? sh[lane] : 0ull;
 }
 __device__ __forceinline__ double* page_of(const KbState& K, const uint64_t* sh, uint64_t shv, int b) {
-#ifdef KB_BIN_NO_SHV  // (experiment builds: the pointer load per chunk, as until round 5)
-    return vec_page(K, sh, b);
-#endif
     if (b >= 64) return vec_page(K, sh, b);  // (dictionaries beyond 4,096 landmarks: the pointer load)
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)shv, b);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(shv >> 32), b);
@@ -537,26 +538,33 @@ __device__ __forceinline__ void bin_one_chunk(const KbDev& D, const ChunkRows<MO
     if (lane < cnt && !direct && R.a >= 0 && w != 0.0) unsafeAtomicAdd(Wacc + R.a, w);  // ds_add_f64
 }
 
-// DEEP (the two select_bin kernels): the rows of ALL chunks of the segment are requested before the first is used, every chunk
-// in registers of its own (fully unrolled; 160 registers).  With one chunk requested ahead -- the other kernels, whose register
-// budget has no room for four -- the rotation at the end of an iteration waits for the loads issued at its top: a chunk costs a
-// full loaded memory latency (7.6 us at step 3000 of config 3: a wave of select_bin_kernel lived 32 us for 3.5 chunks;
-// tools/stamps_probe.sh and the kernel's ISA, round 5).
-template <int MODE, bool DEEP>
+// DEEP > 0: the rows of DEEP chunks are requested together, every chunk in registers of its own (fully unrolled).  DEEP = 0: one
+// chunk requested ahead in rotating registers -- the rotation at the end of an iteration waits for the loads issued at its top, so
+// a chunk costs a full loaded memory latency (7.6 us at step 3000 of config 3: a wave of select_bin_kernel lived 32 us for 3.5
+// chunks; tools/stamps_probe.sh, the kernel's ISA).  Round 5 measured both on the select_bin kernels: DEEP = 2 (128 registers) and
+// 4 (168, three waves per SIMD) are no faster than 0 (profiles/r05_kbrl_variants.txt), so 0 stays everywhere.
+template <int MODE, int DEEP>
 __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, const uint64_t* sh, uint64_t shv, int m, int d, const double* x,
                                            int b0, int b1, double* Wacc, double* dlist, int pos0) {
     const int lane = threadIdx.x & 63;
     int flags = 0, ndir = 0;
-    if (DEEP) {
-        ChunkRows<MODE> Rs[KB_BIN_SEG];
+    if (DEEP > 0) {  // DEEP chunks' rows requested together, in registers of their own; the segment in groups of DEEP
+        static_assert(DEEP == 0 || KB_BIN_SEG % (DEEP ? DEEP : 1) == 0, "groups tile the segment");
 #pragma unroll
-        for (int i = 0; i < KB_BIN_SEG; ++i)
-            if (b0 + i < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + i), lane, d, Rs[i]);
+        for (int g0 = 0; g0 < KB_BIN_SEG; g0 += (DEEP ? DEEP : 1)) {
+            if (b0 + g0 < b1) {
+                ChunkRows<MODE> Rs[DEEP ? DEEP : 1];
 #pragma unroll
-        for (int i = 0; i < KB_BIN_SEG; ++i) {
-            if (b0 + i < b1) {  // (wave-uniform)
-                const int b = b0 + i;
-                bin_one_chunk<MODE>(D, Rs[i], page_of(K, sh, shv, b), lane, m - 64 * b < 64 ? m - 64 * b : 64, d, x, Wacc, dlist, pos0, flags, ndir);
+                for (int i = 0; i < DEEP; ++i)
+                    if (b0 + g0 + i < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + g0 + i), lane, d, Rs[i]);
+#pragma unroll
+                for (int i = 0; i < DEEP; ++i) {
+                    if (b0 + g0 + i < b1) {  // (wave-uniform)
+                        const int b = b0 + g0 + i;
+                        bin_one_chunk<MODE>(D, Rs[i], page_of(K, sh, shv, b), lane, m - 64 * b < 64 ? m - 64 * b : 64, d, x, Wacc, dlist, pos0, flags,
+                                            ndir);
+                    }
+                }
             }
         }
     } else {
@@ -577,7 +585,7 @@ __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, cons
 // zero -- W[a] = ((0 + S_0[a]) + S_1[a]) + ... .  A dictionary of at most one segment (256 landmarks) is summed exactly as
 // until round 5; a larger one can be walked by several waves at once, a segment each (select_bin_big_kernel), and comes out
 // with the same bits as from this one wave.  Wseg: 256 doubles of LDS scratch (used beyond one segment).
-template <int MODE, bool DEEP = false>
+template <int MODE, int DEEP = 0>
 __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
                                          double* W, double* Wseg, double* dlist, uint64_t shv) {
     const int lane = threadIdx.x & 63;
@@ -1879,21 +1887,32 @@ __global__ __launch_bounds__(64, KB_OCC) void select_kernel(SelArgs A) {
 // Per learner: one pass over the landmarks plus 208 x 204 multiply-adds on the matrix pipe, whatever m is.  Round 3 walked
 // every landmark for every group of 64 candidates, here and again in update_control.
 #ifndef KB_BIN_OCC
-#define KB_BIN_OCC 3  // (four chunks of rows in flight per wave: 162 registers)
+#define KB_BIN_OCC 4
 #endif
-// the next step's list of large learners (the other of the two): who is on it is decided by whoever bins the learner
-__device__ __forceinline__ void note_big(const KbState& K, int T, int big_par, int task, int m) {
-    const int pw = 1 - big_par;
-    int listed = 0;
-    if (m >= KB_BIG_M) {
-        int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
-        const int slot = atomicAdd(&L[0], 1);
-        if (slot < KB_BIG_MAX) {
-            L[1 + slot] = task;
-            listed = 1;
-        }
+// The next step's list of large learners (the other of the two) and who is on it, from the dictionary sizes: a workgroup counts
+// its large learners and reserves their places with ONE atomic.  Until round 5 every wave of select_bin_kernel took its place
+// itself -- some 4,000 returning atomics on one address per launch at step 3000 of config 3, served one after the other by
+// one L2 channel: THE duration of that kernel (0.2 ms where its memory traffic takes 0.1; tools/ubench/scatter_read.hip).
+__global__ __launch_bounds__(256) void big_list_kernel(KbDev D, KbState K, int big_par) {
+    __shared__ int wcount[4], base;
+    const int T = D.n_envs * D.S, pw = 1 - big_par;
+    const int task = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool big = task < T && K.m[dict_of(D, task)] >= KB_BIG_M;
+    const unsigned long long mask = __ballot(big);
+    if (lane == 0) wcount[wv] = __builtin_popcountll(mask);
+    __syncthreads();
+    int32_t* L = K.big + (size_t)pw * (1 + KB_BIG_MAX);
+    if (threadIdx.x == 0) {
+        const int tot = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        base = tot ? atomicAdd(&L[0], tot) : 0;
     }
-    K.isbig[(size_t)pw * T + task] = listed;
+    __syncthreads();
+    int pos = base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+    for (int q = 0; q < wv; ++q) pos += wcount[q];
+    const int listed = big && pos < KB_BIG_MAX ? 1 : 0;
+    if (listed) L[1 + pos] = task;
+    if (task < T) K.isbig[(size_t)pw * T + task] = listed;
 }
 
 // The learners of the large-learner list, a workgroup of KB_BINBIG_WAVES waves each: wave w bins segments w, w + waves, ... of
@@ -1901,8 +1920,10 @@ __device__ __forceinline__ void note_big(const KbState& K, int T, int big_par, i
 // every round -- the order bin_pass keeps on one wave, so both give the same bits.  One wave walking a dictionary of 1,645
 // landmarks chunk after chunk was select_bin_kernel's whole duration at step 3000 of config 3 (26 chunks x 7.6 us: round 5,
 // tools/stamps_probe.sh); its mean learner has 3.5 chunks.
-#define KB_BINBIG_WAVES 8
-__global__ __launch_bounds__(64 * KB_BINBIG_WAVES) void select_bin_big_kernel(SelArgs A) {
+#ifndef KB_BINBIG_WAVES
+#define KB_BINBIG_WAVES 4
+#endif
+__global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_big_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
     __shared__ double W[256];
@@ -1920,7 +1941,6 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES) void select_bin_big_kernel(Se
     const uint64_t* sh = shells_of(D, K, dict);
     const uint64_t shv = shell_vector(D, sh);
     const int m = K.m[dict];
-    if (threadIdx.x == 0) note_big(K, T, A.big_par, task, m);
     if (m < 2) {
         if (threadIdx.x == 0) K.fdirect[task] = 0;
         return;
@@ -1938,7 +1958,7 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES) void select_bin_big_kernel(Se
 #pragma unroll
             for (int k = 0; k < 4; ++k) Ws[wv][lane + 64 * k] = 0.0;
             const int b0 = sg * KB_BIN_SEG, b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
-            r = bin_chunks<0, true>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
+            r = bin_chunks<0, KB_BIN_DEEP>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
         }
         if (lane == 0) res[wv] = r;
         __syncthreads();
@@ -1989,7 +2009,6 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, i
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st1 = __builtin_amdgcn_s_memtime();
 #endif
-    if (A.big_par >= 0 && lane == 0) note_big(K, T, A.big_par, task, m);
     if (m < 2) {  // (nothing to bin: select_gemm_kernel scores the single landmark in float32, kernel.py:16)
         if (lane == 0) K.fdirect[task] = 0;
         return;
@@ -1998,7 +2017,7 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, i
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     __syncthreads();
-    const int direct = bin_pass<0, true>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
+    const int direct = bin_pass<0, KB_BIN_DEEP>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
 #ifdef KB_BIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();
