@@ -9,6 +9,10 @@ struct kb_handle {
     hipStream_t stream = nullptr;
     hipEvent_t ev_order = nullptr;  // orders the agent's stream against the simulator's (kb_step_resident)
     hipEvent_t ev_join = nullptr;   // kb_run_resident: the agent's stream waits for the graph launches on the simulator's
+    // The repairs of the small dictionaries (update_small_kernel: a workgroup per learner, latency-bound) run on a side stream BESIDE
+    // the chip-wide rounds of the large ones (they touch different learners; the pool's allocator and the error flags are atomics)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_sfork = nullptr, ev_sjoin = nullptr;
     kb::KbDev D;
     kb::KbState K;
     std::vector<void*> allocs;
@@ -234,6 +238,11 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     }
     HIPCHK(k, hipSetDevice(device));
     HIPCHK(k, hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking));
+    if (!cfg->shared_dictionary && !(dev_env("KBRL_SIDE_STREAM") && atoi(dev_env("KBRL_SIDE_STREAM")) == 0)) {
+        HIPCHK(k, hipStreamCreateWithFlags(&k->side, hipStreamNonBlocking));
+        HIPCHK(k, hipEventCreateWithFlags(&k->ev_sfork, hipEventDisableTiming));
+        HIPCHK(k, hipEventCreateWithFlags(&k->ev_sjoin, hipEventDisableTiming));
+    }
     kb::KbDev& D = k->D;
     memset(&D, 0, sizeof D);
     D.n_envs = cfg->n_envs;
@@ -408,6 +417,10 @@ extern "C" void kb_destroy(kb_handle* k) {
     }
     if (k->ev_order) (void)hipEventDestroy(k->ev_order);
     if (k->ev_join) (void)hipEventDestroy(k->ev_join);
+    if (k->side) (void)hipStreamSynchronize(k->side);
+    if (k->side) (void)hipStreamDestroy(k->side);
+    if (k->ev_sfork) (void)hipEventDestroy(k->ev_sfork);
+    if (k->ev_sjoin) (void)hipEventDestroy(k->ev_sjoin);
     kb_comm_release(k);
     if (k->d_gather) (void)hipFree(k->d_gather);
     kb_history_release(k);
@@ -534,9 +547,16 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
         // the learners with a mistake to repair: small dictionaries one wave each, all at once; large ones a workgroup
         // each, taken by persistent workgroups
         const unsigned blocks = (unsigned)(k->T < k->heavy_blocks ? k->T : k->heavy_blocks);
+        // (with per-kernel event timing on, everything stays on the one stream: the account is per kernel, not per overlap)
+        const bool forked = k->side != nullptr && !k->timing;
         hipEvent_t es;
         if ((rc = kb_time_begin(k, &es, 7)) != RS_OK) return rc;
-        hipLaunchKernelGGL(kb::update_small_kernel, dim3((unsigned)(k->T < 4096 ? k->T : 4096)), dim3(256), 0, k->stream, a);
+        if (forked) {
+            HIPCHK(k, hipEventRecord(k->ev_sfork, k->stream));
+            HIPCHK(k, hipStreamWaitEvent(k->side, k->ev_sfork, 0));
+        }
+        hipLaunchKernelGGL(kb::update_small_kernel, dim3((unsigned)(k->T < 4096 ? k->T : 4096)), dim3(256), 0, forked ? k->side : k->stream, a);
+        if (forked) HIPCHK(k, hipEventRecord(k->ev_sjoin, k->side));
         if (es) HIPCHK(k, hipEventRecord(es, k->stream));
         // The rounds are nine launches that do nothing while no dictionary is large (early in learning): they are
         // enqueued only once a recent step has queued a few large learners.  The host reads that count from pinned memory
@@ -559,6 +579,7 @@ static int launch_update_control(kb_handle* k, const float* d_state, const int32
             if (er) HIPCHK(k, hipEventRecord(er, k->stream));
         }
         hipLaunchKernelGGL(kb::update_heavy_kernel, dim3(blocks), dim3(KB_HEAVY_THREADS), 0, k->stream, a);
+        if (forked) HIPCHK(k, hipStreamWaitEvent(k->stream, k->ev_sjoin, 0));
         hipLaunchKernelGGL(kb::heavy_reset_kernel, dim3(1), dim3(1), 0, k->stream, k->K, (volatile int32_t*)k->h_seen);
     }
     if (e1) HIPCHK(k, hipEventRecord(e1, k->stream));  // the whole update phase
