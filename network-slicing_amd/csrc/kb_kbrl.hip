@@ -1923,6 +1923,7 @@ __global__ __launch_bounds__(256) void big_list_kernel(KbDev D, KbState K, int b
 #ifndef KB_BINBIG_WAVES
 #define KB_BINBIG_WAVES 4
 #endif
+#define KB_BINBIG_GRID 1024
 __global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_big_kernel(SelArgs A) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
@@ -1932,8 +1933,11 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_b
     __shared__ double x[KB_DMAX];
     __shared__ int res[KB_BINBIG_WAVES];
     const int T = D.n_envs * D.S;
-    const int task = learner_of_slot(K, T, A.big_par, (int)blockIdx.x);  // (slots below KB_BIG_MAX: the list)
-    if (task < 0) return;
+    // KB_BINBIG_GRID workgroups walk the list (an empty list costs a thousand workgroups that leave at once, not four thousand)
+    for (int slot = (int)blockIdx.x; slot < KB_BIG_MAX; slot += KB_BINBIG_GRID) {
+    const int task = learner_of_slot(K, T, A.big_par, slot);  // (slots below KB_BIG_MAX: the list)
+    if (task < 0) return;  // (the list is dense from its start: nothing further on either)
+    __syncthreads();       // (the previous learner's LDS is done with)
     const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1;
     const int dict = dict_of(D, task);
@@ -1943,7 +1947,7 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_b
     const int m = K.m[dict];
     if (m < 2) {
         if (threadIdx.x == 0) K.fdirect[task] = 0;
-        return;
+        continue;
     }
     if (threadIdx.x < 256) W[threadIdx.x] = 0.0;
     if (threadIdx.x < d - 1) x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
@@ -1982,6 +1986,7 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_b
     }
     if (threadIdx.x < 256) K.Wg[(size_t)task * 256 + threadIdx.x] = W[threadIdx.x];
     if (threadIdx.x == 0) K.fdirect[task] = flags | (ndir << 8);
+    }
 }
 
 // every other learner (and, on a handle without the list, every learner): a wave each.  slot0: KB_BIG_MAX when the list's
