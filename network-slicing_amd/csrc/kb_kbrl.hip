@@ -214,8 +214,8 @@ struct Lds {
     double x[KB_DMAX];
     double red[16];
     double fbuf[256];  // the scores of the 256 candidates, handed from wave 0 to the other waves of a multi-wave block
-    double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned)
-    double Wseg[256];  //   the segment in progress of a dictionary of more than KB_BIN_SEG chunks (bin_pass)
+    double W[256];     // binned scoring: W[a] = sum of coeff_j E_j over the landmarks with grid index a (score_binned); the segment in
+                       //   progress of a dictionary of more than KB_BIN_SEG chunks borrows fbuf (never live during a binning pass)
     double dl[KB_DLIST * 3];  //   and the (coeff, last coordinate, D0) of the landmarks that take the direct evaluation (bin_pass)
     int ired[8];
 };
@@ -715,7 +715,7 @@ __device__ __forceinline__ void score_binned(const KbDev& D, const KbState& K, c
         const int lane = threadIdx.x & 63;
 #pragma unroll
         for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.Wseg, sm.dl, shell_vector(D, sh));
+        const int direct = bin_pass<MODE>(D, K, sh, m, d, sm.x, sm.W, sm.fbuf, sm.dl, shell_vector(D, sh));
         chain_scores<NG>(D, sm.G2, sm.W, c_base, ng, f);
         if (direct) add_direct_terms<NG>(D, K, sh, m, d, c_base, ng, direct, (const double*)sm.dl, f);
     }
@@ -1310,7 +1310,7 @@ __device__ __forceinline__ void rescore(const KbDev& D, const KbState& K, const 
         if (threadIdx.x < 64) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) ((volatile double*)sm.W)[lane + 64 * k] = 0.0;
-            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.Wseg, sm.dl, shell_vector(D, sh));
+            const int direct = bin_pass<1>(D, K, sh, m, d, sm.x, sm.W, sm.fbuf, sm.dl, shell_vector(D, sh));
             if (lane == 0) sm.ired[4] = direct;
         }
         __syncthreads();
