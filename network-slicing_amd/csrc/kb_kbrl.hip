@@ -888,13 +888,8 @@ __device__ __forceinline__ double* tri_part(const KbState& K, const uint64_t* sh
     return K.pool + sh[bi] + KB_VEC + (size_t)(bi + 1) * KB_TILE + (size_t)bj * 128;
 }
 
-// `slab` (optional): 8 x KB_SLAB_LD doubles of LDS per WAVE.  With it TWO slabs of eight rows are requested together and the
-// row-wise operand is read back out of LDS (the wave's own transposing copy of the slab) instead of a second time from memory:
-// twice the bytes in flight per wave at the same registers (round 5: the kernel moves one loaded memory latency per slab, and a
-// wave held 4 KB in flight).  Same products, same sums, same order: same bits as without.
-#define KB_SLAB_LD 72  // doubles between the rows of the LDS copy (64 + 8: the row-wise reads of eight rows spread over the banks)
 __device__ __forceinline__ void matvec_tri_tiles(const KbState& K, const uint64_t* sh, int m, int t0, int tstride,
-                                                 int t_end = 0x7fffffff, double* slab = nullptr) {
+                                                 int t_end = 0x7fffffff) {
     const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
     const int cl = lane >> 3, sg = lane & 7;
     const int nt = nb * (nb + 1) / 2;
@@ -912,8 +907,15 @@ __device__ __forceinline__ void matvec_tri_tiles(const KbState& K, const uint64_
         double acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-        // one slab: the column sums' step and (off-diagonal tiles) the row sums of its eight rows
-        auto slab_step = [&](int x, const double (&v)[8], const double (&tv)[8]) {
+        for (int x = 0; x < 8; ++x) {
+            if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
+            double v[8], tv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
+            if (off) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) tv[k] = Tp[(8 * x + cl) * 64 + sg + 8 * k];
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u)
                 if (8 * x + u < rows) acc[u] = __builtin_fma(v[u], readlane_f64(kfr, 8 * x + u), acc[u]);
@@ -926,46 +928,70 @@ __device__ __forceinline__ void matvec_tri_tiles(const KbState& K, const uint64_
                 ta += __shfl_xor(ta, 4);
                 if (sg == 0) part[64 + 8 * x + cl] = ta;
             }
-        };
-        if (slab) {
-            auto through_lds = [&](const double (&v)[8], double (&tv)[8]) {  // tv[k] = T[8 x + cl][sg + 8 k] out of the wave's copy
+        }
+        part[lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
+}
+
+// The same tiles for heavy_matvec_kernel, whose waves do nothing else: TWO slabs of eight rows are requested together and the
+// row-wise operand is read back out of LDS (`slab`: 8 x KB_SLAB_LD doubles per WAVE, the wave's own copy of the slab) instead of a
+// second time from memory -- twice the bytes in flight per wave at four waves per SIMD (round 5: the kernel moves one loaded
+// memory latency per slab and a wave held 4 KB in flight; 0.24 -> 0.21 ms per step at step 3000 of config 3).  Same products,
+// same sums, same order as above: same bits (rows past the dictionary's end contribute zeros here, whatever the tile holds
+// there above: those partial sums are never read).  A function of its own: as one function with a flag the per-learner
+// kernels that use the version above spilled 608 B per lane.
+#define KB_SLAB_LD 72  // doubles between the rows of the LDS copy (64 + 8: the row-wise reads of eight rows spread over the banks)
+__device__ __forceinline__ void matvec_tri_tiles_lds(const KbState& K, const uint64_t* sh, int m, int t0, int t_end, double* slab) {
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
+    const int cl = lane >> 3, sg = lane & 7;
+    const int nt = nb * (nb + 1) / 2;
+    for (int t = t0; t < nt && t < t_end; ++t) {
+        int bi, bj;
+        tri_tile_of(t, &bi, &bj);
+        const double* Tp = kinv_tile_lo(K, sh, bi, bj);
+        const int rows = m - 64 * bi < 64 ? m - 64 * bi : 64;
+        const bool off = bi != bj;
+        const double kfr = vec_page(K, sh, bi)[KB_ROW_KF * KB_CH + lane];
+        double kc[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) slab[u * KB_SLAB_LD + lane] = v[u];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int k = 0; k < 8; ++k) kc[k] = off ? vec_page(K, sh, bj)[KB_ROW_KF * KB_CH + sg + 8 * k] : 0.0;
+        double* part = tri_part(K, sh, bi, bj);
+        double acc[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tv[k] = slab[cl * KB_SLAB_LD + sg + 8 * k];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // (read before the next slab overwrites it)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            };
-            for (int x = 0; x < 8; x += 2) {
-                if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
-                const bool two = 8 * (x + 1) < rows;
-                double v0[8], v1[8], tv[8];
+        for (int u = 0; u < 8; ++u) acc[u] = 0.0;
+        for (int x = 0; x < 8; x += 2) {
+            if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
+            const bool two = 8 * (x + 1) < rows;
+            double v[2][8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v0[u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
+            for (int u = 0; u < 8; ++u) v[0][u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) v1[u] = (two && 8 * (x + 1) + u < rows) ? Tp[(8 * (x + 1) + u) * 64 + lane] : 0.0;
+            for (int u = 0; u < 8; ++u) v[1][u] = (two && 8 * (x + 1) + u < rows) ? Tp[(8 * (x + 1) + u) * 64 + lane] : 0.0;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) tv[k] = 0.0;
-                if (off) through_lds(v0, tv);
-                slab_step(x, v0, tv);
-                if (two) {
-                    if (off) through_lds(v1, tv);
-                    slab_step(x + 1, v1, tv);
+            for (int h = 0; h < 2; ++h) {
+                if (h == 0 || two) {
+                    const int xs = x + h;
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (8 * xs + u < rows) acc[u] = __builtin_fma(v[h][u], readlane_f64(kfr, 8 * xs + u), acc[u]);
+                    if (off) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) slab[u * KB_SLAB_LD + lane] = v[h][u];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        double ta = 0.0;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) ta = __builtin_fma(slab[cl * KB_SLAB_LD + sg + 8 * k], kc[k], ta);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();  // (read before the next slab overwrites it)
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        ta += __shfl_xor(ta, 1);
+                        ta += __shfl_xor(ta, 2);
+                        ta += __shfl_xor(ta, 4);
+                        if (sg == 0) part[64 + 8 * xs + cl] = ta;
+                    }
                 }
-            }
-        } else {
-            for (int x = 0; x < 8; ++x) {
-                if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
-                double v[8], tv[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
-#pragma unroll
-                for (int k = 0; k < 8; ++k) tv[k] = off ? Tp[(8 * x + cl) * 64 + sg + 8 * k] : 0.0;
-                slab_step(x, v, tv);
             }
         }
         part[lane] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
@@ -1646,7 +1672,10 @@ __global__ __launch_bounds__(256, KB_MV_OCC) void heavy_matvec_kernel(KbDev D, K
         const long long nb = (m + 63) >> 6;
         const long long a = lo > sb ? lo - sb : 0, b = (hi < se ? hi : se) - sb;
         if (D.tri) {  // the work line counts tiles
-            if (a < b) matvec_tri_tiles(K, shells_of(D, K, dict), m, (int)a, 1, (int)b, KB_MV_LDS ? slabs[threadIdx.x >> 6] : nullptr);
+            if (a < b) {
+                if (KB_MV_LDS) matvec_tri_tiles_lds(K, shells_of(D, K, dict), m, (int)a, (int)b, slabs[threadIdx.x >> 6]);
+                else matvec_tri_tiles(K, shells_of(D, K, dict), m, (int)a, 1, (int)b);
+            }
         } else {      // units whose first pass lies in [lo, hi)
             const int u0 = (int)((a + nb - 1) / nb), u1 = (int)((b + nb - 1) / nb);
             if (u0 < u1) matvec_partials<1>(K, shells_of(D, K, dict), m, u0, 1, u1);
