@@ -43,6 +43,40 @@ def digest(agent):
     return h.hexdigest(), sizes
 
 
+def resident_loop(agent, rank, world, n, steps, device):
+    """the closed loop on the device (kb_shared_step_resident, max_rounds rounds, no round count asked for): the last round's failure
+    mark is looked at by the NEXT call, so the host never waits for the device inside the loop.  Environments: scenario_0 replicas
+    [rank * n, (rank + 1) * n) of one batch.  FAIL_RANK / FAIL_STEP: that rank's round fails locally (it reports at once); the other
+    ranks must leave at their next call."""
+    import ctypes as C
+    from ranslice.config import make_config
+    from ranslice.fading import synth_fading
+    from ranslice.sharding import replica_seeds
+    from ranslice.vec_env import VecRanSlice
+    env = VecRanSlice(n_envs=n, cfg=make_config(0, n_envs=n), fading=[synth_fading(t, 2000) for t in range(3)], device=device)
+    env.reset(seeds=replica_seeds(0, rank * n, n))
+    a0 = np.full((n, 5), 20, np.int32)
+    env._check(env.L.rs_step(env.h, a0.ctypes.data_as(C.POINTER(C.c_int32)), None, None, None, None))
+    fail_rank, fail_step = int(os.environ.get('FAIL_RANK', '-1')), int(os.environ.get('FAIL_STEP', '-1'))
+    for i in range(steps):
+        if rank == fail_rank and i == fail_step:
+            os.environ['KBRL_INJECT_FAIL_ROUND'] = str(agent.max_rounds - 1)   # the LAST permitted round of this step
+        try:
+            agent.step_resident(env)
+        except _lib.RanSliceError as e:
+            print('FAILED %d step %d: %s' % (rank, i, e), flush=True)
+            agent.close()
+            sys.exit(3)
+        env.step_resident()
+    env.synchronize()
+    agent.synchronize()
+    d, sizes = digest(agent)
+    acts = env.fetch()['actions']
+    print('RESULT %d %s %s %s device=%d' % (rank, d, sizes, hashlib.sha256(acts.tobytes()).hexdigest(), device), flush=True)
+    agent.close()
+    env.close()
+
+
 def main():
     rank, world, id_file, n, steps = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), int(sys.argv[5])
     ia, sf, seq = batch(n * world, steps)
@@ -68,6 +102,9 @@ def main():
                 uid = f.read()
         agent.comm_init(uid, rank, world)
     agent.reset(ia[lo:hi], sf[lo:hi])
+    if os.environ.get('RESIDENT'):
+        resident_loop(agent, rank, world, n, steps, device)
+        return
     acts = []
     fail_rank, fail_step = int(os.environ.get('FAIL_RANK', '-1')), int(os.environ.get('FAIL_STEP', '-1'))
     abort_step = int(os.environ.get('ABORT_STEP', '-1'))
