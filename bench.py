@@ -593,7 +593,7 @@ def main():
     ap.add_argument('--kbrl-steps', type=int, default=200)
     ap.add_argument('--kbrl-sos', action='store_true', help="config 3 also on the fixtures' trace profile (full record only)")
     ap.add_argument('--shared-steps', type=int, default=200)
-    ap.add_argument('--shared-warmup', type=int, default=30)
+    ap.add_argument('--shared-warmup', type=int, default=100)
     ap.add_argument('--shared-leg', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--graph', action='store_true',
                     help='replay the timed loop from a captured hipGraph (rs_run_random); the kernel time for the '

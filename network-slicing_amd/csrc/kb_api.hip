@@ -45,12 +45,6 @@ struct kb_handle {
     int comm_rank = 0, comm_world = 1;
     bool comm_aborted = false;     // the communicator was aborted: shared steps refuse until kb_comm_init forms a new one
     int32_t* h_total = nullptr;    // pinned: the per-round (proposals left, failure mark) pair of the shared step
-    // The last permitted round of a resident shared step decides nothing but "did any rank fail": its pair is read back at the START of
-    // the next shared step (or by kb_synchronize), so the host does not wait for the device once per step -- every rank looks at the
-    // same merged mark at the same point of the same step, and all of them leave together, one call later.
-    int32_t* h_late = nullptr;     // pinned: that round's pair
-    hipEvent_t ev_late = nullptr;  // recorded behind its copy
-    bool late_pending = false;
     int budget_cap = 256;
     int heavy_blocks = 256;
     int mv_grid = 2048, r1_grid = 2048;  // one co-resident round of workgroups of the two Kinv-streaming kernels (kb_create)
@@ -170,7 +164,6 @@ static void kb_comm_abort(kb_handle* k) {
     if (k->comm && rccl::CommAbort) (void)rccl::CommAbort(k->comm);
     k->comm = nullptr;
     k->comm_aborted = true;
-    k->late_pending = false;
 }
 
 /* 128 bytes for kb_comm_init, generated by ONE rank (ncclGetUniqueId) and handed to the others by the launcher */
@@ -436,8 +429,6 @@ extern "C" void kb_destroy(kb_handle* k) {
     kb_history_release(k);
     if (k->h_seen) (void)hipHostFree(k->h_seen);
     if (k->h_total) (void)hipHostFree(k->h_total);
-    if (k->h_late) (void)hipHostFree(k->h_late);
-    if (k->ev_late) (void)hipEventDestroy(k->ev_late);
     if (k->stream) (void)hipStreamDestroy(k->stream);
     delete k;
 }
@@ -1085,16 +1076,11 @@ extern "C" int kb_kernel_time_ms(kb_handle* k, double* avg_ms, int64_t* launches
     return RS_OK;
 }
 
-static int shared_resolve_late(kb_handle* k);
 // Waits for the agent's stream and reports a dictionary overflow raised by any kernel since kb_reset -- the resident
 // loop (kb_step_resident) never reads the flag itself, so this is where a device-driven run learns about it.
 extern "C" int kb_synchronize(kb_handle* k) {
     if (!k) return RS_EINVAL;
     HIPCHK(k, hipSetDevice(k->device));
-    {
-        const int lrc = shared_resolve_late(k);  // (a failure mark of the last resident shared step surfaces here at the latest)
-        if (lrc != RS_OK) return lrc;
-    }
     HIPCHK(k, hipStreamSynchronize(k->stream));
     return kb_check(k);
 }
@@ -1194,17 +1180,16 @@ extern "C" int kb_shared_commit(kb_handle* k, const int32_t* n_accept) {
 // for an asynchronous error (a peer that died: ncclCommGetAsyncError) and a clock runs (KBRL_COLLECTIVE_TIMEOUT_S, default
 // 120 s); either one aborts the communicator (ncclCommAbort) and returns RS_EHIP instead of leaving the rank in the
 // collective for an outside watchdog to find.
-static int shared_wait(kb_handle* k, hipEvent_t ev = nullptr) {  // ev: wait for this event instead of the whole stream
+static int shared_wait(kb_handle* k) {
     if (!k->comm) {
-        if (ev) HIPCHK(k, hipEventSynchronize(ev));
-        else HIPCHK(k, hipStreamSynchronize(k->stream));
+        HIPCHK(k, hipStreamSynchronize(k->stream));
         return RS_OK;
     }
     static const double limit = getenv("KBRL_COLLECTIVE_TIMEOUT_S") ? atof(getenv("KBRL_COLLECTIVE_TIMEOUT_S")) : 120.0;
     const auto t0 = std::chrono::steady_clock::now();
     const bool inject = dev_env("KBRL_INJECT_TIMEOUT") != nullptr;  // test build: as if the peers never answered
     for (;;) {
-        const hipError_t q = inject ? hipErrorNotReady : (ev ? hipEventQuery(ev) : hipStreamQuery(k->stream));
+        const hipError_t q = inject ? hipErrorNotReady : hipStreamQuery(k->stream);
         if (q == hipSuccess) return RS_OK;
         const char* why = nullptr;
         int async_err = 0;
@@ -1223,30 +1208,12 @@ static int shared_wait(kb_handle* k, hipEvent_t ev = nullptr) {  // ev: wait for
     }
 }
 
-// the pair of the previous resident step's last round, if it was left pending (kb_handle::late_pending)
-static int shared_resolve_late(kb_handle* k) {
-    if (!k->late_pending) return RS_OK;
-    k->late_pending = false;
-    const int wrc = shared_wait(k, k->ev_late);
-    if (wrc != RS_OK) return wrc;
-    if (((volatile int32_t*)k->h_late)[1] != 0) {
-        k->err = "kb_shared_step: a rank of the shared-dictionary group reported a failure in the last round of the previous step; "
-                 "all ranks leave at this call";
-        return RS_EHIP;
-    }
-    return RS_OK;
-}
-
 // the rounds of one shared learning step on device buffers (state / action / labels of the local replicas)
 static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d_action, const int32_t* d_labels, int32_t budget,
                             int32_t max_rounds, int32_t* hits_host, int32_t* rounds_out) {
     if (k->comm_aborted) {  // not a one-rank world: its dictionaries would silently diverge from the group's
         k->err = "kb_shared_step: the communicator of this handle was aborted; join a new one with kb_comm_init";
         return RS_ESTATE;
-    }
-    {
-        const int lrc = shared_resolve_late(k);
-        if (lrc != RS_OK) return lrc;
     }
     const size_t T = (size_t)k->T, S = (size_t)k->cfg.n_slices;
     const int W = k->comm ? k->comm_world : 1, me = k->comm ? k->comm_rank : 0;
@@ -1315,16 +1282,6 @@ static int shared_step_core(kb_handle* k, const float* d_state, const int32_t* d
         // the last permitted round decides nothing: a single-rank handle whose caller does not ask for the count does not wait
         // for it (with other ranks in the step the failure flag is read after every round, so that all leave together)
         if (rnd + 1 == max_rounds && !rounds_out && !k->comm && local_err.empty()) break;
-        if (rnd + 1 == max_rounds && !rounds_out && !hits_host && k->comm && local_err.empty()) {
-            // with other ranks in the step the mark is still looked at -- by the next call (shared_resolve_late), not by a wait here
-            if (!k->h_late) HIPCHK(k, hipHostMalloc((void**)&k->h_late, 2 * sizeof(int32_t), hipHostMallocDefault));
-            if (!k->ev_late) HIPCHK(k, hipEventCreateWithFlags(&k->ev_late, hipEventDisableTiming));
-            k->h_late[0] = k->h_late[1] = 0;
-            HIPCHK(k, hipMemcpyAsync(k->h_late, k->d_total, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, k->stream));
-            HIPCHK(k, hipEventRecord(k->ev_late, k->stream));
-            k->late_pending = true;
-            break;
-        }
         // The pair comes back through PINNED memory: a device-to-host copy into pageable memory blocks the calling thread until
         // the stream reaches it -- behind an all-gather a silent peer never completes -- and the bounded wait below would never run.
         if (!k->h_total) HIPCHK(k, hipHostMalloc((void**)&k->h_total, 2 * sizeof(int32_t), hipHostMallocDefault));

@@ -45,9 +45,9 @@ def digest(agent):
 
 def resident_loop(agent, rank, world, n, steps, device):
     """the closed loop on the device (kb_shared_step_resident, max_rounds rounds, no round count asked for): the last round's failure
-    mark is looked at by the NEXT call, so the host never waits for the device inside the loop.  Environments: scenario_0 replicas
+    mark comes back once per step.  Environments: scenario_0 replicas
     [rank * n, (rank + 1) * n) of one batch.  FAIL_RANK / FAIL_STEP: that rank's round fails locally (it reports at once); the other
-    ranks must leave at their next call."""
+    ranks must leave at the same step."""
     import ctypes as C
     from ranslice.config import make_config
     from ranslice.fading import synth_fading

@@ -405,11 +405,12 @@ def test_silent_peer_ends_in_a_timeout_not_a_hang(tmp_path):
     assert time.time() - t0 < 120
 
 
-def test_resident_loop_through_rccl_does_not_wait_per_step(tmp_path):
-    """kb_shared_step_resident with a communicator reads the last round's failure mark at the NEXT call (round 5: the host
-    used to wait for the device once per step).  One rank: the loop through a real one-rank RCCL communicator == the loop
-    without one (dictionaries, last actions).  Two ranks (two GPUs; skipped -- not verified -- elsewhere): rank 1's last round
-    fails locally at step 3 and reports at once; rank 0 learns of it from the merged mark and leaves at its NEXT call, step 4."""
+def test_resident_loop_through_rccl(tmp_path):
+    """kb_shared_step_resident through a communicator.  One rank: the closed loop on the device through a real one-rank RCCL
+    communicator == the loop without one (dictionaries, last actions).  Two ranks (two GPUs; skipped -- not verified -- elsewhere):
+    rank 1's last round fails locally at step 3; both ranks leave kb_shared_step_resident at step 3, told by the merged mark.
+    (Round 5 tried reading that mark a fixed number of calls later instead of waiting for it once per step: 3.3-3.4 ms per step
+    against 2.9 on one GPU -- slower, for reasons in the streams' interplay that were not pursued -- and went back.)"""
     plain = _run_ranks(1, 16, 8, tmp_path, {'RESIDENT': '1'})
     assert plain[0][0] == 0, plain[0][2][-2000:]
     rccl = _run_ranks(1, 16, 8, tmp_path, {'RESIDENT': '1', 'RCCL_WORLD1': '1'})
@@ -419,8 +420,8 @@ def test_resident_loop_through_rccl_does_not_wait_per_step(tmp_path):
     err = ' '.join(e[-400:] for _, _, e in two)
     if any('ncclCommInitRank' in e or 'Duplicate' in e or 'invalid usage' in e for _, _, e in two):
         pytest.skip('one-rank part verified; RCCL does not form a 2-rank communicator on a single device: %s' % err[-200:])
-    assert two[1][0] == 3 and 'FAILED 1 step 3' in two[1][1], two[1][1][-500:]
-    assert two[0][0] == 3 and 'FAILED 0 step 4' in two[0][1] and 'previous step' in two[0][1], two[0][1][-500:]
+    for r in (0, 1):
+        assert two[r][0] == 3 and ('FAILED %d step 3' % r) in two[r][1], two[r][1][-500:]
 
 
 def test_shared_resident_loop_equals_host_loop():
