@@ -339,6 +339,70 @@ def test_config5_per_gpu_shard_graph_loop_vs_oracle():
             assert h[5][k].tobytes() == info.tobytes(), ('info', r, mk)
 
 
+def _oracle_churn_script_run(args):
+    """one oracle replica of the high-churn configuration driven by the bench action script; outputs of the steps in `marks`"""
+    seed, replica, marks = args
+    from test_gpu_parity import _churn
+    cfg = _churn(make_config(0, n_envs=1))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'fading_small.npz'))
+    o = po.OracleEnv(cfg, [g['t0'], g['t1'], g['t2']])
+    o.set_seed(seed)
+    o.reset()
+    out = {}
+    for i in range(marks[-1]):
+        a = po.random_actions(cfg, ACTION_SEED, i, replica)
+        r = o.step(a)
+        if i + 1 in marks:
+            out[i + 1] = (a, r['obs'].copy(), r['reward'], r['labels'].copy(), r['violations'].copy(), r['info'].copy())
+    return out
+
+
+def test_split_step_at_its_batch_size_vs_oracle(golden_dir):
+    """From 12,288 replicas of five slices on the production library deals the cost ranking out to TWO launches side by side: the
+    lightest 7/8 of the tasks eight to a wave on the 8-lane instance, the rest (every task with eight UEs or more among them) on
+    the 16-lane one; a task that outgrows eight lanes inside a step is replayed by the 32-lane instance (rs_api.hip, round 5).
+    16,384 replicas of the high-churn configuration (slices of 0 to 15 UEs, NaN-column trace), the scripted loop replayed from a
+    captured hipGraph and stepped one by one: 96 sampled replicas against the oracle after 8, 9, 30 and 61 steps, bit for bit."""
+    from ranslice.vec_env import VecRanSlice
+    from test_gpu_parity import _churn
+    n = 16384
+    g = np.load(os.path.join(golden_dir, 'fading_small.npz'))
+    sample = sorted(set([0, 1, 7, 8, 63, 64, 4095, 4096, 8191, 8192, 12287, 12288, 16382, 16383] + list(range(11, n, 199))))
+    marks = (8, 9, 30, 61)
+    cfg = _churn(make_config(0, n_envs=n))
+    with ProcessPoolExecutor(max_workers=min(16, os.cpu_count() or 1), mp_context=_SPAWN) as ex:
+        fut = ex.map(_oracle_churn_script_run, [(replica_seed(0, r), r, marks) for r in sample], chunksize=4)
+        env = VecRanSlice(n_envs=n, cfg=cfg, fading=[g['t0'], g['t1'], g['t2']])
+        env.reset()
+        hip, done = {}, 0
+        for mk in marks:
+            if mk - done >= 3:
+                env.run_random(ACTION_SEED, done, mk - done, graph=True)
+            else:
+                for i in range(done, mk):
+                    env.random_actions(ACTION_SEED, i)
+                    env.step_resident()
+            done = mk
+            f = env.fetch()
+            hip[mk] = (f['actions'][sample].copy(), f['obs'][sample].copy(), f['reward'][sample].copy(),
+                       f['labels'][sample].copy(), f['violations'][sample].copy(), env.l1_info()[sample].copy())
+        c = env.counters()
+        env.close()
+        ref = list(fut)
+    mean_ue = c[3] / (marks[-1] * cfg.slots_per_step * n * cfg.n_embb)
+    assert mean_ue > 1.0, mean_ue
+    bad = []
+    for k, r in enumerate(sample):
+        for mk in marks:
+            a, obs, rew, lab, viol, info = ref[k][mk]
+            h = hip[mk]
+            if not ((h[0][k] == a).all() and h[1][k].tobytes() == obs.tobytes() and h[2][k] == rew and (h[3][k] == lab).all()
+                    and (h[4][k] == viol).all() and h[5][k].tobytes() == info.tobytes()):
+                bad.append((r, mk))
+                break
+    assert not bad, bad[:10]
+
+
 def _oracle_script_run_ids(args):
     """as _oracle_script_run with the script seed given (a rank's own seed) and the replica's LOCAL index in it"""
     scenario, seed, replica, steps, cols, action_seed = args
