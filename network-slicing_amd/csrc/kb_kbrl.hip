@@ -998,6 +998,52 @@ __device__ __forceinline__ void matvec_tri_tiles_lds(const KbState& K, const uin
     }
 }
 
+__device__ __forceinline__ void matvec_tri_combine_wide(const KbState& K, const uint64_t* sh, int m) {
+    // (heavy_finish_kernel's form of matvec_tri_combine below: same sums in the same order; the per-learner kernels keep the plain
+    // loop -- with this one inlined they spilled 608 B per lane.)
+    // Per output: its column of tiles (increasing bi), then its row of tiles, added one after the other in that order.  The partial
+    // sums come from up to 2 n_b scattered places: their loads are issued eight at a time before the (ordered) adds, and the shell
+    // offsets they need come out of a register (one coalesced load per wave) -- one dependent pair of loads per term, as until round
+    // 5, made this loop the duration of heavy_finish_kernel for a dictionary of 26 blocks (~50 us).
+    const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
+    const uint64_t shv = lane < nb ? sh[lane] : 0ull;  // (the first 64 shells; a wave's outputs share their block b)
+    auto part_of = [&](int bi, int bj) -> const double* {
+        uint64_t off;
+        if (bi < 64) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)shv, bi);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(shv >> 32), bi);
+            off = ((uint64_t)hi << 32) | lo;
+        } else {
+            off = sh[bi];
+        }
+        return K.pool + off + KB_VEC + (size_t)(bi + 1) * KB_TILE + (size_t)bj * 128;
+    };
+    for (int i0 = (int)(threadIdx.x & ~63u); i0 < m; i0 += blockDim.x) {  // (whole waves: b is wave-uniform)
+        const int i = i0 + lane;
+        const int b = i0 >> 6, c = lane;
+        double dsum = part_of(b, b)[c];
+        for (int br0 = b + 1; br0 < nb; br0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = br0 + u < nb ? part_of(br0 + u, b)[c] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (br0 + u < nb) dsum += v[u];
+        }
+        double tsum = 0.0;
+        for (int br0 = 0; br0 < b; br0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = br0 + u < b ? part_of(b, br0 + u)[64 + c] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (br0 + u < b) tsum += v[u];
+        }
+        if (i < m) vec_page(K, sh, b)[KB_ROW_DS * KB_CH + c] = dsum + tsum;
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void matvec_tri_combine(const KbState& K, const uint64_t* sh, int m) {
     const int nb = (m + 63) >> 6;
     for (int i = threadIdx.x; i < m; i += blockDim.x) {
@@ -1731,7 +1777,7 @@ __global__ __launch_bounds__(256) void heavy_finish_kernel(CtlArgs A) {
         LoopStats st = {(uint64_t)K.hv_pend[2 * slot], 1, 0, 0};
         if (threadIdx.x == 0 && K.hv_pend[2 * slot + 1] > 0) K.tie_ctr[task] += (uint32_t)K.hv_pend[2 * slot + 1];  // Q11
         if (D.tri)
-            matvec_tri_combine(K, sh, m);
+            matvec_tri_combine_wide(K, sh, m);
         else
             matvec_combine(K, sh, m);
         int branch;
