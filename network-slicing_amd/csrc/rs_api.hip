@@ -412,11 +412,6 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
             HIPCHK(h, hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
         }
     }
-    HIPCHK(h, hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
-    HIPCHK(h, hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
     h->mux = cfg->l1_multiplex != 0;
     h->n_ran = cfg->n_embb + cfg->n_mmtc;
     h->n_slices = h->mux ? (cfg->n_embb > 0) + (cfg->n_mmtc > 0) : h->n_ran;
@@ -586,6 +581,15 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_LIGHT")) h->mixed_light = atoi(e);
+    if (h->mixed > 0 || h->mixed_light < 256) {
+        // the split step's two extra streams exist only on handles that split: several handles side by side (evaluate_grid: six cells)
+        // must stay within the hardware queues of the runtime -- with two idle streams more per handle the grid took 220 s against 135
+        HIPCHK(h, hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork2, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join2, hipEventDisableTiming));
+        HIPCHK(h, hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_join3, hipEventDisableTiming));
+    }
     h->block_hint = auto_hint(h);
     if (const char* e = dev_env("RANSLICE_HINT")) {  // developer knob (profiles/HISTORY.md): as rs_set_schedule_hint
         h->hint_auto = atoi(e) < 0;
@@ -896,7 +900,7 @@ static int launch_step(rs_handle* h) {
             const int par = h->order_par;
             h->order_par ^= 1;
             const unsigned nb = (unsigned)((h->n_tasks + 255) / 256);
-            const bool split = (h->mixed > 0 || h->mixed_light < 256) && !h->trace_on && h->group == 16 && h->n_tasks >= 4096;
+            const bool split = h->side2 != nullptr && (h->mixed > 0 || h->mixed_light < 256) && !h->trace_on && h->group == 16 && h->n_tasks >= 4096;
             // the three stretches of the ranking (heaviest first): [0, head) one task per 16-lane wave, [head, n - light) four per
             // 16-lane wave, composed among themselves as without a split, [n - light, n) eight per 8-lane wave
             if (split) {
