@@ -940,6 +940,9 @@ __device__ __forceinline__ void matvec_tri_tiles(const KbState& K, const uint64_
 // same sums, same order as above: same bits (rows past the dictionary's end contribute zeros here, whatever the tile holds
 // there above: those partial sums are never read).  A function of its own: as one function with a flag the per-learner
 // kernels that use the version above spilled 608 B per lane.
+#ifndef KB_MV_SLABS
+#define KB_MV_SLABS 2  // slabs of eight rows a wave of heavy_matvec_kernel requests together
+#endif
 #define KB_SLAB_LD 72  // doubles between the rows of the LDS copy (64 + 8: the row-wise reads of eight rows spread over the banks)
 __device__ __forceinline__ void matvec_tri_tiles_lds(const KbState& K, const uint64_t* sh, int m, int t0, int t_end, double* slab) {
     const int nb = (m + 63) >> 6, lane = threadIdx.x & 63;
@@ -959,17 +962,17 @@ __device__ __forceinline__ void matvec_tri_tiles_lds(const KbState& K, const uin
         double acc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] = 0.0;
-        for (int x = 0; x < 8; x += 2) {
+        for (int x = 0; x < 8; x += KB_MV_SLABS) {
             if (8 * x >= rows) break;  // (wave-uniform; the last row block of the dictionary)
-            const bool two = 8 * (x + 1) < rows;
-            double v[2][8];
+            double v[KB_MV_SLABS][8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[0][u] = 8 * x + u < rows ? Tp[(8 * x + u) * 64 + lane] : 0.0;
+            for (int h = 0; h < KB_MV_SLABS; ++h) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[1][u] = (two && 8 * (x + 1) + u < rows) ? Tp[(8 * (x + 1) + u) * 64 + lane] : 0.0;
+                for (int u = 0; u < 8; ++u) v[h][u] = 8 * (x + h) + u < rows ? Tp[(8 * (x + h) + u) * 64 + lane] : 0.0;
+            }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (h == 0 || two) {
+            for (int h = 0; h < KB_MV_SLABS; ++h) {
+                if (8 * (x + h) < rows) {
                     const int xs = x + h;
 #pragma unroll
                     for (int u = 0; u < 8; ++u)
