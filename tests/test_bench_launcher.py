@@ -65,6 +65,27 @@ def test_bench_imports_no_torch():
                 assert not re.search(r'^\s*(import|from)\s+torch', src, flags=re.M), f
 
 
+def test_bench_and_product_import_with_torch_masked():
+    """the same at run time: with `torch` made unimportable, bench.py, the rank group and every module of the product package
+    still import (what `python bench.py --gpus 1` touches before it reaches the GPU)"""
+    import subprocess
+    code = (
+        "import sys, importlib.util\n"
+        "sys.modules['torch'] = None\n"
+        "root = %r\n"
+        "sys.path[:0] = [root, root + '/network-slicing_amd', root + '/tools']\n"
+        "spec = importlib.util.spec_from_file_location('bench_masked', root + '/bench.py')\n"
+        "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+        "import rank_group, gym_ran_slice, scenario_creator, kbrl_control, node_b, experiments_kbrl\n"
+        "from ranslice import _lib, config, fading, sharding, vec_env, kbrl_dev, report, gymshim\n"
+        "from algorithms import kernel, projectron\n"
+        "g = rank_group.RankGroup(0, 1); assert g.max(2.5) == 2.5 and g.allgather('x') == ['x']\n"
+        "assert 'torch' not in [k for k, v in sys.modules.items() if v is not None]\n"
+        "print('ok')\n" % ROOT)
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip().endswith('ok'), out.stderr[-1500:]
+
+
 def _canned_full(bench):
     """a full record with every sub-record at the length a real run produces (long strings, nested dicts)"""
     long = 'x' * 900
