@@ -373,11 +373,11 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     h->cfg = *cfg;
     h->device = device;
     if (cfg->n_envs <= 0 || cfg->n_prbs <= 0 || cfg->n_prbs > RS_MAX_PRBS || cfg->n_embb < 0 || cfg->n_mmtc < 0 ||
-        cfg->n_embb + cfg->n_mmtc <= 0 || cfg->slots_per_step <= 0 || cfg->n_mcs <= 0 || cfg->n_mcs > 32 ||
+        cfg->n_embb + cfg->n_mmtc <= 0 || cfg->slots_per_step <= 0 || cfg->slots_per_step > 63 || cfg->n_mcs <= 0 || cfg->n_mcs > 32 ||
         cfg->pf_granularity <= 0 || (cfg->max_ue != 0 && cfg->max_ue != (cfg->l1_multiplex ? RS_MUX_UE : RS_GROUP)) ||
         (cfg->l1_multiplex && (cfg->n_embb > 6 || cfg->n_mmtc > RS_MUX_RAN)) ||
         (cfg->max_bursts != 0 && cfg->max_bursts != RS_BURSTS)) {
-        h->err = "rs_create: unsupported configuration (n_prbs <= 256; max_ue 0 or 32, 64 with l1_multiplex; max_bursts 0 or 16; "
+        h->err = "rs_create: unsupported configuration (n_prbs <= 256; slots_per_step <= 63; max_ue 0 or 32, 64 with l1_multiplex; max_bursts 0 or 16; "
                  "l1_multiplex: at most 6 eMBB and 8 mMTC RAN slices)";
         return RS_EINVAL;
     }

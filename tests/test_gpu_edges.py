@@ -346,3 +346,66 @@ def test_multiplexed_l1_many_mmtc_slices(golden_dir):
         VecRanSlice(n_envs=2, cfg=make_config(None, n_envs=2, L1_level=False, n_prbs=100, n_embb=0, n_mmtc=2),
                     fading=_fading(golden_dir))
     assert e.value.code == _lib.RS_EINVAL and 'eMBB' in str(e.value)
+
+
+def _fuzz_case(k):
+    """one random configuration: carrier, slice mix, slots per step, propagation, PF parameters, traffic"""
+    rng = np.random.default_rng(7000 + k)
+    n_embb = int(rng.integers(0, 6))
+    n_mmtc = int(rng.integers(0 if n_embb else 1, 4))
+    kw = dict(n_prbs=int(rng.integers(4, 201)), n_embb=n_embb, n_mmtc=n_mmtc,   # (a 100-row trace extends to 200 PRBs, channel_models.py:144-148)
+              slots_per_step=int(rng.choice([1, 3, 12, 13, 25, 50, 63])),
+              propagation_type=str(rng.choice(['macro_cell_urban_2GHz', 'macro_cell_urban_900MHz', 'macro_cell_rural'])),
+              penalty=int(rng.choice([1, 100, 1000])))
+    gran, window = int(rng.choice([1, 2, 2, 3, 4])), int(rng.choice([5, 50, 200]))
+    churn = bool(rng.integers(0, 2))
+    n_envs = int(rng.choice([1, 2, 5, 9, 17, 33]))
+    return kw, gran, window, churn, n_envs
+
+
+@pytest.mark.parametrize('k', range(16))
+def test_random_configurations_vs_oracle(golden_dir, k):
+    """Configurations no scenario of the reference uses -- carriers of 4 to 200 PRBs, 0-5 eMBB and 0-3 mMTC slices, 1 to 63 slots per
+    step, every propagation model, PF granularity 1-4 and window 5-200, quiet and high-churn traffic, ragged batch sizes -- through
+    the production instance against the oracle: observations, rewards, labels, violations, info sums and (eMBB, small batches)
+    every UE's allocation in every slot, bit for bit."""
+    from ranslice.vec_env import VecRanSlice
+    from test_gpu_parity import _actions, _churn, _small_fading
+    kw, gran, window, churn, n = _fuzz_case(k)
+    fading = _small_fading(golden_dir)
+
+    def cfg_for(n_envs):
+        c = make_config(None, n_envs=n_envs, **kw)
+        c.pf_granularity, c.pf_window = gran, window
+        return _churn(c) if churn else c
+    cfg = cfg_for(n)
+    env = VecRanSlice(n_envs=n, cfg=cfg, fading=fading, seed=4000 + k)
+    trace = cfg.n_embb > 0 and n <= 9
+    if trace:
+        env.set_alloc_trace(True)
+    env.reset()
+    oracles = []
+    for r in range(n):
+        o = po.OracleEnv(cfg_for(1), fading)
+        o.set_seed(replica_seed(4000 + k, r))
+        o.reset()
+        oracles.append(o)
+    rng = np.random.default_rng(100 + k)
+    S = cfg.n_embb + cfg.n_mmtc
+    for i in range(10):
+        acts = _actions(rng, n, S, cfg.n_prbs, i)
+        obs, rew, done, info = env.step(acts)
+        l1 = env.l1_info()
+        tr = env.alloc_trace() if trace else None
+        for r, o in enumerate(oracles):
+            out = o.step(acts[r], trace=trace)
+            assert obs[r].tobytes() == out['obs'].tobytes(), (kw, 'obs', i, r)
+            assert rew[r] == out['reward'] and (info['SLA_labels'][r] == out['labels']).all(), (kw, 'reward/labels', i, r)
+            assert (info['violations'][r] == out['violations']).all() and l1[r].tobytes() == out['info'].tobytes(), (kw, 'info', i, r)
+            if trace:
+                a, b = tr[r], out['trace']
+                for f in ('serial', 'type', 'e_snr', 'prbs', 'bits'):
+                    assert (a[f] == b[f]).all(), (kw, f, i, r)
+                for f in ('queue', 'th', 'p'):
+                    assert a[f].tobytes() == b[f].tobytes(), (kw, f, i, r)
+    env.close()
