@@ -394,6 +394,8 @@ def test_random_configurations_vs_oracle(golden_dir, k):
     S = cfg.n_embb + cfg.n_mmtc
     for i in range(10):
         acts = _actions(rng, n, S, cfg.n_prbs, i)
+        over = acts.sum(axis=1) > cfg.n_prbs          # (the small-integer script on a carrier narrower than its slices)
+        acts[over] = np.minimum(acts[over], cfg.n_prbs // S)
         obs, rew, done, info = env.step(acts)
         l1 = env.l1_info()
         tr = env.alloc_trace() if trace else None
