@@ -39,7 +39,7 @@ typedef struct rs_config {
     int32_t n_prbs;         /* scenario_creator.py:26-50 */
     int32_t n_embb;         /* eMBB slices come first, then mMTC (scenario_creator.py:158-166) */
     int32_t n_mmtc;
-    int32_t slots_per_step; /* scenario_creator.py:100 (50) */
+    int32_t slots_per_step; /* scenario_creator.py:100 (50); 1 .. 63 (the per-step statistics of a task are packed) */
     int32_t max_ue;         /* capacity: UEs per eMBB slice (0 -> 32) */
     int32_t max_bursts;     /* capacity: VBR bursts running at once per UE (0 -> 16) */
     int32_t max_mtc_queue;  /* capacity: backlogged mMTC devices per slice (0 -> 1024) */
