@@ -236,3 +236,19 @@ def test_scaling_report_runs_end_to_end_on_a_one_gpu_box(monkeypatch, capsys):
     cmd, env = seen[0]
     assert cmd[cmd.index('--gpus') + 1] == '1' and '--no-cpu-baseline' in cmd and '--no-kbrl' in cmd
     assert 'RANK' not in env and 'WORLD_SIZE' not in env
+
+
+def test_hbm_traffic_summary_feeds_the_roofline():
+    """profiles/hbm_traffic.json (tools/make_hbm_traffic.py from a tools/profile_round.sh run) carries what bench.py quotes as
+    roofline.traffic and roofline.limiter, taken at the population of the default bench's timed run, and its sources are committed"""
+    import json
+    t = json.load(open(os.path.join(ROOT, 'profiles', 'hbm_traffic.json')))
+    for k in ('embb_step_kernel_bytes_per_launch', 'mean_ues_per_slice', 'n_envs', 'valu_issue_frac', 'valu_insts_per_launch', 'file',
+              'valu_issue_file', 'algorithmic_bytes_per_launch_same_run', 'kernel_ms_hip_events', 'kernel_ms_rocprofv3_trace'):
+        assert t.get(k) is not None, k
+    assert t['n_envs'] == 4096 and 3.2 < t['mean_ues_per_slice'] < 3.4          # the stationary population of the default bench
+    assert 0.5 < t['embb_step_kernel_bytes_per_launch'] / t['algorithmic_bytes_per_launch_same_run'] < 1.5
+    assert 0.5 < t['valu_issue_frac'] < 1.0
+    assert abs(t['kernel_ms_hip_events'] - t['kernel_ms_rocprofv3_trace']) < 0.05 * t['kernel_ms_hip_events']   # the two clocks agree
+    for f in (t['file'], t['valu_issue_file']):
+        assert os.path.exists(os.path.join(ROOT, f)), f
