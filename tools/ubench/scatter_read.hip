@@ -19,7 +19,7 @@ struct Args {
     const int* chain;        // dependent-load chain table
     size_t page_stride;
     double* out;
-    int max_chunks, stores, do_chain, do_exp, do_lds;
+    int max_chunks, stores, do_chain, do_exp, do_lds, layout;  // layout 1: the vector page's real rows (0-9 coordinates, 16 coefficient, 21 index)
 };
 
 __global__ __launch_bounds__(64, 4) void scatter(Args A) {
@@ -37,8 +37,9 @@ __global__ __launch_bounds__(64, 4) void scatter(Args A) {
     double acc = 0.0;
     double cur[12], nxt[12];
     const double* P = A.pool + (size_t)my[0] * A.page_stride;
+    const int rmap[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 21};
 #pragma unroll
-    for (int r = 0; r < 12; ++r) nxt[r] = P[r * 64 + lane];
+    for (int r = 0; r < 12; ++r) nxt[r] = P[(A.layout ? rmap[r] : r) * 64 + lane];
     for (int c = 0; c < chunks; ++c) {
         double* Pw = A.wpool + (size_t)my[c] * A.page_stride;
 #pragma unroll
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(64, 4) void scatter(Args A) {
         if (c + 1 < chunks) {
             const double* Q = A.pool + (size_t)my[c + 1] * A.page_stride;
 #pragma unroll
-            for (int r = 0; r < 12; ++r) nxt[r] = Q[r * 64 + lane];
+            for (int r = 0; r < 12; ++r) nxt[r] = Q[(A.layout ? rmap[r] : r) * 64 + lane];
         }
         double s = 0.0;
 #pragma unroll
@@ -54,8 +55,8 @@ __global__ __launch_bounds__(64, 4) void scatter(Args A) {
         if (A.do_exp)
             for (int i = 0; i < 30; ++i) s = __builtin_fma(s, 0.999, 1e-3);
         if (A.stores) {
-            Pw[17 * 64 + lane] = s;
-            Pw[18 * 64 + lane] = s + 1.0;
+            Pw[(A.layout ? 17 : 12) * 64 + lane] = s;
+            Pw[(A.layout ? 18 : 13) * 64 + lane] = s + 1.0;
         }
         if (A.do_lds) unsafeAtomicAdd(&W[(lane * 7 + c) & 255], s);
         acc += s;
@@ -102,11 +103,13 @@ int main() {
     hipMemcpy(duni, uni.data(), 4 * waves, hipMemcpyHostToDevice);
     hipMemcpy(dskew, skew.data(), 4 * waves, hipMemcpyHostToDevice);
     printf("skewed chunk counts: mean %.2f\n", (double)tot / waves);
-    struct V { const char* name; int skewed, stores, chain, ex, lds; };
-    const V vs[] = {{"plain", 0, 0, 0, 0, 0}, {"+stores", 0, 1, 0, 0, 0}, {"+chain", 0, 0, 1, 0, 0}, {"+exp", 0, 0, 0, 1, 0}, {"+lds", 0, 0, 0, 0, 1},
-                    {"+skew", 1, 0, 0, 0, 0}, {"+skew+stores", 1, 1, 0, 0, 0}, {"all", 1, 1, 1, 1, 1}, {"all but skew", 0, 1, 1, 1, 1}};
+    struct V { const char* name; int skewed, stores, chain, ex, lds, layout; };
+    const V vs[] = {{"plain", 0, 0, 0, 0, 0, 0}, {"+stores", 0, 1, 0, 0, 0, 0}, {"+chain", 0, 0, 1, 0, 0, 0}, {"+exp", 0, 0, 0, 1, 0, 0}, {"+lds", 0, 0, 0, 0, 1, 0},
+                    {"+skew", 1, 0, 0, 0, 0, 0}, {"+skew+stores", 1, 1, 0, 0, 0, 0}, {"all", 1, 1, 1, 1, 1, 0}, {"all but skew", 0, 1, 1, 1, 1, 0},
+                    {"real rows", 0, 0, 0, 0, 0, 1}, {"real rows+stores", 0, 1, 0, 0, 0, 1}, {"real rows, all", 1, 1, 1, 1, 1, 1},
+                    {"contiguous, all", 1, 1, 1, 1, 1, 0}};
     for (const V& v : vs) {
-        Args A = {pool, pool, dpg, v.skewed ? dskew : duni, dchain, stride, out, max_chunks, v.stores, v.chain, v.ex, v.lds};
+        Args A = {pool, pool, dpg, v.skewed ? dskew : duni, dchain, stride, out, max_chunks, v.stores, v.chain, v.ex, v.lds, v.layout};
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(scatter, dim3(waves), dim3(64), 0, 0, A);
