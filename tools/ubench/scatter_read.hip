@@ -19,7 +19,8 @@ struct Args {
     const int* chain;        // dependent-load chain table
     size_t page_stride;
     double* out;
-    int max_chunks, stores, do_chain, do_exp, do_lds, layout;  // layout 1: the vector page's real rows (0-9 coordinates, 16 coefficient, 21 index)
+    int max_chunks, stores, do_chain, do_exp, do_lds, layout, extra;  // extra: bit 0 a 2-KB result per wave, bit 1 a dependent state load + barriers
+    const float* state; double* wg;  // layout 1: the vector page's real rows (0-9 coordinates, 16 coefficient, 21 index)
 };
 
 __global__ __launch_bounds__(64, 4) void scatter(Args A) {
@@ -34,7 +35,12 @@ __global__ __launch_bounds__(64, 4) void scatter(Args A) {
     const uint32_t* my = A.pages + (size_t)w * A.max_chunks;
     const int chunks = A.nchunks[w];
     for (int k = lane; k < 256; k += 64) W[k] = 0.0;
-    double acc = 0.0;
+    __shared__ double xs[16];
+    if (A.extra & 2) {
+        if (lane < 10) xs[lane] = (double)A.state[(size_t)(w / 5) * 50 + (w % 5) * 10 + lane];
+        __syncthreads();
+    }
+    double acc = (A.extra & 2) ? xs[lane & 7] : 0.0;
     double cur[12], nxt[12];
     const double* P = A.pool + (size_t)my[0] * A.page_stride;
     const int rmap[12] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 16, 21};
@@ -61,6 +67,9 @@ __global__ __launch_bounds__(64, 4) void scatter(Args A) {
         if (A.do_lds) unsafeAtomicAdd(&W[(lane * 7 + c) & 255], s);
         acc += s;
     }
+    if (A.extra & 2) __syncthreads();
+    if (A.extra & 1)
+        for (int k = 0; k < 4; ++k) A.wg[(size_t)w * 256 + lane + 64 * k] = W[lane + 64 * k] + acc;
     A.out[(size_t)blockIdx.x * 64 + lane] = acc + W[lane];
 }
 
@@ -103,13 +112,17 @@ int main() {
     hipMemcpy(duni, uni.data(), 4 * waves, hipMemcpyHostToDevice);
     hipMemcpy(dskew, skew.data(), 4 * waves, hipMemcpyHostToDevice);
     printf("skewed chunk counts: mean %.2f\n", (double)tot / waves);
-    struct V { const char* name; int skewed, stores, chain, ex, lds, layout; };
+    struct V { const char* name; int skewed, stores, chain, ex, lds, layout, extra; };
+    float* dstate; double* dwg;
+    hipMalloc(&dstate, 4 * 50 * 8192); hipMemset(dstate, 0, 4 * 50 * 8192);
+    hipMalloc(&dwg, 8 * 256 * (size_t)waves);
     const V vs[] = {{"plain", 0, 0, 0, 0, 0, 0}, {"+stores", 0, 1, 0, 0, 0, 0}, {"+chain", 0, 0, 1, 0, 0, 0}, {"+exp", 0, 0, 0, 1, 0, 0}, {"+lds", 0, 0, 0, 0, 1, 0},
                     {"+skew", 1, 0, 0, 0, 0, 0}, {"+skew+stores", 1, 1, 0, 0, 0, 0}, {"all", 1, 1, 1, 1, 1, 0}, {"all but skew", 0, 1, 1, 1, 1, 0},
                     {"real rows", 0, 0, 0, 0, 0, 1}, {"real rows+stores", 0, 1, 0, 0, 0, 1}, {"real rows, all", 1, 1, 1, 1, 1, 1},
-                    {"contiguous, all", 1, 1, 1, 1, 1, 0}};
+                    {"contiguous, all", 1, 1, 1, 1, 1, 0}, {"all + 2 KB result", 1, 1, 1, 1, 1, 1, 1}, {"all + state/barriers", 1, 1, 1, 1, 1, 1, 2},
+                    {"all + both", 1, 1, 1, 1, 1, 1, 3}};
     for (const V& v : vs) {
-        Args A = {pool, pool, dpg, v.skewed ? dskew : duni, dchain, stride, out, max_chunks, v.stores, v.chain, v.ex, v.lds, v.layout};
+        Args A = {pool, pool, dpg, v.skewed ? dskew : duni, dchain, stride, out, max_chunks, v.stores, v.chain, v.ex, v.lds, v.layout, v.extra, dstate, dwg};
         hipEvent_t a, b;
         hipEventCreate(&a); hipEventCreate(&b);
         for (int it = 0; it < 3; ++it) hipLaunchKernelGGL(scatter, dim3(waves), dim3(64), 0, 0, A);
