@@ -365,6 +365,42 @@ static void mcs_lookup(const rs_config* c, double A, double B, int e_snr, int* m
     *rate_out = (int)((double)c->sym_per_prb * (c->mcs_rate[mcs] * (double)c->mcs_order[mcs]));
 }
 
+// The reception test by guard band (rs_embb.hip, fast_sigmoid): u < p_rx  <=>  S > S*(u) for A, k > 0, both sides formed in
+// float32 and compared with a band that covers their errors.  Per RB of the span (absolute, in units of one sigmoid):
+//   S~  : 4e-7  = argument (three float roundings: 1.8e-7 |t|, through t sigma'(t) <= 0.224) + v_exp_f32 and v_rcp_f32 at two
+//                 ulps each + the rounding of 1 + e;
+//   S*~ : 4e-7 for its sigmoid + 0.25 k x 6.2e-6 / A for s* (u and 1 - u in float, v_rcp_f32, v_log_f32 to 4e-6 absolute in
+//                 log2 units over |log2| <= 13.3 -- the draw is within [1e-4, 1 - 1e-4] or the UE takes the exact path --,
+//                 the float products with ln 2 and 1/A);
+//   the exact chain itself (channel_models.py:35-41,297-313 in f64: y = S/n, 1/y - 1, log, A (s - ref) - B, exp, 1/(1+e))
+//                 equals the real-valued p at an S perturbed by < 1e-15 n, times (1 +- 1e-12); p rises by at least
+//                 u (1 - u) / e x 4 (A/k) x 2e-6 >= 3e-10 (A/k) over 2e-6 n of S, which is what the last term buys.
+//   band = 6e-6 + 6e-6 k/A per RB (needed: 2.8e-6 + 1.6e-6 k/A).  Single-RB spans compare s - ref with s* - ref in dB:
+//   6.2e-6/A of error + 8e-6/A of margin -> 4e-5/A + 1e-6.
+// Off (band 0: every UE evaluated exactly) unless A > 0, every k > 0 and 1 <= A/k <= 1e4.
+static void rx_fast_setup(RsDev& d) {
+    const double A = d.mcsA;
+    double kmax = 0.0, kmin = 1e300;
+    bool ok = std::isfinite(A) && A > 0.0 && std::isfinite(d.mcsB);
+    for (int m = 0; m < 3; ++m) {
+        const double k = d.mi_k[m];
+        ok = ok && std::isfinite(k) && k > 0.0 && std::isfinite(d.mi_x0[m]);
+        kmax = k > kmax ? k : kmax;
+        kmin = k < kmin ? k : kmin;
+        d.rx_c1[m] = (float)(-k * RS_INV_LN2);
+    }
+    ok = ok && A / kmax >= 1.0 && A / kmin <= 1.0e4;
+    d.rx_invA = ok ? (float)(1.0 / A) : 0.0f;
+    d.rx_B = (float)d.mcsB;
+    d.rx_band = ok ? 6.0e-6 + 6.0e-6 * (kmax / A) : 0.0;
+    d.rx_band1 = ok ? 4.0e-5 / A + 1.0e-6 : 0.0;
+    if (dev_env("RANSLICE_RX_EXACT")) d.rx_band = 0.0;  // test build: the exact probability for every UE
+    if (const char* e = dev_env("RANSLICE_RX_BAND_SCALE")) {  // test build: a wider band sends more UEs down the exact path
+        const double f = atof(e);
+        if (f >= 1.0) { d.rx_band *= f; d.rx_band1 *= f; }
+    }
+}
+
 extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     if (!cfg || !out) return RS_EINVAL;
     *out = nullptr;
@@ -503,6 +539,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         d.mi_x0[m] = cfg->mi_x0[m];
         d.mi_k[m] = cfg->mi_k[m];
     }
+    rx_fast_setup(d);
     d.mtc_n_dev = cfg->mtc_n_devices;
     d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
     d.mtc_n_rep = cfg->mtc_n_rep;

@@ -51,6 +51,11 @@ struct RsDev {
     double mcs_ref[32];
     int32_t mcs_mod[32];    // modulation of each MCS (0 qpsk, 1 16qam, 2 64qam)
     double mi_x0[3], mi_k[3];  // mutual-information sigmoid per modulation (channel_models.py:268-270)
+    // the reception test by guard band (rs_embb.hip: fast_sigmoid; set up by rx_fast_setup in rs_api.hip)
+    double rx_band;         // guard band of the MI-sum comparison, per RB of the span; 0 = every UE takes the exact path
+    double rx_band1;        // guard band (dB) of the single-RB comparison
+    float rx_c1[3];         // -k log2(e) per modulation
+    float rx_invA, rx_B;    // 1 / mcsA, mcsB
     double penalty;
     // mMTC
     int32_t mtc_n_dev, mtc_cap, mtc_n_rep, mtc_n_period;

@@ -632,6 +632,106 @@ __device__ __noinline__ double wide_response(const double* mi, const double* fad
     return out;
 }
 
+// ---- The reception TEST without the reception PROBABILITY (non-tracing instances).
+// All the simulator does with MCSCodeset.response (channel_models.py:297-313) is one comparison, `u < p_rx`
+// (slice_l1.py:219-224), and p_rx is a strictly increasing function of the MI sum S = sum_i sigmoid(snr_i):
+//     u < p_rx  <=>  S > S*(u),   S* = n sigmoid_mod(s*),  s* = ref(mcs) + (B - ln((1-u)/u)) / A        (A, k > 0).
+// So the kernel forms S~ ~ S and S*~ ~ S* in float32 on the transcendental unit (v_exp_f32 / v_log_f32 / v_rcp_f32:
+// ~9 instructions per RB where the exact sigmoid is ~45, and the sum may take any order) and decides by them whenever
+// they lie further apart than a guard band that covers both approximation errors several times over (RsDev.rx_band,
+// derived in rs_api.hip: rx_fast_setup); a UE inside the band, or whose draw is within 1e-4 of 0 or 1, is evaluated
+// exactly as before.  The outcome is the exact path's outcome in every case, so results stay bit-identical to the oracle;
+// only ~2e-4 of the evaluations take the exact path (counted: rs_get_rx_stats).
+//
+// sigmoid of the float argument d (= snr - x0, any magnitude) with slope constant c1 = -k log2(e): absolute error below
+// 3e-7 whatever d is (the argument's relative error of 2e-7 enters through t sigma'(t) <= 0.23)
+__device__ __forceinline__ float fast_sigmoid(float d, float c1) {
+    float t2 = d * c1;
+    t2 = __builtin_fminf(__builtin_fmaxf(t2, -100.0f), 100.0f);  // 2^+-100: finite, normal; sigmoid is 0 or 1 to 1e-30 there
+    const float e = __builtin_amdgcn_exp2f(t2);
+    return __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// S~ of the spans flagged `mine` (2..RS_FAST_WIDE RBs), dealt to 8-lane teams like team_response; any order
+#ifndef RS_FAST_WIDE
+#define RS_FAST_WIDE 48
+#endif
+__device__ __forceinline__ double fast_team_sums(const double* mi, const float* c1s, const double* fad, const double* nom_wave,
+                                                 bool mine, int rbs, int span_col, int mod) {
+    const int lane = (int)(threadIdx.x & 63u);
+    double out = 0.0;
+    const unsigned long long wmask = __builtin_amdgcn_ballot_w64(mine);
+    const int n_sp = __popcll(wmask);
+    const int my_sp = __popcll(wmask & ((1ull << lane) - 1ull));
+    const int team = lane >> 3, j = lane & 7;
+    unsigned long long rest = wmask;
+    for (int round = 0; round * 8 < n_sp; ++round) {
+        int owner = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int o = rest ? __builtin_ctzll(rest) : 0;
+            rest &= rest - 1ull;
+            owner = team == k ? o : owner;
+        }
+        const bool on = round * 8 + team < n_sp;
+        const int c0 = bperm(span_col, owner);
+        const int n_o = bperm(rbs, owner);
+        const int n = on ? n_o : 0;
+        const int md = bperm(mod, owner);
+        const double nomx = nom_wave[owner] - mi[md];
+        const float c1 = c1s[md];
+        const double* __restrict__ sp = fad + (on ? c0 : 0);
+        double acc = 0.0;
+        for (int i = j; wave_any(i < n); i += 16) {
+            const bool p1 = i < n, p2 = i + 8 < n;
+            const double v1 = p1 ? sp[i] : 0.0, v2 = p2 ? sp[i + 8] : 0.0;  // (both fetches in flight)
+            const float s1 = fast_sigmoid((float)(v1 + nomx), c1), s2 = fast_sigmoid((float)(v2 + nomx), c1);
+            acc += p1 ? (double)s1 : 0.0;
+            acc += p2 ? (double)s2 : 0.0;
+        }
+        acc += dpp_d<DPP_XOR1>(acc);
+        acc += dpp_d<DPP_XOR2>(acc);
+        acc += dpp_d<DPP_HMIRROR>(acc);
+        const double got = bperm(acc, (my_sp & 7) << 3);
+        if (mine && (my_sp >> 3) == round) out = got;
+    }
+    return out;
+}
+
+// S~ of spans wider than RS_FAST_WIDE RBs (an agent's allocation): the whole wave, one RB per lane and pass
+__device__ __forceinline__ double fast_wide_sums(const double* mi, const float* c1s, const double* fad, const double* nom_wave,
+                                                 bool mine, int rbs, int span_col, int mod) {
+    const int lane = (int)(threadIdx.x & 63u);
+    double out = 0.0;
+    unsigned long long wm = __builtin_amdgcn_ballot_w64(mine);
+    while (wm != 0ull) {
+        const int ol = __builtin_ctzll(wm);  // the span's owner lane (uniform)
+        wm &= wm - 1ull;
+        const int n = __builtin_amdgcn_readlane(rbs, ol);
+        const int c0 = __builtin_amdgcn_readlane(span_col, ol);
+        const int md = __builtin_amdgcn_readlane(mod, ol);
+        const double nomx = nom_wave[ol] - mi[md];
+        const float c1 = c1s[md];
+        double acc = 0.0;
+        for (int k0 = 0; k0 < n; k0 += 128) {
+            const int k1 = k0 + lane, k2 = k0 + 64 + lane;
+            const bool p1 = k1 < n, p2 = k2 < n;
+            const double v1 = p1 ? fad[c0 + k1] : 0.0, v2 = p2 ? fad[c0 + k2] : 0.0;
+            const float s1 = fast_sigmoid((float)(v1 + nomx), c1), s2 = fast_sigmoid((float)(v2 + nomx), c1);
+            acc += p1 ? (double)s1 : 0.0;
+            acc += p2 ? (double)s2 : 0.0;
+        }
+        acc += dpp_d<DPP_XOR1>(acc);
+        acc += dpp_d<DPP_XOR2>(acc);
+        acc += dpp_d<DPP_HMIRROR>(acc);
+        acc += dpp_d<DPP_MIRROR>(acc);
+        acc += bperm(acc, lane ^ 16);
+        acc += bperm(acc, lane ^ 32);
+        if (lane == ol) out = acc;
+    }
+    return out;
+}
+
 // 5 waves per SIMD for the production instance (the whole 4096-replica batch is then co-resident).  The tracing
 // instances are test tooling: they keep the register budget of 3 waves per SIMD.
 // BLOCK: the contested PF allocation may hand out RB pairs in block rounds (wide slices); without it the instance
@@ -658,6 +758,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     __shared__ int L_lut[RS_LUT_MAX];        // e_snr -> modulation << 24 | mcs << 16 | rate (mcs_rate_vs_error)
     __shared__ double L_ref[32];             // MCS reference SNR (estimate_rx_prob)
     __shared__ double L_mi[8];               // logistic MI curves: x0 of the three modulations, pad, k of the three, pad
+    __shared__ float L_c1[4];                // -k log2(e) of the three modulations in float32 (the reception test by guard band)
     __shared__ int L_task[TPB][4];           // per task: cbr_at, vbr_at, slice draw counter, next UE serial
     __shared__ double W_mi[4][RS_WIDE_MAX];  // per wave: MI values of one WIDE span (response of 65..192 RBs); sized so
                                              // that a block stays within 25 LDS granules of 1280 B: 5 blocks per CU
@@ -666,6 +767,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     if (tid < RS_LUT_MAX) L_lut[tid] = tid < D->lut_n ? ((D->mcs_mod[D->lut_mcs[tid]] << 24) | (D->lut_mcs[tid] << 16) | D->lut_rate[tid]) : 0;
     if (tid >= 64 && tid < 96) L_ref[tid - 64] = D->mcs_ref[tid - 64];
     if (tid >= 96 && tid < 104) L_mi[tid - 96] = (tid & 3) == 3 ? 0.0 : (tid < 100 ? D->mi_x0[tid - 96] : D->mi_k[tid - 100]);
+    if (tid >= 104 && tid < 108) L_c1[tid - 104] = tid < 107 ? D->rx_c1[tid - 104] : 0.0f;
     __syncthreads();
     const RsState& S = *A.S;
     const int clock0 = (int)A.run[0];
@@ -695,6 +797,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const bool pf_div_fast = BLOCK ? FDIV : (D->pf_div_fast != 0);
     const int gran = D->gran;
     const bool has_nan = D->has_nan != 0;
+    const bool rx_fast = D->rx_band > 0.0;  // the reception test by guard band is available for this configuration
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2];
     const int fo0 = (int)D->fad_off[0], fo1 = (int)D->fad_off[1], fo2 = (int)D->fad_off[2];  // < 2^31 (rs_load_fading)
     const int vo0 = (int)D->valid_off[0], vo1 = (int)D->valid_off[1], vo2 = (int)D->valid_off[2];
@@ -1465,24 +1568,58 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             // anything: those that sent bits.  (A UE holding RBs without data still consumes its Bernoulli draw
             // below; the allocation trace wants every probability, so the tracing instances evaluate them all.)
             const bool needed = sched && active && rbs > 0 && (TRACE || bits > 0);
-            // R1 + R2 fused: np.mean's pairwise sum of the mutual information over a UE's RBs.  The spans to evaluate
-            // (all tasks of the wave) are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator
-            // R_j: it evaluates the sigmoid of its elements one after the other and adds them in numpy's order, the
-            // team meets for the tree and the remainder.  No per-RB values are stored anywhere.
-            double sum_rx = 0.0;
             const int span_col = col + prb_lo + prb_i;  // first element of my span in the fading table
-            constexpr int WIDE = RS_WIDE_SPAN;
-            const bool wide_sp = needed && rbs > WIDE && rbs <= RS_WIDE_MAX;
-            if (wave_any(wide_sp)) sum_rx = wide_response(L_mi, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
-            sum_rx = team_response(L_mi, A.fad, &L_nom[wb], needed && !wide_sp, rbs, span_col, mod, sum_rx);
+            // ---- the reception test by guard band (see fast_sigmoid above): decided in float32 for all but ~2e-4 of the UEs
+            bool exact = needed;   // UEs whose probability is evaluated exactly
+            bool rx_ok = false;    // outcome of the others
+            if (!TRACE && rx_fast) {
+                double u = 0.5;
+                if (needed) {
+                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], L_ctr[lt]};
+                    u = rs_stream_uniform(&st);  // the draw the reception step consumes below
+                }
+                const bool central = u >= 1.0e-4 && u <= 1.0 - 1.0e-4;
+                const float lf = 0.6931471805599453f * __builtin_amdgcn_logf((float)(1.0 - u) * __builtin_amdgcn_rcpf((float)u));
+                const float dq = (D->rx_B - lf) * D->rx_invA;  // s* - ref(mcs), dB
+                const double x0 = L_mi[mod], ref = L_ref[mcs];
+                const bool single = rbs == 1;  // no MI average (channel_models.py:305): the RB's SINR against s* itself
+                const bool multi = needed && !single;
+                const bool fw = multi && rbs > RS_FAST_WIDE;
+                double S = 0.0;
+                if (wave_any(fw)) S = fast_wide_sums(L_mi, L_c1, A.fad, &L_nom[wb], fw, rbs, span_col, mod);
+                if (wave_any(multi && !fw)) {
+                    const double s2 = fast_team_sums(L_mi, L_c1, A.fad, &L_nom[wb], multi && !fw, rbs, span_col, mod);
+                    S = fw ? S : s2;
+                }
+                if (needed && single) S = (A.fad[span_col] + L_nom[lt]) - ref;
+                const float ystar = fast_sigmoid((float)((ref - x0) + (double)dq), L_c1[mod]);
+                const double St = single ? (double)dq : (double)rbs * (double)ystar;
+                const double band = single ? D->rx_band1 : (double)rbs * D->rx_band;
+                const double dd = S - St;
+                const bool sure = central && (dd > band || dd < -band);  // (NaN anywhere: not sure)
+                rx_ok = dd > 0.0;
+                exact = needed && !sure;
+            }
             SEC_MARK(10)
-            // R3: effective SNR and reception probability, every evaluated UE in its own lane
-            if (needed) {
-                const double x0 = L_mi[mod], kk = L_mi[4 + mod];
-                double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
-                if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
-                const double x = D->mcsA * (s_eff - L_ref[mcs]) - D->mcsB;
-                p_rx = rs_sigmoid(x, 0.0, 1.0);
+            if (wave_any(exact)) {
+                // R1 + R2 fused: np.mean's pairwise sum of the mutual information over a UE's RBs.  The spans to evaluate
+                // (all tasks of the wave) are dealt out to TEAMS of 8 lanes, lane j of a team owning numpy's accumulator
+                // R_j: it evaluates the sigmoid of its elements one after the other and adds them in numpy's order, the
+                // team meets for the tree and the remainder.  No per-RB values are stored anywhere.
+                double sum_rx = 0.0;
+                constexpr int WIDE = RS_WIDE_SPAN;
+                const bool wide_sp = exact && rbs > WIDE && rbs <= RS_WIDE_MAX;
+                if (wave_any(wide_sp)) sum_rx = wide_response(L_mi, A.fad, W_mi[tid >> 6], &L_nom[wb], wide_sp, rbs, span_col, mod);
+                sum_rx = team_response(L_mi, A.fad, &L_nom[wb], exact && !wide_sp, rbs, span_col, mod, sum_rx);
+                // R3: effective SNR and reception probability, every evaluated UE in its own lane
+                if (exact) {
+                    const double x0 = L_mi[mod], kk = L_mi[4 + mod];
+                    double s_eff = sum_rx;  // rbs == 1: the RB's SINR itself (0 + x, numpy's n < 8 path)
+                    if (rbs > 1) s_eff = rs_inv_sigmoid(sum_rx / (double)rbs, x0, kk);
+                    const double x = D->mcsA * (s_eff - L_ref[mcs]) - D->mcsB;
+                    p_rx = rs_sigmoid(x, 0.0, 1.0);
+                    if (!TRACE) atomicAdd((unsigned long long*)&A.counters[(size_t)task * 4 + 1], 1ull);
+                }
             }
             SEC_MARK(4)
             // ---- reception + UE.transmission_step (slice_l1.py:219-224, slice_ran.py:51-55)
@@ -1490,9 +1627,11 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                 bool received = false;
                 if (rbs > 0) {  // the draw is consumed whether or not anything rides on it
                     const unsigned c = L_ctr[lt];
-                    if (needed) {
+                    if (exact) {
                         rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], c};
                         received = rs_stream_uniform(&st) < p_rx;
+                    } else if (needed) {
+                        received = rx_ok;
                     }
                     L_ctr[lt] = c + 1u;
                 }
