@@ -147,6 +147,14 @@ int rs_get_alloc_trace(rs_handle* h, rs_alloc_rec* out);
  * [1] = env-steps executed, [2] = PF loop iterations, [3] = UE-slots. */
 int rs_get_counters(rs_handle* h, uint64_t counters[4]);
 
+/* The reception step (slice_l1.py:219-224: `rng.random() < mcs_codeset.response(mcs, snr)`, channel_models.py:297-313) is
+ * decided without forming the probability whenever a float32 evaluation of both sides leaves no doubt (rs_embb.hip:
+ * fast_sigmoid; the outcome is the exact comparison's in every case).  Since the last rs_reset, per-slice step kernels
+ * without allocation tracing: out[0] = reception tests, out[1] = those that evaluated the exact probability, out[2] = 1 if
+ * the short test is available for this configuration (mcsA > 0, every MI slope k > 0, 1 <= mcsA / k <= 1e4).  The two counts
+ * share one 64-bit word per task (32 bits each: they wrap after ~2e7 steps of one task). */
+int rs_get_rx_stats(rs_handle* h, uint64_t out[3]);
+
 /* Average device time of the dominant step kernel over the launches since the last call,
  * measured with HIP events on the handle's stream (bench.py roofline leg). */
 int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches);

@@ -98,6 +98,9 @@ struct rs_handle {
     std::vector<std::pair<void*, size_t>> regions;  // every device array behind the handle but the tables (rs_save_state)
     double* fad = nullptr;
     uint8_t* fad_valid = nullptr;
+    double rx_band0 = 0.0;       // the reception test's guard band per RB before the table-dependent term (rx_fast_setup)
+    float* fad32 = nullptr;      // the same samples in float32 (the reception test by guard band: rs_embb.hip, fast_sigmoid)
+    double* fps = nullptr;       // per column the prefix sums of its samples, P + 1 entries (channel estimates by guard band)
     bool fad_loaded[RS_N_TRACES] = {false, false, false};
     std::vector<double> fad_host[RS_N_TRACES];
     std::vector<uint8_t> valid_host[RS_N_TRACES];
@@ -378,7 +381,7 @@ static void mcs_lookup(const rs_config* c, double A, double B, int e_snr, int* m
 //   band = 6e-6 + 6e-6 k/A per RB (needed: 2.8e-6 + 1.6e-6 k/A).  Single-RB spans compare s - ref with s* - ref in dB:
 //   6.2e-6/A of error + 8e-6/A of margin -> 4e-5/A + 1e-6.
 // Off (band 0: every UE evaluated exactly) unless A > 0, every k > 0 and 1 <= A/k <= 1e4.
-static void rx_fast_setup(RsDev& d) {
+static void rx_fast_setup(RsDev& d, double* band0) {
     const double A = d.mcsA;
     double kmax = 0.0, kmin = 1e300;
     bool ok = std::isfinite(A) && A > 0.0 && std::isfinite(d.mcsB);
@@ -392,12 +395,13 @@ static void rx_fast_setup(RsDev& d) {
     ok = ok && A / kmax >= 1.0 && A / kmin <= 1.0e4;
     d.rx_invA = ok ? (float)(1.0 / A) : 0.0f;
     d.rx_B = (float)d.mcsB;
-    d.rx_band = ok ? 6.0e-6 + 6.0e-6 * (kmax / A) : 0.0;
+    d.rx_band = 0.0;  // set when the tables are loaded (upload_fading adds the float32 samples' term)
+    *band0 = ok ? 6.0e-6 + 6.0e-6 * (kmax / A) : 0.0;
     d.rx_band1 = ok ? 4.0e-5 / A + 1.0e-6 : 0.0;
-    if (dev_env("RANSLICE_RX_EXACT")) d.rx_band = 0.0;  // test build: the exact probability for every UE
-    if (const char* e = dev_env("RANSLICE_RX_BAND_SCALE")) {  // test build: a wider band sends more UEs down the exact path
+    if (dev_env("RANSLICE_RX_EXACT")) *band0 = 0.0;  // test build: the exact probability for every UE
+    if (const char* e = dev_env("RANSLICE_RX_BAND_SCALE")) {
         const double f = atof(e);
-        if (f >= 1.0) { d.rx_band *= f; d.rx_band1 *= f; }
+        if (f >= 1.0) d.rx_band1 *= f;
     }
 }
 
@@ -539,7 +543,7 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
         d.mi_x0[m] = cfg->mi_x0[m];
         d.mi_k[m] = cfg->mi_k[m];
     }
-    rx_fast_setup(d);
+    rx_fast_setup(d, &h->rx_band0);
     d.mtc_n_dev = cfg->mtc_n_devices;
     d.mtc_cap = cfg->max_mtc_queue > 0 ? cfg->max_mtc_queue : 1024;
     d.mtc_n_rep = cfg->mtc_n_rep;
@@ -651,6 +655,8 @@ extern "C" void rs_destroy(rs_handle* h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->fad) (void)hipFree(h->fad);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
+    if (h->fad32) (void)hipFree(h->fad32);
+    if (h->fps) (void)hipFree(h->fps);
     if (h->d_trace) (void)hipFree(h->d_trace);
     for (auto& e : h->ev) {
         (void)hipEventDestroy(e.first);
@@ -704,6 +710,10 @@ static int upload_fading(rs_handle* h) {
     }
     if (h->fad) (void)hipFree(h->fad);
     if (h->fad_valid) (void)hipFree(h->fad_valid);
+    if (h->fad32) (void)hipFree(h->fad32);
+    if (h->fps) (void)hipFree(h->fps);
+    h->fad32 = nullptr;
+    h->fps = nullptr;
     // tail padding so that a subgroup's strided reads never leave the allocation
     HIPCHK(h, hipMalloc((void**)&h->fad, sizeof(double) * (elems + 16)));
     HIPCHK(h, hipMalloc((void**)&h->fad_valid, vbytes + 16));
@@ -714,6 +724,58 @@ static int upload_fading(rs_handle* h) {
                                  hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipMemcpyAsync(h->fad_valid + d.valid_off[f], h->valid_host[f].data(), h->valid_host[f].size(),
                                  hipMemcpyHostToDevice, h->stream));
+    }
+    {
+        // Two derived tables for the decisions the step kernel takes by guard band (rs_embb.hip): the samples in float32
+        // for the MI sums of the reception test, and per column the prefix sums of its samples (accumulated in long double,
+        // rounded once) for the channel estimates, round(mean(snr over the slice's RBs)) = round((PS[hi] - PS[lo]) / n + nominal)
+        // unless the mean lies within est_band of a half-integer.  Error of that mean against the f64 pairwise sum the exact
+        // path forms: 2^-52 P smax (the two prefix entries) + 1.1e-15 (smax + |nominal|) (the pairwise sum) + the roundings of
+        // the quotient and the sum < 1.1e-10 for smax <= 1e3, |mean| <= 3e4 (checked by the kernel) -> est_band 1e-9.
+        const int P = d.P;
+        std::vector<float> t32(elems + 64, 0.0f);
+        std::vector<double> ps((elems / (size_t)P) * (size_t)(P + 1) + 16, 0.0);
+        double smax = 0.0;
+        bool finite = true;
+        for (int f = 0; f < RS_N_TRACES; ++f) {
+            const std::vector<double>& tab = h->fad_host[f];
+            const size_t cols = tab.size() / (size_t)P, c0 = (size_t)d.fad_off[f] / (size_t)P;
+            d.col_off[f] = (int32_t)c0;
+            for (size_t t = 0; t < cols; ++t) {
+                long double acc = 0.0L;
+                double* row = &ps[(c0 + t) * (size_t)(P + 1)];
+                row[0] = 0.0;
+                const bool ok = h->valid_host[f][t] != 0;
+                for (int p = 0; p < P; ++p) {
+                    const double v = tab[t * (size_t)P + p];
+                    t32[(size_t)d.fad_off[f] + t * (size_t)P + p] = (float)v;
+                    acc += (long double)v;
+                    row[p + 1] = (double)acc;
+                    if (ok) {
+                        finite = finite && std::isfinite(v);
+                        smax = std::fabs(v) > smax ? std::fabs(v) : smax;
+                    }
+                }
+            }
+        }
+        const bool small = finite && smax <= 1.0e3;
+        d.est_band = (small && !dev_env("RANSLICE_EST_EXACT")) ? 1.0e-9 : 0.0;
+        // the float32 sample adds 2^-24 smax to the sigmoid's argument in dB: 0.25 k 2^-24 smax per RB, doubled
+        double kmax = 0.0;
+        for (int m = 0; m < 3; ++m) kmax = d.mi_k[m] > kmax ? d.mi_k[m] : kmax;
+        d.rx_band = (small && h->rx_band0 > 0.0) ? h->rx_band0 + 0.5 * kmax * 5.97e-8 * smax : 0.0;
+        if (const char* e = dev_env("RANSLICE_RX_BAND_SCALE")) {  // test build: a wider band sends more UEs down the exact path
+            const double fsc = atof(e);
+            if (fsc >= 1.0) d.rx_band *= fsc;
+        }
+        if (const char* e = dev_env("RANSLICE_EST_BAND")) {  // test build: the estimates' band itself (0.2: two in five by the pairwise sum)
+            const double b = atof(e);
+            if (d.est_band > 0.0 && b > 0.0 && b < 0.5) d.est_band = b;
+        }
+        HIPCHK(h, hipMalloc((void**)&h->fad32, sizeof(float) * t32.size()));
+        HIPCHK(h, hipMalloc((void**)&h->fps, sizeof(double) * ps.size()));
+        HIPCHK(h, hipMemcpy(h->fad32, t32.data(), sizeof(float) * t32.size(), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->fps, ps.data(), sizeof(double) * ps.size(), hipMemcpyHostToDevice));
     }
     HIPCHK(h, hipMemcpyAsync(h->ddev, &d, sizeof d, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -809,6 +871,8 @@ static int launch_step(rs_handle* h) {
             a.D = h->ddev;
             a.S = h->d_st;
             a.fad = h->fad;
+            a.fad32 = h->fad32;
+            a.fps = h->fps;
             a.fad_valid = h->fad_valid;
             a.actions = h->d_actions;
             a.run = h->d_run;
@@ -870,6 +934,8 @@ static int launch_step(rs_handle* h) {
         a.D = h->ddev;
         a.S = h->d_st;
         a.fad = h->fad;
+        a.fad32 = h->fad32;
+        a.fps = h->fps;
         a.fad_valid = h->fad_valid;
         a.actions = h->d_actions;
         a.run = h->d_run;
@@ -1216,6 +1282,19 @@ extern "C" int rs_get_counters(rs_handle* h, uint64_t counters[4]) {
     HIPCHK(h, hipMemcpyAsync(counters, h->d_counter_sum, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     counters[1] = h->steps * (uint64_t)h->cfg.n_envs;
+    return RS_OK;
+}
+
+extern "C" int rs_get_rx_stats(rs_handle* h, uint64_t out[3]) {
+    if (!h || !out) return RS_EINVAL;
+    uint64_t c[4];
+    const int rc = rs_get_counters(h, c);
+    if (rc != RS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(c, h->d_counter_sum, sizeof(uint64_t) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    out[0] = c[1] >> 32;
+    out[1] = c[1] & 0xffffffffull;
+    out[2] = h->hdev.rx_band > 0.0 ? 1u : 0u;
     return RS_OK;
 }
 

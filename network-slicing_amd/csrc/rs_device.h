@@ -53,6 +53,9 @@ struct RsDev {
     double mi_x0[3], mi_k[3];  // mutual-information sigmoid per modulation (channel_models.py:268-270)
     // the reception test by guard band (rs_embb.hip: fast_sigmoid; set up by rx_fast_setup in rs_api.hip)
     double rx_band;         // guard band of the MI-sum comparison, per RB of the span; 0 = every UE takes the exact path
+    double est_band;        // guard band of round(mean SINR) formed from the prefix sums; 0 = every estimate by the pairwise sum
+    int32_t col_off[3];     // columns of the traces before trace f (fad_off / P)
+    int32_t pad_rx;
     double rx_band1;        // guard band (dB) of the single-RB comparison
     float rx_c1[3];         // -k log2(e) per modulation
     float rx_invA, rx_B;    // 1 / mcsA, mcsB

@@ -503,6 +503,8 @@ struct StepArgs {
     const RsDev* D;
     const RsState* S;         // device copy of the state pointers (kept out of the kernarg SGPRs)
     const double* fad;        // [trace][time][P]
+    const float* fad32;       // the same samples in float32 (decisions by guard band; rs_api.hip: upload_fading)
+    const double* fps;        // [trace][time][P + 1] prefix sums of a column's samples
     const uint8_t* fad_valid; // [trace][time]
     const int32_t* actions;   // [n_envs][n_slices]
     const int64_t* run;       // device-side run state: [0] slots elapsed since reset before this step (rs_api.hip)
@@ -643,20 +645,27 @@ __device__ __noinline__ double wide_response(const double* mi, const double* fad
 // exactly as before.  The outcome is the exact path's outcome in every case, so results stay bit-identical to the oracle;
 // only ~2e-4 of the evaluations take the exact path (counted: rs_get_rx_stats).
 //
-// sigmoid of the float argument d (= snr - x0, any magnitude) with slope constant c1 = -k log2(e): absolute error below
-// 3e-7 whatever d is (the argument's relative error of 2e-7 enters through t sigma'(t) <= 0.23)
-__device__ __forceinline__ float fast_sigmoid(float d, float c1) {
-    float t2 = d * c1;
-    t2 = __builtin_fminf(__builtin_fmaxf(t2, -100.0f), 100.0f);  // 2^+-100: finite, normal; sigmoid is 0 or 1 to 1e-30 there
+// sigmoid of snr - x0 = (v + hi) + lo (v: the float32 sample; hi + lo: nominal SINR - x0 split into two floats, so that no
+// rounding is relative to anything but the argument itself) with slope constant c1 = -k log2(e), loc = lo c1: absolute error below
+// 4e-7 whatever the magnitudes (the argument's relative error of 2e-7 enters through t sigma'(t) <= 0.23; v_exp_f32 overflows
+// to +inf and underflows to 0, which v_rcp_f32 turns into the limits 0 and 1)
+__device__ __forceinline__ float fast_sigmoid(float v, float hi, float c1, float loc) {
+    const float t2 = __builtin_fmaf(v + hi, c1, loc);
     const float e = __builtin_amdgcn_exp2f(t2);
     return __builtin_amdgcn_rcpf(1.0f + e);
 }
+typedef float rs_f4u __attribute__((ext_vector_type(4), aligned(4)));
+// sum of the sigmoids of the (up to four) elements k0 .. k0 + 3 < n held in q: (s0 + s1) + (s2 + s3) in float32
+__device__ __forceinline__ float fast_quad(rs_f4u q, int k0, int n, float hi, float c1, float loc) {
+    const float s0 = fast_sigmoid(q.x, hi, c1, loc), s1 = fast_sigmoid(q.y, hi, c1, loc);
+    const float s2 = fast_sigmoid(q.z, hi, c1, loc), s3 = fast_sigmoid(q.w, hi, c1, loc);
+    return ((k0 < n ? s0 : 0.0f) + (k0 + 1 < n ? s1 : 0.0f)) + ((k0 + 2 < n ? s2 : 0.0f) + (k0 + 3 < n ? s3 : 0.0f));
+}
 
-// S~ of the spans flagged `mine` (2..RS_FAST_WIDE RBs), dealt to 8-lane teams like team_response; any order
-#ifndef RS_FAST_WIDE
-#define RS_FAST_WIDE 48
-#endif
-__device__ __forceinline__ double fast_team_sums(const double* mi, const float* c1s, const double* fad, const double* nom_wave,
+// S~ of the spans flagged `mine` (2..64 RBs), dealt to 8-lane teams like team_response: lane j of a team takes elements
+// 4 j .. 4 j + 3 and 32 + 4 j .. 35 + 4 j -- two 16-byte loads, both in flight; any order of summation will do
+#define RS_FAST_WIDE 64
+__device__ __forceinline__ double fast_team_sums(const double* mi, const float* c1s, const float* fad32, const double* nom_wave,
                                                  bool mine, int rbs, int span_col, int mod) {
     const int lane = (int)(threadIdx.x & 63u);
     double out = 0.0;
@@ -678,17 +687,15 @@ __device__ __forceinline__ double fast_team_sums(const double* mi, const float* 
         const int n_o = bperm(rbs, owner);
         const int n = on ? n_o : 0;
         const int md = bperm(mod, owner);
+        const float* __restrict__ sp = fad32 + (on ? c0 : 0) + 4 * j;
+        rs_f4u qa = {0.0f, 0.0f, 0.0f, 0.0f}, qb = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (4 * j < n) qa = *(const rs_f4u*)sp;
+        if (32 + 4 * j < n) qb = *(const rs_f4u*)(sp + 32);
         const double nomx = nom_wave[owner] - mi[md];
         const float c1 = c1s[md];
-        const double* __restrict__ sp = fad + (on ? c0 : 0);
-        double acc = 0.0;
-        for (int i = j; wave_any(i < n); i += 16) {
-            const bool p1 = i < n, p2 = i + 8 < n;
-            const double v1 = p1 ? sp[i] : 0.0, v2 = p2 ? sp[i + 8] : 0.0;  // (both fetches in flight)
-            const float s1 = fast_sigmoid((float)(v1 + nomx), c1), s2 = fast_sigmoid((float)(v2 + nomx), c1);
-            acc += p1 ? (double)s1 : 0.0;
-            acc += p2 ? (double)s2 : 0.0;
-        }
+        const float hi = (float)nomx, loc = (float)(nomx - (double)hi) * c1;
+        double acc = (double)fast_quad(qa, 4 * j, n, hi, c1, loc);
+        if (wave_any(n > 32)) acc += (double)fast_quad(qb, 32 + 4 * j, n, hi, c1, loc);
         acc += dpp_d<DPP_XOR1>(acc);
         acc += dpp_d<DPP_XOR2>(acc);
         acc += dpp_d<DPP_HMIRROR>(acc);
@@ -698,29 +705,32 @@ __device__ __forceinline__ double fast_team_sums(const double* mi, const float* 
     return out;
 }
 
-// S~ of spans wider than RS_FAST_WIDE RBs (an agent's allocation): the whole wave, one RB per lane and pass
-__device__ __forceinline__ double fast_wide_sums(const double* mi, const float* c1s, const double* fad, const double* nom_wave,
+// S~ of spans wider than RS_FAST_WIDE RBs (an agent's allocation): the whole wave, lane l elements 4 l .. 4 l + 3 of the span in
+// one 16-byte load (n <= 256); the next span's load is issued before this one's arithmetic
+__device__ __forceinline__ double fast_wide_sums(const double* mi, const float* c1s, const float* fad32, const double* nom_wave,
                                                  bool mine, int rbs, int span_col, int mod) {
     const int lane = (int)(threadIdx.x & 63u);
     double out = 0.0;
     unsigned long long wm = __builtin_amdgcn_ballot_w64(mine);
+    rs_f4u q = {0.0f, 0.0f, 0.0f, 0.0f};
+    {
+        const int ol = __builtin_ctzll(wm);
+        if (4 * lane < __builtin_amdgcn_readlane(rbs, ol)) q = *(const rs_f4u*)(fad32 + __builtin_amdgcn_readlane(span_col, ol) + 4 * lane);
+    }
     while (wm != 0ull) {
         const int ol = __builtin_ctzll(wm);  // the span's owner lane (uniform)
         wm &= wm - 1ull;
         const int n = __builtin_amdgcn_readlane(rbs, ol);
-        const int c0 = __builtin_amdgcn_readlane(span_col, ol);
         const int md = __builtin_amdgcn_readlane(mod, ol);
+        rs_f4u qn = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (wm != 0ull) {
+            const int on_ = __builtin_ctzll(wm);
+            if (4 * lane < __builtin_amdgcn_readlane(rbs, on_)) qn = *(const rs_f4u*)(fad32 + __builtin_amdgcn_readlane(span_col, on_) + 4 * lane);
+        }
         const double nomx = nom_wave[ol] - mi[md];
         const float c1 = c1s[md];
-        double acc = 0.0;
-        for (int k0 = 0; k0 < n; k0 += 128) {
-            const int k1 = k0 + lane, k2 = k0 + 64 + lane;
-            const bool p1 = k1 < n, p2 = k2 < n;
-            const double v1 = p1 ? fad[c0 + k1] : 0.0, v2 = p2 ? fad[c0 + k2] : 0.0;
-            const float s1 = fast_sigmoid((float)(v1 + nomx), c1), s2 = fast_sigmoid((float)(v2 + nomx), c1);
-            acc += p1 ? (double)s1 : 0.0;
-            acc += p2 ? (double)s2 : 0.0;
-        }
+        const float hi = (float)nomx, loc = (float)(nomx - (double)hi) * c1;
+        double acc = (double)fast_quad(q, 4 * lane, n, hi, c1, loc);
         acc += dpp_d<DPP_XOR1>(acc);
         acc += dpp_d<DPP_XOR2>(acc);
         acc += dpp_d<DPP_HMIRROR>(acc);
@@ -728,6 +738,7 @@ __device__ __forceinline__ double fast_wide_sums(const double* mi, const float* 
         acc += bperm(acc, lane ^ 16);
         acc += bperm(acc, lane ^ 32);
         if (lane == ol) out = acc;
+        q = qn;
     }
     return out;
 }
@@ -798,6 +809,9 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     const int gran = D->gran;
     const bool has_nan = D->has_nan != 0;
     const bool rx_fast = D->rx_band > 0.0;  // the reception test by guard band is available for this configuration
+    const double est_band = D->est_band;
+    const bool est_fast = !TRACE && est_band > 0.0 && A.fps != nullptr;
+    const int co0 = D->col_off[0], co1 = D->col_off[1], co2 = D->col_off[2];
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2];
     const int fo0 = (int)D->fad_off[0], fo1 = (int)D->fad_off[1], fo2 = (int)D->fad_off[2];  // < 2^31 (rs_load_fading)
     const int vo0 = (int)D->valid_off[0], vo1 = (int)D->valid_off[1], vo2 = (int)D->valid_off[2];
@@ -882,6 +896,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     // per-step statistics of the task in one register: UE-slots (bits 0-11, <= 50 x 32), scheduled slots (bits
     // 12-17, <= 50), PF trips (bits 18-31, <= 50 x 128); the fading-sample and RB-pair counters follow from them
     unsigned stat = 0u;
+    unsigned n_rx_tests = 0u;  // reception tests of this wave in this step (wave-uniform; rs_get_rx_stats)
     {
         // The launch ends when its slowest wave ends, and all waves of the batch are co-resident, so waves
         // whose tasks were expensive in the previous step (persistent backlog -> long contested PF loops)
@@ -1148,9 +1163,24 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                             walker_advance(f, fs, Tn, has_nan, vcol, k0, k1, (uint32_t)isl, ser, (uint32_t)(now + a));
                     }
                 }
-                const double* __restrict__ colp = A.fad + (on ? sel3(ftype, fo0, fo1, fo2) + f * P + plo : 0);
-                const double sum = lane_pairwise(np, on, [&](int i) { return colp[i] + nom; });
-                if (on) T_esnr[wb + src][tt] = (short)(int)RS_RINT(sum / (double)np);  // round(np.mean(...)): half-to-even (Q7)
+                // round(np.mean(snr)) (half-to-even, Q7) from the column's prefix sums -- two loads whatever the slice's width --
+                // unless the mean lies within est_band of a half-integer (rs_api.hip: upload_fading); then, as in the tracing
+                // instances' every estimate, numpy's pairwise sum of the samples themselves decides
+                bool todo = on;
+                if (est_fast) {
+                    const double* __restrict__ ps = A.fps + (on ? (sel3(ftype, co0, co1, co2) + f) * (P + 1) + plo : 0);
+                    const double pa = ps[0], pb = ps[on ? np : 0];
+                    const double mean = (pb - pa) / (double)np + nom;
+                    const double rr = RS_RINT(mean);
+                    const bool sure = __builtin_fabs(mean - rr) < 0.5 - est_band && __builtin_fabs(mean) < 3.0e4;
+                    if (on && sure) T_esnr[wb + src][tt] = (short)(int)rr;
+                    todo = on && !sure;
+                }
+                if (wave_any(todo)) {
+                    const double* __restrict__ colp = A.fad + (todo ? sel3(ftype, fo0, fo1, fo2) + f * P + plo : 0);
+                    const double sum = lane_pairwise(np, todo, [&](int i) { return colp[i] + nom; });
+                    if (todo) T_esnr[wb + src][tt] = (short)(int)RS_RINT(sum / (double)np);  // round(np.mean(...)): half-to-even (Q7)
+                }
             }
         }
 
@@ -1572,6 +1602,7 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             // ---- the reception test by guard band (see fast_sigmoid above): decided in float32 for all but ~2e-4 of the UEs
             bool exact = needed;   // UEs whose probability is evaluated exactly
             bool rx_ok = false;    // outcome of the others
+            if (!TRACE) n_rx_tests += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(needed));  // (scalar: statistics only)
             if (!TRACE && rx_fast) {
                 double u = 0.5;
                 if (needed) {
@@ -1586,13 +1617,13 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
                 const bool multi = needed && !single;
                 const bool fw = multi && rbs > RS_FAST_WIDE;
                 double S = 0.0;
-                if (wave_any(fw)) S = fast_wide_sums(L_mi, L_c1, A.fad, &L_nom[wb], fw, rbs, span_col, mod);
+                if (wave_any(fw)) S = fast_wide_sums(L_mi, L_c1, A.fad32, &L_nom[wb], fw, rbs, span_col, mod);
                 if (wave_any(multi && !fw)) {
-                    const double s2 = fast_team_sums(L_mi, L_c1, A.fad, &L_nom[wb], multi && !fw, rbs, span_col, mod);
+                    const double s2 = fast_team_sums(L_mi, L_c1, A.fad32, &L_nom[wb], multi && !fw, rbs, span_col, mod);
                     S = fw ? S : s2;
                 }
                 if (needed && single) S = (A.fad[span_col] + L_nom[lt]) - ref;
-                const float ystar = fast_sigmoid((float)((ref - x0) + (double)dq), L_c1[mod]);
+                const float ystar = fast_sigmoid((float)((ref - x0) + (double)dq), 0.0f, L_c1[mod], 0.0f);
                 const double St = single ? (double)dq : (double)rbs * (double)ystar;
                 const double band = single ? D->rx_band1 : (double)rbs * D->rx_band;
                 const double dd = S - St;
@@ -1714,6 +1745,8 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
     flush();
     SEC_FLUSH(A.sections)
     const bool wave_worked = wave_any(valid);
+    // reception tests of the wave: upper half of counter [1] of its first task (the lower half counts the UEs evaluated exactly)
+    if (!TRACE && (tid & 63) == 0 && n_rx_tests != 0u) atomicAdd((unsigned long long*)&A.counters[(size_t)task * 4 + 1], (unsigned long long)n_rx_tests << 32);
     if (RS_DYN_PRIO && A.pace && (tid & 63) == 0 && wave_worked) {
         atomicAdd(&A.pace[0], (__builtin_amdgcn_s_memtime() - pace_t0) / (unsigned long long)slots);
         atomicAdd(&A.pace[1], 1ull);

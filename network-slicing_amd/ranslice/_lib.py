@@ -22,7 +22,7 @@ KB_EXPORTS = (
 
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
-    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
+    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_get_rx_stats', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
     'rs_set_kernel_timing', 'rs_synchronize', 'rs_state_bytes', 'rs_save_state', 'rs_load_state', 'rs_device_count', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
 ) + KB_EXPORTS
 
@@ -77,6 +77,7 @@ def load(dev=None):
     L.rs_set_alloc_trace.argtypes = [vp, C.c_int]
     L.rs_get_alloc_trace.argtypes = [vp, vp]
     L.rs_get_counters.argtypes = [vp, up]
+    L.rs_get_rx_stats.argtypes = [vp, up]
     L.rs_get_section_profile.argtypes = [vp, up]
     L.rs_get_task_profile.argtypes = [vp, up]
     L.rs_set_group_size.argtypes = [vp, C.c_int]

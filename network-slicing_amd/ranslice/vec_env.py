@@ -156,6 +156,12 @@ class VecRanSlice:
         self._check(self.L.rs_get_counters(self.h, c))
         return [int(x) for x in c]
 
+    def rx_stats(self):
+        """(reception tests, of which evaluated the exact probability, short test available) since reset()"""
+        c = (C.c_uint64 * 3)()
+        self._check(self.L.rs_get_rx_stats(self.h, c))
+        return int(c[0]), int(c[1]), bool(c[2])
+
     def set_kernel_timing(self, enable=True):
         self._check(self.L.rs_set_kernel_timing(self.h, int(bool(enable))))
 
