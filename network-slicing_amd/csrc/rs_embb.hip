@@ -665,8 +665,9 @@ __device__ __forceinline__ float fast_quad(rs_f4u q, int k0, int n, float hi, fl
 // S~ of the spans flagged `mine` (2..64 RBs), dealt to 8-lane teams like team_response: lane j of a team takes elements
 // 4 j .. 4 j + 3 and 32 + 4 j .. 35 + 4 j -- two 16-byte loads, both in flight; any order of summation will do
 #define RS_FAST_WIDE 64
+template <class F>
 __device__ __forceinline__ double fast_team_sums(const double* mi, const float* c1s, const float* fad32, const double* nom_wave,
-                                                 bool mine, int rbs, int span_col, int mod) {
+                                                 bool mine, int rbs, int span_col, int mod, F meanwhile) {
     const int lane = (int)(threadIdx.x & 63u);
     double out = 0.0;
     const unsigned long long wmask = __builtin_amdgcn_ballot_w64(mine);
@@ -693,6 +694,7 @@ __device__ __forceinline__ double fast_team_sums(const double* mi, const float* 
         if (32 + 4 * j < n) qb = *(const rs_f4u*)(sp + 32);
         const double nomx = nom_wave[owner] - mi[md];
         const float c1 = c1s[md];
+        if (round == 0) meanwhile();  // the caller's arithmetic that needs none of this, under the loads' latency
         const float hi = (float)nomx, loc = (float)(nomx - (double)hi) * c1;
         double acc = (double)fast_quad(qa, 4 * j, n, hi, c1, loc);
         if (wave_any(n > 32)) acc += (double)fast_quad(qb, 32 + 4 * j, n, hi, c1, loc);
@@ -1604,27 +1606,39 @@ __global__ __launch_bounds__(256, (G == 16 && !TRACE) ? RS_OCC : RS_OCC_OTHER) v
             bool rx_ok = false;    // outcome of the others
             if (!TRACE) n_rx_tests += (unsigned)__popcll(__builtin_amdgcn_ballot_w64(needed));  // (scalar: statistics only)
             if (!TRACE && rx_fast) {
-                double u = 0.5;
-                if (needed) {
-                    rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], L_ctr[lt]};
-                    u = rs_stream_uniform(&st);  // the draw the reception step consumes below
-                }
-                const bool central = u >= 1.0e-4 && u <= 1.0 - 1.0e-4;
-                const float lf = 0.6931471805599453f * __builtin_amdgcn_logf((float)(1.0 - u) * __builtin_amdgcn_rcpf((float)u));
-                const float dq = (D->rx_B - lf) * D->rx_invA;  // s* - ref(mcs), dB
-                const double x0 = L_mi[mod], ref = L_ref[mcs];
                 const bool single = rbs == 1;  // no MI average (channel_models.py:305): the RB's SINR against s* itself
                 const bool multi = needed && !single;
                 const bool fw = multi && rbs > RS_FAST_WIDE;
+                const double x0 = L_mi[mod], ref = L_ref[mcs];
+                double S1 = 0.0;
+                if (needed && single) S1 = A.fad[span_col];
+                bool central = false;
+                double St = 0.0;
+                // the draw and the threshold S*(u): independent of the sums, so they run while the samples are on their way
+                auto threshold = [&]() {
+                    double u = 0.5;
+                    if (needed) {
+                        rs_stream st = {key0, key1, (uint32_t)sl, L_serial[lt], L_ctr[lt]};
+                        u = rs_stream_uniform(&st);  // the draw the reception step consumes below
+                    }
+                    central = u >= 1.0e-4 && u <= 1.0 - 1.0e-4;
+                    const float lf = 0.6931471805599453f * __builtin_amdgcn_logf((float)(1.0 - u) * __builtin_amdgcn_rcpf((float)u));
+                    const float dq = (D->rx_B - lf) * D->rx_invA;  // s* - ref(mcs), dB
+                    const float ystar = fast_sigmoid((float)((ref - x0) + (double)dq), 0.0f, L_c1[mod], 0.0f);
+                    St = single ? (double)dq : (double)rbs * (double)ystar;
+                };
                 double S = 0.0;
-                if (wave_any(fw)) S = fast_wide_sums(L_mi, L_c1, A.fad32, &L_nom[wb], fw, rbs, span_col, mod);
+                bool thr_done = false;
                 if (wave_any(multi && !fw)) {
-                    const double s2 = fast_team_sums(L_mi, L_c1, A.fad32, &L_nom[wb], multi && !fw, rbs, span_col, mod);
-                    S = fw ? S : s2;
+                    S = fast_team_sums(L_mi, L_c1, A.fad32, &L_nom[wb], multi && !fw, rbs, span_col, mod, threshold);
+                    thr_done = true;
                 }
-                if (needed && single) S = (A.fad[span_col] + L_nom[lt]) - ref;
-                const float ystar = fast_sigmoid((float)((ref - x0) + (double)dq), 0.0f, L_c1[mod], 0.0f);
-                const double St = single ? (double)dq : (double)rbs * (double)ystar;
+                if (wave_any(fw)) {
+                    const double s2 = fast_wide_sums(L_mi, L_c1, A.fad32, &L_nom[wb], fw, rbs, span_col, mod);
+                    S = fw ? s2 : S;
+                }
+                if (!thr_done) threshold();
+                if (needed && single) S = (S1 + L_nom[lt]) - ref;
                 const double band = single ? D->rx_band1 : (double)rbs * D->rx_band;
                 const double dd = S - St;
                 const bool sure = central && (dd > band || dd < -band);  // (NaN anywhere: not sure)
