@@ -156,7 +156,7 @@ def _free_port():
 
 
 KBRL_CAPACITY = 4096          # a limit, not a reservation: dictionaries take their storage from the pool as they grow
-KBRL_POOL_BYTES = 64 << 30
+KBRL_POOL_HEADROOM = 24 << 30   # the pool takes the device's free memory less this (ranslice._lib.default_pool_bytes)
 KBRL_LATE_STEP = 3000         # second measurement point: dictionaries of several hundred landmarks
 SEL_TILE_ROWS = 16            # select_gemm_kernel: v_mfma_f64_16x16x4 tiles of 16 candidates x 16 learners, 4 grid indices per instruction
 
@@ -171,11 +171,13 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
     from ranslice.fading import synth_traces
     from ranslice.kbrl_dev import VecKBRL
     from ranslice.vec_env import VecRanSlice
+    from ranslice import _lib
     cap = int(os.environ.get('KBRL_CAPACITY', KBRL_CAPACITY))
     cfg = make_config(SCENARIO, n_envs=n_envs)
     env = VecRanSlice(n_envs=n_envs, cfg=cfg, fading=synth_traces(FADING_COLS, profile), device=device)
+    pool_bytes = _lib.default_pool_bytes(device, headroom=KBRL_POOL_HEADROOM)   # sized from hipMemGetInfo
     agent = VecKBRL(n_envs, [10] * cfg.n_embb, cfg.n_prbs, accuracy_range=(0.99, 0.999), capacity=cap, device=device,
-                    pool_bytes=KBRL_POOL_BYTES)
+                    pool_bytes=pool_bytes)
     rng = np.random.default_rng(0)
     ia = rng.integers(EMBB_A[0], EMBB_A[1], size=(n_envs, cfg.n_embb)).astype(np.int32)   # scenario_creator.py:220-221
     sf = rng.integers(EMBB_SEC[0], EMBB_SEC[1], size=(n_envs, cfg.n_embb)).astype(np.int32)
@@ -302,7 +304,7 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
     rec = {
         'workload': 'scenario_0, %d replicas + one KBRL agent per replica, closed loop on the device (%s traces)'
                     % (n_envs, profile),
-        'traces': profile, 'dictionary_capacity': cap, 'pool_bytes': KBRL_POOL_BYTES,
+        'traces': profile, 'dictionary_capacity': cap, 'pool_bytes': pool_bytes,
         'value': head['value'], 'unit': 'env-steps/s', 'ms_per_step': head['ms_per_step'], 'value_at_steps': head['steps'],
         'roofline': (head['kinv_streaming'] or {}).get('rank1'),
         'early': early, 'late': late,
@@ -311,6 +313,15 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
                    'update_control starts from the scores select_action left (DESIGN.md section 4 KBRL)',
         'peak_tflops_f64': F64_PEAK_TFLOPS,
     }
+    # the reference's run length (experiments_kbrl.py:22: 50,400 steps): how many replicas of one GPU get there without a flagged
+    # dictionary -- measured by tools/run_length.py, committed under profiles/
+    rpath = os.path.join(ROOT, 'profiles', 'run_length.json')
+    if os.path.exists(rpath):
+        try:
+            with open(rpath) as f:
+                rec['reference_run_length'] = json.load(f)
+        except Exception:
+            pass
     ppath = os.path.join(ROOT, 'profiles', 'kbrl_mfma_share.json')
     if os.path.exists(ppath):
         try:
@@ -511,8 +522,12 @@ def compact_kbrl(k):
          'mfma_instructions': (head.get('select_mfma') or {}).get('instructions_per_launch'),
          'mfma_kernel': 'select_gemm_kernel (v_mfma_f64_16x16x4)',
          'dictionary_size_mean': _r(head.get('dictionary_size_mean')), 'dictionary_size_max': head.get('dictionary_size_max'),
-         'pool_GB_used': _r((head.get('pool') or {}).get('used_bytes', 0) / 1e9),
+         'pool_GB_used': _r((head.get('pool') or {}).get('used_bytes', 0) / 1e9), 'pool_GB': _r(k.get('pool_bytes', 0) / 1e9),
          'pool_exhausted_near_step': _r((head.get('pool_horizon') or {}).get('exhausted_near_step'))}
+    rl = k.get('reference_run_length') or {}
+    if rl:
+        c['replicas_reaching_50400_steps_unflagged'] = rl.get('replicas_unflagged')
+        c['run_length_source'] = rl.get('source')
     return c
 
 
@@ -724,8 +739,9 @@ def main():
         env.set_kernel_timing(True)
         run(100)
         env.synchronize()
-    kern_ms, launches = env.kernel_time_ms()
+    (kern_ms, kern_min, kern_max), launches = env.kernel_time_stats_ms()
     env.set_kernel_timing(False)
+    rx_tests, rx_exact, rx_short = env.rx_stats()
     out = env.fetch()  # also surfaces capacity-overflow errors
     assert np.isfinite(out['reward']).all()
 
@@ -752,9 +768,16 @@ def main():
             'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
             'traffic': None,
-            'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'launches_timed': launches,
+            'algorithmic_bytes_per_launch': alg_bytes, 'kernel_ms': kern_ms, 'kernel_ms_min': kern_min, 'kernel_ms_max': kern_max,
+            'launches_timed': launches,
             'bytes_per_env_step': alg_bytes / n_envs, 'mean_ues_per_slice': mean_ue,
             'pf_iterations_per_env_step': (c1[2] - c0[2]) / args.steps / n_envs,
+            # the byte model above is the REFERENCE algorithm's (every UE reads its slice's samples every slot, 8 B each:
+            # channel_models.py:171-191); since round 6 the kernel takes the channel estimates from per-column prefix sums (16 B
+            # each) and the reception sums from a float32 mirror, so what it moves (`traffic`) is less than it
+            'byte_model': 'reference algorithm: 8 B x fading samples + 2 x state + I/O (SURVEY 8d)',
+            # reception tests decided in float32 by guard band / of which fell inside the band and formed the f64 probability
+            'rx_tests_since_reset': rx_tests, 'rx_exact_share': (rx_exact / rx_tests) if rx_tests else None, 'rx_short_test': rx_short,
         }
         # Counters of a separate rocprofv3 --pmc run of this command (tools/profile_round.sh), NOT of this process: the HBM bytes per
         # launch are comparable with algorithmic_bytes_per_launch only at the same UE population, so `traffic` is filled in only then.
@@ -768,7 +791,10 @@ def main():
                 same = pop is not None and abs(pop - mean_ue) <= 0.03 * mean_ue and n_envs == prof.get('n_envs', ENVS_PER_GPU)
                 if same:
                     roof['traffic'] = prof.get('embb_step_kernel_bytes_per_launch')
-                    roof['traffic_source'] = prof.get('file', 'profiles/hbm_traffic.json')
+                    roof['traffic_over_algorithmic'] = roof['traffic'] / alg_bytes if roof['traffic'] and alg_bytes else None
+                    roof['traffic_from'] = 'committed profile (%s; FETCH_SIZE x %.1f, WRITE_SIZE x %.1f per profiles/%s), not this run' % (
+                        prof.get('file', 'profiles/hbm_traffic.json'), prof.get('fetch_correction', 1.0), prof.get('write_correction', 1.0),
+                        prof.get('calibration_file', '?'))
                 roof['profiled_traffic'] = {'bytes_per_launch': prof.get('embb_step_kernel_bytes_per_launch'),
                                             'mean_ues_per_slice': pop, 'same_population_as_this_run': bool(same),
                                             'source': 'profiles/hbm_traffic.json (%s)' % prof.get('source', 'see file')}

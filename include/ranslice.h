@@ -158,6 +158,8 @@ int rs_get_rx_stats(rs_handle* h, uint64_t out[3]);
 /* Average device time of the dominant step kernel over the launches since the last call,
  * measured with HIP events on the handle's stream (bench.py roofline leg). */
 int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches);
+/* The same with the spread: out = {mean, min, max} ms over those launches (a 20-step driver run rests on 20 of them). */
+int rs_kernel_time_stats_ms(rs_handle* h, double out[3], int64_t* launches);
 int rs_set_kernel_timing(rs_handle* h, int enable);
 
 /* Lanes per (replica, eMBB slice) task in the primary step launch: 8, 16 or 32 (default: 32 up to 6144 tasks,
@@ -184,6 +186,8 @@ int rs_get_task_profile(rs_handle* h, uint64_t* out);
 int rs_synchronize(rs_handle* h);
 /* HIP devices visible to this process, or RS_EHIP */
 int rs_device_count(void);
+/* Free and total bytes of a device's memory (hipMemGetInfo), e.g. to size kb_config.pool_bytes. */
+int rs_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes);
 int rs_n_vars(const rs_handle* h);
 /* Checkpoint / restore (no reference counterpart: a run of experiments_kbrl.py that dies starts over).  The state of a handle
  * -- every device array behind it except the tables (fading traces, constants), plus its slot clock -- as one blob of

@@ -683,6 +683,16 @@ extern "C" int rs_device_count(void) {
     return hipGetDeviceCount(&n) == hipSuccess ? n : RS_EHIP;
 }
 
+/* free and total bytes of a device's memory (hipMemGetInfo): callers size the KBRL pool from it (bench.py, tools/run_length.py) */
+extern "C" int rs_device_mem_info(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    if (!free_bytes || !total_bytes) return RS_EINVAL;
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess) return RS_EHIP;
+    *free_bytes = (uint64_t)f;
+    *total_bytes = (uint64_t)t;
+    return RS_OK;
+}
+
 // ------------------------------------------------------------------ fading tables
 
 static int upload_fading(rs_handle* h) {
@@ -1343,20 +1353,32 @@ extern "C" int rs_set_kernel_timing(rs_handle* h, int enable) {
     return RS_OK;
 }
 
-extern "C" int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches) {
-    if (!h || !avg_ms) return RS_EINVAL;
+extern "C" int rs_kernel_time_stats_ms(rs_handle* h, double out[3], int64_t* launches) {
+    if (!h || !out) return RS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    double tot = 0.0;
+    double tot = 0.0, mn = 0.0, mx = 0.0;
     for (size_t i = 0; i < h->ev_used; ++i) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[i].first, h->ev[i].second));
         tot += ms;
+        mn = (i == 0 || ms < mn) ? ms : mn;
+        mx = ms > mx ? ms : mx;
     }
-    *avg_ms = h->ev_used ? tot / (double)h->ev_used : 0.0;
+    out[0] = h->ev_used ? tot / (double)h->ev_used : 0.0;
+    out[1] = mn;
+    out[2] = mx;
     if (launches) *launches = (int64_t)h->ev_used;
     h->ev_used = 0;
     return RS_OK;
+}
+
+extern "C" int rs_kernel_time_ms(rs_handle* h, double* avg_ms, int64_t* launches) {
+    if (!h || !avg_ms) return RS_EINVAL;
+    double st[3];
+    const int rc = rs_kernel_time_stats_ms(h, st, launches);
+    if (rc == RS_OK) *avg_ms = st[0];
+    return rc;
 }
 
 extern "C" int rs_synchronize(rs_handle* h) {

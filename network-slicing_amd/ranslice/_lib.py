@@ -22,8 +22,8 @@ KB_EXPORTS = (
 
 EXPORTS = (
     'rs_create', 'rs_load_fading', 'rs_reset', 'rs_step', 'rs_step_resident', 'rs_random_actions', 'rs_fetch',
-    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_get_rx_stats', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms',
-    'rs_set_kernel_timing', 'rs_synchronize', 'rs_state_bytes', 'rs_save_state', 'rs_load_state', 'rs_device_count', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
+    'rs_get_info', 'rs_set_alloc_trace', 'rs_get_alloc_trace', 'rs_get_counters', 'rs_get_rx_stats', 'rs_set_group_size', 'rs_set_schedule_hint', 'rs_get_section_profile', 'rs_get_task_profile', 'rs_run_random', 'rs_kernel_time_ms', 'rs_kernel_time_stats_ms',
+    'rs_set_kernel_timing', 'rs_synchronize', 'rs_state_bytes', 'rs_save_state', 'rs_load_state', 'rs_device_count', 'rs_device_mem_info', 'rs_n_vars', 'rs_n_slices', 'rs_last_error', 'rs_destroy',
 ) + KB_EXPORTS
 
 
@@ -42,6 +42,21 @@ def device_count():
     if n < 0:
         raise RanSliceError(n, 'hipGetDeviceCount failed')
     return n
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of the device's memory"""
+    f, t = C.c_uint64(), C.c_uint64()
+    rc = load().rs_device_mem_info(int(device), C.byref(f), C.byref(t))
+    if rc < 0:
+        raise RanSliceError(rc, 'hipMemGetInfo failed')
+    return int(f.value), int(t.value)
+
+
+def default_pool_bytes(device=0, headroom=24 << 30, floor=8 << 30):
+    """a KBRL pool that takes what the device has left after `headroom` (the simulator's state, the tables, the histories)"""
+    free, _ = device_mem_info(device)
+    return max(int(floor), int(free) - int(headroom))
 
 
 def load(dev=None):
@@ -83,6 +98,7 @@ def load(dev=None):
     L.rs_set_group_size.argtypes = [vp, C.c_int]
     L.rs_set_schedule_hint.argtypes = [vp, C.c_int]
     L.rs_kernel_time_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
+    L.rs_kernel_time_stats_ms.argtypes = [vp, dp, C.POINTER(C.c_int64)]
     L.rs_set_kernel_timing.argtypes = [vp, C.c_int]
     L.rs_synchronize.argtypes = [vp]
     L.rs_n_vars.argtypes = [vp]
@@ -130,6 +146,7 @@ def load(dev=None):
     L.kb_shared_step_resident.argtypes = [vp, vp, C.c_int32, C.c_int32, ip]
     L.kb_shared_merge.argtypes = [vp, dp, C.c_int32, C.c_int32, C.c_int32, dp, ip, ip, ip]
     L.rs_device_count.argtypes = []
+    L.rs_device_mem_info.argtypes = [C.c_int, up, up]
     L.kb_kernel_time_ms.argtypes = [vp, dp, i64p]
     L.kb_phase_times_ms.argtypes = [vp, dp, i64p]
     L.kb_repair_times_ms.argtypes = [vp, dp, i64p]

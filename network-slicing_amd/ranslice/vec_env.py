@@ -165,6 +165,13 @@ class VecRanSlice:
     def set_kernel_timing(self, enable=True):
         self._check(self.L.rs_set_kernel_timing(self.h, int(bool(enable))))
 
+    def kernel_time_stats_ms(self):
+        """((mean, min, max) ms of the dominant step kernel over the launches since the last call, launches)"""
+        st = (C.c_double * 3)()
+        n = C.c_int64()
+        self._check(self.L.rs_kernel_time_stats_ms(self.h, st, C.byref(n)))
+        return (st[0], st[1], st[2]), n.value
+
     def kernel_time_ms(self):
         ms = C.c_double()
         n = C.c_int64()
