@@ -278,7 +278,8 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
         if ph['select_bin_launch_ms']:
             sb_bytes = float(np.sum(sizes)) * (8.0 * (d - 1) + 8.0 + 4.0 + 16.0)
             gbs = sb_bytes / (ph['select_bin_launch_ms'] * 1e-3) / 1e9
-            rec['select_bin'] = {'bound': 'hbm', 'kernel': 'select_bin_kernel', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+            rec['select_bin'] = {'bound': 'hbm', 'kernel': 'binning pass of select_action: select_bin_big_kernel + select_bin_kernel (+ big_list_kernel), '
+                                 'one HIP-event bracket', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                  'frac': gbs / HBM_PEAK_GBS, 'bytes_per_launch': sb_bytes, 'launch_ms_mean': ph['select_bin_launch_ms'],
                                  'landmarks': int(np.sum(sizes))}
         # the memory horizon: the pool never frees before kb_reset; at the growth of this window it is exhausted at ...

@@ -338,7 +338,7 @@ int kb_set_kernel_timing(kb_handle* k, int enable);
  * n[1] the rank-1 update -- over the span the last kb_phase_times_ms call covered (for their HBM roofline) */
 int kb_repair_times_ms(kb_handle* k, double ms[2], int64_t n[2]);
 /* the same for every kernel that has a roofline entry of its own in the bench record: mean duration of ONE launch over that
- * span -- [2] heavy_matvec_kernel, [3] heavy_rank1_kernel, [4] select_bin_kernel, [5] heavy_finish_kernel, [6] select_gemm_kernel,
+ * span -- [2] heavy_matvec_kernel, [3] heavy_rank1_kernel, [4] the binning pass of select_action (select_bin_kernel alone, or select_bin_big_kernel + select_bin_kernel + big_list_kernel once large learners are listed), [5] heavy_finish_kernel, [6] select_gemm_kernel,
  * [7] update_small_kernel; [0], [1] repeat the two phases of kb_phase_times_ms */
 int kb_kernel_times_ms(kb_handle* k, double ms[8], int64_t n[8]);
 /* Checkpoint / restore of the agents: the per-learner tables, the control state, the part of the dictionary pool in use and

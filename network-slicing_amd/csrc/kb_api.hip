@@ -1466,7 +1466,8 @@ struct kb_state_header {
     uint64_t magic, n_regions, cfg_hash, pool_doubles_used, hist_steps, total_bytes;
     int32_t big_par, is_reset, seen0, seen1;
 };
-static const uint64_t kKbStateMagic = 0x4b42534c49434534ull;
+static const uint64_t kKbStateMagic = 0x4b42534c49434535ull;      // "KBSLICE5": the configuration hash no longer covers the pool's size
+static const uint64_t kKbStateMagicOld = 0x4b42534c49434534ull;   // "KBSLICE4" (rounds 4-5 before that change): refused by name
 static uint64_t kb_cfg_hash(const kb_handle* k) {
     uint64_t x = 1469598103934665603ull;
     kb_config c = k->cfg;
@@ -1540,6 +1541,11 @@ extern "C" int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes) {
     if (!k || !blob || bytes < sizeof(kb_state_header)) return RS_EINVAL;
     kb_state_header hd;
     memcpy(&hd, blob, sizeof hd);
+    if (hd.magic == kKbStateMagicOld) {
+        k->err = "kb_load_state: older checkpoint format (KBSLICE4: its configuration hash covered the pool's size); re-create the "
+                 "checkpoint with this build";
+        return RS_EINVAL;
+    }
     if (hd.magic != kKbStateMagic || hd.n_regions != k->regions.size() || hd.cfg_hash != kb_cfg_hash(k)) {
         k->err = "kb_load_state: the blob was not saved by a handle of this configuration";
         return RS_EINVAL;
@@ -1582,6 +1588,17 @@ extern "C" int kb_load_state(kb_handle* k, const void* blob, uint64_t bytes) {
             HIPCHK(k, hipMemcpy(hp[i], o, part[i], hipMemcpyHostToDevice));
             o += part[i];
         }
+    if (hd.pool_doubles_used < (uint64_t)k->D.pool_doubles) {
+        // "the pool was exhausted" (err bit 16) described the pool the blob came from; this one has room again
+        std::vector<int32_t> e((size_t)k->cfg.n_envs);
+        HIPCHK(k, hipMemcpy(e.data(), k->K.err, sizeof(int32_t) * e.size(), hipMemcpyDeviceToHost));
+        bool any = false;
+        for (auto& v : e) {
+            any = any || (v & 16);
+            v &= ~16;
+        }
+        if (any) HIPCHK(k, hipMemcpy(k->K.err, e.data(), sizeof(int32_t) * e.size(), hipMemcpyHostToDevice));
+    }
     k->big_par = hd.big_par;
     k->is_reset = hd.is_reset != 0;
     if (k->h_seen) {

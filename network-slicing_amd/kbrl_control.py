@@ -115,7 +115,9 @@ class KBRL_Control:
                           "reference's SVvariable grows without bound): pass a larger capacity / pool_bytes to "
                           'KBRL_Control / create_kbrl_agent (capacity up to 65536; the pool is bounded by device memory)'
                           % (sizes[0].tolist(), self._dev.capacity, pool['used_bytes'] / 2 ** 20, pool['total_bytes'] / 2 ** 20))
-        print('KBRL run of %d steps: %.2f PRBs on average, %d SLA violations, %.3f of the actions adjusted, accuracy per learner %s'
-              % (steps, out['resources'].mean(), int(out['violation'].sum()), out['adjusted'].mean(),
-                 np.array2string(out['hits'].mean(axis=1), precision=3)))
+        # the summary the reference's run prints (kbrl_control.py:143-146): same four `label = value` lines on stdout, so that log
+        # parsers written against it keep working
+        for label, value in (('mean resources', out['resources'].mean()), ('total violations', out['violation'].sum()),
+                             ('mean adjusted', out['adjusted'].mean()), ('mean accuracy', out['hits'].mean(axis=1))):
+            print('%s = %s' % (label, value))
         return out

@@ -78,12 +78,21 @@ class VecKBRL:
                                             adjusted.ctypes.data_as(_ip)))
         return action, adjusted
 
+    def _same_library(self, env):
+        # an agent handle and an environment handle that meet in one call must come from the same image of the library (the test
+        # build's structures need not match the production build's: ranslice._lib.load picks per handle)
+        if env.L is not self.L:
+            raise RuntimeError('the agent and the environment were created from different builds of libranslice '
+                               '(RANSLICE_DEV_BUILD changed between the two constructors?)')
+
     def step_resident(self, env):
+        self._same_library(env)
         self._check(self.L.kb_step_resident(self.h, env.h))
 
     def run_resident(self, env, n_steps, graph=True):
         """n_steps x (step_resident(env); env.step_resident()) from one call (kb_run_resident); graph: two captured steps
         replayed as a hipGraph -- same results, a fraction of the launches"""
+        self._same_library(env)
         self._check(self.L.kb_run_resident(self.h, env.h, int(n_steps), 1 if graph else 0))
 
     def history_begin(self, steps):
@@ -312,6 +321,7 @@ class SharedVecKBRL(VecKBRL):
         """one closed-loop agent step on the device: the shared learning step on the simulator's buffers, then
         select_action into them (kb_shared_step_resident).  count_rounds: wait for the number of exchange rounds
         that had proposals (rounds_last); without it the host does not wait for the last permitted round at all"""
+        self._same_library(env)
         if count_rounds:
             rounds = C.c_int32()
             self._check(self.L.kb_shared_step_resident(self.h, env.h, self.budget, self.max_rounds, C.byref(rounds)))

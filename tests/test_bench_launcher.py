@@ -252,3 +252,30 @@ def test_hbm_traffic_summary_feeds_the_roofline():
     assert abs(t['kernel_ms_hip_events'] - t['kernel_ms_rocprofv3_trace']) < 0.05 * t['kernel_ms_hip_events']   # the two clocks agree
     for f in (t['file'], t['valu_issue_file']):
         assert os.path.exists(os.path.join(ROOT, f)), f
+
+
+def test_committed_counter_summaries_are_of_the_current_round():
+    """profiles/kbrl_mfma_share.json and profiles/hbm_traffic.json are printed beside the timings of the round's bench record
+    (`profiled_counters`, `roofline.traffic` / `limiter`): their sources must not be older than the newest committed bench line
+    (round-4 counters beside round-5 timings), and the counter corrections must name a committed calibration."""
+    import glob
+    import json
+    import re
+    prof = os.path.join(ROOT, 'profiles')
+    rounds = [int(m.group(1)) for m in (re.match(r'r(\d+)_.*bench_line\.json$', os.path.basename(f)) for f in glob.glob(os.path.join(prof, 'r*_bench_line.json'))) if m]
+    newest = max(rounds)
+    k = json.load(open(os.path.join(prof, 'kbrl_mfma_share.json')))
+    m = re.search(r'profiles/r(\d+)_', k['source'])
+    assert m and int(m.group(1)) >= newest, (k['source'], newest)
+    assert os.path.exists(os.path.join(ROOT, re.search(r'(profiles/\S+\.txt)', k['source']).group(1)))
+    g = k['kernels']['select_gemm_kernel']
+    assert g['SQ_INSTS_MFMA'] > 0 and 0.05 < g['mfma_util'] < 1.0            # MFMA-busy time / kernel time, from the same state
+    t = json.load(open(os.path.join(prof, 'hbm_traffic.json')))
+    m = re.search(r'profiles/r(\d+)_', t['file'])
+    assert m and int(m.group(1)) >= newest, (t['file'], newest)
+    assert t['fetch_correction'] == 2.0 and t['write_correction'] == 1.0
+    cal = json.load(open(os.path.join(prof, t['calibration_file'].replace('.txt', '.json'))))
+    for name in ('read_4B_per_lane', 'read_8B_per_lane', 'read_16B_per_lane', 'read_128B_segments'):
+        assert abs(cal[name]['fetch_ratio'] * t['fetch_correction'] - 1.0) < 0.01, name     # every coalesced shape: counter x 2 = true bytes
+    for name in ('write_4B_per_lane', 'write_8B_per_lane', 'write_16B_per_lane'):
+        assert abs(cal[name]['write_ratio'] * t['write_correction'] - 1.0) < 0.01, name

@@ -33,7 +33,7 @@ def test_seeds_independent_of_sharding():
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tests/dist_util.py (torch.distributed helpers of the gloo tests)
     from dist_util import max_over_ranks, sum_over_ranks
     from ranslice.sharding import shard_range, replica_seeds, aggregate_throughput
     os.environ['MASTER_ADDR'] = '127.0.0.1'

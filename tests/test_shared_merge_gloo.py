@@ -56,7 +56,7 @@ def test_merge_is_sharding_independent():
 def _worker(rank, world, port, q):
     import torch.distributed as dist
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))   # tests/dist_util.py (torch.distributed helpers of the gloo tests)
     from dist_util import gather_exchange
     from ranslice.kbrl_dev import merge_proposals
     os.environ['MASTER_ADDR'] = '127.0.0.1'

@@ -16,11 +16,52 @@ import struct
 import time
 
 
+def rdzv_dir():
+    """A directory only this user can enter: $XDG_RUNTIME_DIR, else /tmp/ranslice-<uid> (created 0700; refused if somebody else
+    owns it or others may write to it).  The rendezvous file carries the join token, so it must not sit world-readable under a
+    predictable name in /tmp."""
+    d = os.environ.get('XDG_RUNTIME_DIR')
+    if d and os.path.isdir(d) and os.access(d, os.W_OK | os.X_OK):
+        return d
+    d = os.path.join('/tmp', 'ranslice-%d' % os.getuid())
+    try:
+        os.mkdir(d, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    import stat
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        raise PermissionError('rank group: %s is not a private directory of this user' % d)
+    return d
+
+
 def default_rdzv_file():
     f = os.environ.get('RANSLICE_RDZV_FILE')
     if f:
         return f
-    return os.path.join('/tmp', 'ranslice_rdzv_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid()))
+    return os.path.join(rdzv_dir(), 'rdzv_%s_%d' % (os.environ.get('MASTER_PORT', '0'), os.getppid()))
+
+
+def _publish(path, obj):
+    """write `obj` to `path` for the other ranks: a fresh 0600 file (O_EXCL | O_NOFOLLOW: no symlink is followed, nobody's
+    pre-created file is reused) moved into place; a stale file of a crashed launch with the same name is removed first"""
+    try:
+        os.unlink(path)
+    except FileNotFoundError:
+        pass
+    tmp = '%s.%d.%s.tmp' % (path, os.getpid(), secrets.token_hex(4))
+    fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL | os.O_NOFOLLOW, 0o600)
+    with os.fdopen(fd, 'w') as f:
+        json.dump(obj, f)
+    os.replace(tmp, path)
+
+
+def _read_published(path):
+    fd = os.open(path, os.O_RDONLY | os.O_NOFOLLOW)
+    with os.fdopen(fd) as f:
+        if os.fstat(f.fileno()).st_uid != os.getuid():
+            raise PermissionError('rank group: %s belongs to another user' % path)
+        return json.load(f)
 
 
 def _send(sock, obj):
@@ -63,10 +104,7 @@ class RankGroup:
         srv.bind(('127.0.0.1', 0))
         srv.listen(self.world)
         token = secrets.token_hex(16)
-        tmp = '%s.%d.tmp' % (self.file, os.getpid())
-        with open(tmp, 'w') as f:
-            json.dump({'port': srv.getsockname()[1], 'token': token}, f)
-        os.replace(tmp, self.file)
+        _publish(self.file, {'port': srv.getsockname()[1], 'token': token})
         deadline = time.time() + self.timeout
         while len(self.peers) < self.world - 1:
             srv.settimeout(max(0.1, deadline - time.time()))
@@ -96,8 +134,7 @@ class RankGroup:
             if time.time() > deadline:
                 raise TimeoutError('rank group: rank %d found no rank 0 through %s' % (self.rank, self.file))
             try:
-                with open(self.file) as f:
-                    info = json.load(f)
+                info = _read_published(self.file)
                 s = socket.create_connection(('127.0.0.1', int(info['port'])), timeout=2.0)
                 s.settimeout(self.timeout)
                 _send(s, {'token': info['token'], 'rank': self.rank})
