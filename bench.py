@@ -385,6 +385,7 @@ SHARED_SCENARIO = 2           # BASELINE config 4: scenario index 2 (100 PRBs, 1
 SHARED_BUDGET = 256           # proposals per slice and exchange round
 SHARED_CAPACITY = 1024        # landmarks per shared dictionary (config 3/4 capacity)
 SHARED_TIMEOUT_S = 300
+SHARED_FILL_WARMUP = 30       # the first window of the leg starts here: the eMBB dictionary is still filling
 
 
 def shared_leg(args):
@@ -427,16 +428,31 @@ def shared_leg(args):
         for _ in range(k):
             agent.step_resident(env)
             env.step_resident()
+    def window(k):
+        env.synchronize()
+        agent.synchronize()
+        group.barrier()
+        t0 = time.perf_counter()
+        run(k)
+        env.synchronize()
+        agent.synchronize()
+        dt_ = group.max(time.perf_counter() - t0)
+        sz = [int(agent.learner(0, s)['m']) for s in range(len(dims))]
+        return dt_, sz
+
+    def regime_of(sz):
+        # a shared dictionary at its capacity only projects (cheap); one that still grows pays a rank-1 update per insertion
+        return 'saturated' if max(sz) >= SHARED_CAPACITY else 'filling'
+    # two windows: while the eMBB dictionary still fills, and after it has reached its capacity
+    first_w = None
+    if args.shared_warmup > SHARED_FILL_WARMUP:
+        run(SHARED_FILL_WARMUP)
+        dt_a, sz_a = window(args.shared_steps)
+        first_w = {'steps': [SHARED_FILL_WARMUP, SHARED_FILL_WARMUP + args.shared_steps], 'value': world * N * args.shared_steps / dt_a,
+                   'ms_per_step': 1e3 * dt_a / args.shared_steps, 'regime': regime_of(sz_a), 'dictionary_sizes': sz_a}
     run(args.shared_warmup)
-    env.synchronize()
-    agent.synchronize()
-    group.barrier()
-    t0 = time.perf_counter()
-    run(args.shared_steps)
-    env.synchronize()
-    agent.synchronize()
-    dt = group.max(time.perf_counter() - t0)
-    sizes = [int(agent.learner(0, s)['m']) for s in range(len(dims))]
+    dt, sizes = window(args.shared_steps)
+    start = (SHARED_FILL_WARMUP + args.shared_steps if first_w else 0) + args.shared_warmup
     all_sizes = group.allgather(sizes)
     all_ranks = group.allgather([rccl_rank, rccl_ranks])
     if rank == 0:
@@ -448,6 +464,7 @@ def shared_leg(args):
                                                                                          cfg.n_mmtc, N, world),
             'value': world * N * args.shared_steps / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / args.shared_steps,
             'steps': args.shared_steps, 'warmup': args.shared_warmup, 'n_gpus': world,
+            'window': [start, start + args.shared_steps], 'regime': regime_of(sizes), 'filling_window': first_w,
             'rccl_ranks': rccl_ranks, 'rccl_rank_of_each_process': [r[0] for r in all_ranks],
             'collective': 'ncclAllGather (RCCL, bound by libranslice.so: kb_shared_step_resident), one per step on the agent\'s stream',
             'allgather_bytes_per_rank_per_step': blk, 'allgather_bytes_total_per_step': blk * world,
@@ -535,9 +552,13 @@ def compact_kbrl(k):
 def compact_shared(sh):
     if not sh or 'error' in sh:
         return sh
-    keys = ('value', 'unit', 'ms_per_step', 'steps', 'n_gpus', 'rccl_ranks', 'allgather_bytes_total_per_step', 'capacity',
+    keys = ('value', 'unit', 'ms_per_step', 'steps', 'window', 'regime', 'n_gpus', 'rccl_ranks', 'allgather_bytes_total_per_step', 'capacity',
             'dictionary_sizes', 'dictionaries_identical_on_all_ranks')
     c = {k: _r(sh.get(k)) for k in keys}
+    fw = sh.get('filling_window')
+    if fw:
+        c['filling_window'] = {'steps': fw.get('steps'), 'value': _r(fw.get('value')), 'ms_per_step': _r(fw.get('ms_per_step')),
+                               'regime': fw.get('regime')}
     c['workload'] = 'config 4: scenario index 2, 4096 replicas/GPU, shared dictionaries, ncclAllGather per step'
     return c
 

@@ -609,8 +609,13 @@ static int launch_select(kb_handle* k, const float* d_state, int32_t* d_action_o
         hipEvent_t eb, eg;
         if ((rc = kb_time_begin(k, &eb, 4)) != RS_OK) return rc;
         if (a.big_par >= 0) {  // the listed large learners several waves each, the others a wave each
-            hipLaunchKernelGGL(kb::select_bin_big_kernel, dim3(KB_BINBIG_GRID), dim3(64 * KB_BINBIG_WAVES), 0, k->stream, a);
-            hipLaunchKernelGGL(kb::select_bin_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a, (int)KB_BIG_MAX);
+            if (dev_env("KBRL_BIN_TWO_LAUNCHES")) {  // test build: the two kernels one after the other (rounds 4-5; same bits)
+                hipLaunchKernelGGL(kb::select_bin_big_kernel, dim3(KB_BINBIG_GRID), dim3(64 * KB_BINBIG_WAVES), 0, k->stream, a);
+                hipLaunchKernelGGL(kb::select_bin_kernel, dim3((unsigned)k->T), dim3(64), 0, k->stream, a, (int)KB_BIG_MAX);
+            } else {
+                hipLaunchKernelGGL(kb::select_bin_all_kernel, dim3(KB_BINBIG_GRID + (unsigned)((k->T + KB_BINBIG_WAVES - 1) / KB_BINBIG_WAVES)),
+                                   dim3(64 * KB_BINBIG_WAVES), 0, k->stream, a);
+            }
             hipLaunchKernelGGL(kb::big_list_kernel, dim3((unsigned)((k->T + 255) / 256)), dim3(256), 0, k->stream, k->D, k->K, a.big_par);
         } else {
             hipLaunchKernelGGL(kb::select_bin_kernel, dim3(slots), dim3(64), 0, k->stream, a, 0);

@@ -2043,14 +2043,21 @@ __global__ __launch_bounds__(256) void big_list_kernel(KbDev D, KbState K, int b
 #define KB_BINBIG_WAVES 4
 #endif
 #define KB_BINBIG_GRID 1024
-__global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_big_kernel(SelArgs A) {
+struct BinBigLds {
+    double W[256];
+    double Ws[KB_BINBIG_WAVES][256];
+    double dls[KB_BINBIG_WAVES][KB_DLIST * 3];
+    double x[KB_DMAX];
+    int res[KB_BINBIG_WAVES];
+};
+__device__ __forceinline__ void select_bin_big_body(const SelArgs& A, BinBigLds& L_) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    __shared__ double W[256];
-    __shared__ double Ws[KB_BINBIG_WAVES][256];
-    __shared__ double dls[KB_BINBIG_WAVES][KB_DLIST * 3];
-    __shared__ double x[KB_DMAX];
-    __shared__ int res[KB_BINBIG_WAVES];
+    double (&W)[256] = L_.W;
+    double (&Ws)[KB_BINBIG_WAVES][256] = L_.Ws;
+    double (&dls)[KB_BINBIG_WAVES][KB_DLIST * 3] = L_.dls;
+    double (&x)[KB_DMAX] = L_.x;
+    int (&res)[KB_BINBIG_WAVES] = L_.res;
     const int T = D.n_envs * D.S;
     // KB_BINBIG_GRID workgroups walk the list (an empty list costs a thousand workgroups that leave at once, not four thousand)
     for (int slot = (int)blockIdx.x; slot < KB_BIG_MAX; slot += KB_BINBIG_GRID) {
@@ -2107,25 +2114,47 @@ __global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_b
     if (threadIdx.x == 0) K.fdirect[task] = flags | (ndir << 8);
     }
 }
+__global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_big_kernel(SelArgs A) {
+    __shared__ BinBigLds L_;
+    select_bin_big_body(A, L_);
+}
 
 // every other learner (and, on a handle without the list, every learner): a wave each.  slot0: KB_BIG_MAX when the list's
 // places are select_bin_big_kernel's, else 0
-__global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, int slot0) {
+struct BinLds {
+    double W[256];
+    double Wseg[256];
+    double x[KB_DMAX];
+};
+// one wave's barrier with its own LDS traffic: __syncthreads where the wave is the whole workgroup (SOLO), a wave barrier with LDS
+// fences where other waves of the workgroup have left or do other work (select_bin_all_kernel)
+template <bool SOLO>
+__device__ __forceinline__ void bin_wave_sync() {
+    if (SOLO) {
+        __syncthreads();
+    } else {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+template <bool SOLO>
+__device__ __forceinline__ void select_bin_body(const SelArgs& A, int slot, BinLds& L_) {
     const KbDev& D = A.D;
     const KbState& K = A.K;
-    __shared__ double W[256];
-    __shared__ double Wseg[256];
-    __shared__ double x[KB_DMAX];
+    double (&W)[256] = L_.W;
+    double (&Wseg)[256] = L_.Wseg;
+    double (&x)[KB_DMAX] = L_.x;
     const int T = D.n_envs * D.S;
 #ifdef KB_BIN_STAMPS  // experiment build: where a wave's time goes (every 16th wave adds its s_memtime differences to hv_work[4..7])
     const unsigned long long st0 = __builtin_amdgcn_s_memtime();
 #endif
-    const int task = learner_of_slot(K, T, A.big_par, slot0 + (int)blockIdx.x);
+    const int task = learner_of_slot(K, T, A.big_par, slot);
     if (task < 0) return;
     const int env = task / D.S, s = task - env * D.S;
     const int d = D.dims[s] + 1;
     const int dict = dict_of(D, task);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const uint64_t* sh = shells_of(D, K, dict);
     const uint64_t shv = shell_vector(D, sh);  // (requested together with m: one round trip, not two)
     const int m = K.m[dict];
@@ -2140,7 +2169,7 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, i
 #pragma unroll
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
-    __syncthreads();
+    bin_wave_sync<SOLO>();
     const int direct = bin_pass<0, KB_BIN_DEEP>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
 #ifdef KB_BIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -2152,11 +2181,31 @@ __global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, i
         atomicAdd(&K.hv_work[7], 1ull);                             // waves recorded
     }
 #endif
-    __syncthreads();
+    bin_wave_sync<SOLO>();
     double* Wg = K.Wg + (size_t)task * 256;
 #pragma unroll
     for (int k = 0; k < 4; ++k) Wg[lane + 64 * k] = W[lane + 64 * k];
     if (lane == 0) K.fdirect[task] = direct;
+}
+__global__ __launch_bounds__(64, KB_BIN_OCC) void select_bin_kernel(SelArgs A, int slot0) {
+    __shared__ BinLds L_;
+    select_bin_body<true>(A, slot0 + (int)blockIdx.x, L_);
+}
+// Both in ONE launch (round 6): the first KB_BINBIG_GRID workgroups walk the large-learner list four waves a learner, every
+// other workgroup takes four of the remaining learners, a wave each.  As two launches on one stream the two kernels ran one after
+// the other (0.085 + 0.095 ms at step 3000 of config 3), each waiting three quarters of its cycles for memory; side by side they
+// share the chip.  Same routines, same sums, same bits.
+__global__ __launch_bounds__(64 * KB_BINBIG_WAVES, KB_BIN_OCC) void select_bin_all_kernel(SelArgs A) {
+    __shared__ union {
+        BinBigLds big;
+        BinLds one[KB_BINBIG_WAVES];
+    } L_;
+    if ((int)blockIdx.x < KB_BINBIG_GRID) {
+        select_bin_big_body(A, L_.big);
+    } else {
+        const int wv = threadIdx.x >> 6;
+        select_bin_body<false>(A, KB_BIG_MAX + ((int)blockIdx.x - KB_BINBIG_GRID) * KB_BINBIG_WAVES + wv, L_.one[wv]);
+    }
 }
 
 #define KB_WT_LD 17  // doubles between the rows of W^T in LDS (16 learners + 1: the transposing stores spread over the banks)
