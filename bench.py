@@ -429,6 +429,7 @@ def shared_leg(args):
             agent.step_resident(env)
             env.step_resident()
     def window(k):
+        before = [int(agent.learner(0, s)['m']) for s in range(len(dims))]
         env.synchronize()
         agent.synchronize()
         group.barrier()
@@ -438,20 +439,21 @@ def shared_leg(args):
         agent.synchronize()
         dt_ = group.max(time.perf_counter() - t0)
         sz = [int(agent.learner(0, s)['m']) for s in range(len(dims))]
-        return dt_, sz
+        return dt_, sz, before
 
-    def regime_of(sz):
-        # a shared dictionary at its capacity only projects (cheap); one that still grows pays a rank-1 update per insertion
-        return 'saturated' if max(sz) >= SHARED_CAPACITY else 'filling'
+    def regime_of(before):
+        # a shared dictionary at its capacity only projects (cheap); one that still grows pays a rank-1 update per insertion.
+        # Judged at the START of the window: a dictionary that reaches its capacity inside the window was filling in it.
+        return 'saturated' if max(before) >= SHARED_CAPACITY else 'filling'
     # two windows: while the eMBB dictionary still fills, and after it has reached its capacity
     first_w = None
     if args.shared_warmup > SHARED_FILL_WARMUP:
         run(SHARED_FILL_WARMUP)
-        dt_a, sz_a = window(args.shared_steps)
+        dt_a, sz_a, b_a = window(args.shared_steps)
         first_w = {'steps': [SHARED_FILL_WARMUP, SHARED_FILL_WARMUP + args.shared_steps], 'value': world * N * args.shared_steps / dt_a,
-                   'ms_per_step': 1e3 * dt_a / args.shared_steps, 'regime': regime_of(sz_a), 'dictionary_sizes': sz_a}
+                   'ms_per_step': 1e3 * dt_a / args.shared_steps, 'regime': regime_of(b_a), 'dictionary_sizes_start_end': [b_a, sz_a]}
     run(args.shared_warmup)
-    dt, sizes = window(args.shared_steps)
+    dt, sizes, b_main = window(args.shared_steps)
     start = (SHARED_FILL_WARMUP + args.shared_steps if first_w else 0) + args.shared_warmup
     all_sizes = group.allgather(sizes)
     all_ranks = group.allgather([rccl_rank, rccl_ranks])
@@ -464,7 +466,7 @@ def shared_leg(args):
                                                                                          cfg.n_mmtc, N, world),
             'value': world * N * args.shared_steps / dt, 'unit': 'env-steps/s', 'ms_per_step': 1e3 * dt / args.shared_steps,
             'steps': args.shared_steps, 'warmup': args.shared_warmup, 'n_gpus': world,
-            'window': [start, start + args.shared_steps], 'regime': regime_of(sizes), 'filling_window': first_w,
+            'window': [start, start + args.shared_steps], 'regime': regime_of(b_main), 'filling_window': first_w,
             'rccl_ranks': rccl_ranks, 'rccl_rank_of_each_process': [r[0] for r in all_ranks],
             'collective': 'ncclAllGather (RCCL, bound by libranslice.so: kb_shared_step_resident), one per step on the agent\'s stream',
             'allgather_bytes_per_rank_per_step': blk, 'allgather_bytes_total_per_step': blk * world,

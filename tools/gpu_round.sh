@@ -22,3 +22,8 @@ import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
 print('envs_per_gpu $n (hipGraph loop): value %.4g ms_per_step %.4f kernel_ms %.4f ues %.3f' % (d['value'], d['ms_per_step'], r['kernel_ms'], r['mean_ues_per_slice']))" | tee -a $OUT/${TAG}_big_batches.txt
 done
+# the launch path the driver uses at N = 2, and the one-command curve, on one device (a check of the path, not a scaling measurement)
+( RANSLICE_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --gpus 2 --steps 20 --warmup 5 > $OUT/${TAG}_driver2_stdout.txt 2> $OUT/${TAG}_driver2_stderr.txt; echo "driver-style --gpus 2 rc=$?" )
+tail -1 $OUT/${TAG}_driver2_stdout.txt > $OUT/${TAG}_driver_style_two_ranks_one_gpu.json; cut -c1-300 $OUT/${TAG}_driver_style_two_ranks_one_gpu.json
+( RANSLICE_BENCH_SHARE_GPU=1 timeout 900 python3 bench.py --scaling 1,2 --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_scaling_1_2_one_gpu.json 2> $OUT/${TAG}_scaling_stderr.txt; echo "scaling rc=$?" )
+cut -c1-600 $OUT/${TAG}_scaling_1_2_one_gpu.json
