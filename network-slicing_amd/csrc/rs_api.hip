@@ -769,7 +769,9 @@ static int upload_fading(rs_handle* h) {
             }
         }
         const bool small = finite && smax <= 1.0e3;
-        d.est_band = (small && !dev_env("RANSLICE_EST_EXACT")) ? 1.0e-9 : 0.0;
+        // (the kernel addresses the prefix table with 32-bit element offsets, as it does the samples)
+        const bool ps_fits = ps.size() + (size_t)RS_MAX_PRBS < ((size_t)1 << 31);
+        d.est_band = (small && ps_fits && !dev_env("RANSLICE_EST_EXACT")) ? 1.0e-9 : 0.0;
         // the float32 sample adds 2^-24 smax to the sigmoid's argument in dB: 0.25 k 2^-24 smax per RB, doubled
         double kmax = 0.0;
         for (int m = 0; m < 3; ++m) kmax = d.mi_k[m] > kmax ? d.mi_k[m] : kmax;
