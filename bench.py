@@ -274,9 +274,11 @@ def kbrl_record(n_envs, device, steps, warmup, late_step=KBRL_LATE_STEP, profile
                             'select_gemm': ph['select_gemm_launch_ms'] * ph['n_select_gemm'] / k},
         }
         # select_bin_kernel: ONE pass over every landmark of every learner -- ten coordinate rows, the coefficient and the grid index
-        # in (92 B per landmark of an eMBB learner), the D0 and E rows out (16 B); bytes from the dictionary sizes at the window's end
+        # in (52 B per landmark of an eMBB learner since the coordinates come as float32; 92 B before), the D0 and E rows out (16 B); bytes
+        # from the dictionary sizes at the window's end
         if ph['select_bin_launch_ms']:
-            sb_bytes = float(np.sum(sizes)) * (8.0 * (d - 1) + 8.0 + 4.0 + 16.0)
+            # (round 6: the ten state coordinates from their float32 copy, 4 B each)
+            sb_bytes = float(np.sum(sizes)) * (4.0 * (d - 1) + 8.0 + 4.0 + 16.0)
             gbs = sb_bytes / (ph['select_bin_launch_ms'] * 1e-3) / 1e9
             rec['select_bin'] = {'bound': 'hbm', 'kernel': 'binning pass of select_action: select_bin_big_kernel + select_bin_kernel (+ big_list_kernel), '
                                  'one HIP-event bracket', 'achieved': gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

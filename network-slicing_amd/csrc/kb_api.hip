@@ -346,6 +346,7 @@ extern "C" int kb_create(const kb_config* cfg, int device, kb_handle** out) {
     KA(k->d_cstar, T, true);
     KA(K.workb, D.shared ? (size_t)cfg->n_slices * 2 * k->budget_cap * kb::kb_capr(cfg->capacity) : 1, true);
     KA(K.offgrid, ND, true);
+    KA(K.f32bad, ND, true);
     KA(K.F, D.shared ? 1 : T * 256, true);
     KA(K.fstate, D.shared ? 1 : T * 16, true);
     KA(K.fver, T, true);
@@ -454,6 +455,7 @@ extern "C" int kb_reset(kb_handle* k, const int32_t* initial_action, const int32
     HIPCHK(k, hipMemsetAsync(k->K.shell, 0, sizeof(uint64_t) * (size_t)k->n_dict * k->D.max_shells, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.head, 0xFF, sizeof(int32_t) * (size_t)k->n_dict * KB_HEAD, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.offgrid, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
+    HIPCHK(k, hipMemsetAsync(k->K.f32bad, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.ver, 0, sizeof(int32_t) * (size_t)k->n_dict, k->stream));
     HIPCHK(k, hipMemsetAsync(k->K.fver, 0xFF, sizeof(int32_t) * T, k->stream));  // -1: no stored scores
     HIPCHK(k, hipMemsetAsync(k->d_gstats, 0, sizeof(uint64_t) * 32, k->stream));

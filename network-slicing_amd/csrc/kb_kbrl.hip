@@ -46,6 +46,10 @@ namespace kb {
 #define KB_GTAB 264       // G[k], k = 0..255 (+ padding)
 #define KB_CH 64          // landmarks per chunk
 #define KB_TILE 4096      // doubles per Kinv tile
+#define KB_ROW_F32 11     // eMBB dictionaries (ten state coordinates + the allocation: rows 0..10): rows 11..15 hold the ten state
+                          //   coordinates again as float32, [coordinate][64 landmarks] -- they ARE float32 observations
+                          //   (slice_ran.py:321-325), so the copy is exact and the binning pass of select_action reads 40 B per
+                          //   landmark where the f64 rows are 80 (round 6; K.f32bad says when a dictionary cannot use it)
 #define KB_ROW_CO 16      // rows of a vector page (64 doubles each): 0..15 coordinates, then
 #define KB_ROW_D0 17      //   |l_j[:d-1] - state|^2 of the state being processed
 #define KB_ROW_E 18       //   exp(-gamma D0)
@@ -135,6 +139,8 @@ struct KbState {
     int32_t* isbig;    // [2][T] membership of that list
     double* workb;     // shared mode: [S][2][budget_cap][cap rounded up to 64] kernel columns and d* of a proposal list
     int32_t* offgrid;  // [ND] landmarks whose last coordinate is off the candidate grid (inserted through kb_update)
+    int32_t* f32bad;   // [ND] landmarks of an eMBB dictionary with a state coordinate that is not a float32 value (inserted through
+                       //      kb_update): the binning pass then reads the f64 coordinate rows instead of their float32 copy
     // the scores select_action formed for every candidate of its state (select_gemm_kernel): update_control of the SAME
     // state against the SAME dictionary (the next call of KBRL_Control.run's loop, kbrl_control.py:129-134) starts from them
     double* F;         // [T][256]
@@ -313,12 +319,18 @@ struct ChunkRows {
     int a;
 };
 template <int MODE>
-__device__ __forceinline__ void load_chunk(const double* P, int lane, int d, ChunkRows<MODE>& R) {
+__device__ __forceinline__ void load_chunk(const double* P, int lane, int d, ChunkRows<MODE>& R, bool f32 = false) {
     if (MODE == 1) {
         R.v[0] = P[KB_ROW_E * KB_CH + lane];
     } else if (d - 1 == 10) {
+        if (f32) {  // (wave-uniform) the float32 copy of the ten state coordinates: the same numbers in half the bytes
+            const float* F = (const float*)(P + KB_ROW_F32 * KB_CH);
 #pragma unroll
-        for (int q = 0; q < 10; ++q) R.v[q] = P[q * KB_CH + lane];
+            for (int q = 0; q < 10; ++q) R.v[q] = (double)F[q * KB_CH + lane];
+        } else {
+#pragma unroll
+            for (int q = 0; q < 10; ++q) R.v[q] = P[q * KB_CH + lane];
+        }
     }
     R.co = P[KB_ROW_CO * KB_CH + lane];
     R.a = ((const int32_t*)(P + KB_ROW_IDX * KB_CH))[lane];
@@ -481,6 +493,9 @@ __device__ __forceinline__ void score(const KbDev& D, const KbState& K, const ui
 #define KB_BIN_DEEP 0  // chunks whose rows a wave of the select_bin kernels requests together (0: one ahead, rotating registers;
                        // 2 and 4 measured no faster: profiles/r05_kbrl_variants.txt)
 #endif
+#ifndef KB_F32_ROWS
+#define KB_F32_ROWS 1  // the select_bin kernels read the float32 copy of the state coordinates (KB_ROW_F32)
+#endif
 #ifndef KB_BIN_SEG
 #define KB_BIN_SEG 4  // chunks per segment of a binning pass (below); changes the bits of W for dictionaries beyond a segment
 #endif
@@ -545,7 +560,7 @@ __device__ __forceinline__ void bin_one_chunk(const KbDev& D, const ChunkRows<MO
 // 4 (168, three waves per SIMD) are no faster than 0 (profiles/r05_kbrl_variants.txt), so 0 stays everywhere.
 template <int MODE, int DEEP>
 __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, const uint64_t* sh, uint64_t shv, int m, int d, const double* x,
-                                           int b0, int b1, double* Wacc, double* dlist, int pos0) {
+                                           int b0, int b1, double* Wacc, double* dlist, int pos0, bool f32 = false) {
     const int lane = threadIdx.x & 63;
     int flags = 0, ndir = 0;
     if (DEEP > 0) {  // DEEP chunks' rows requested together, in registers of their own; the segment in groups of DEEP
@@ -556,7 +571,7 @@ __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, cons
                 ChunkRows<MODE> Rs[DEEP ? DEEP : 1];
 #pragma unroll
                 for (int i = 0; i < DEEP; ++i)
-                    if (b0 + g0 + i < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + g0 + i), lane, d, Rs[i]);
+                    if (b0 + g0 + i < b1) load_chunk<MODE>(page_of(K, sh, shv, b0 + g0 + i), lane, d, Rs[i], f32);
 #pragma unroll
                 for (int i = 0; i < DEEP; ++i) {
                     if (b0 + g0 + i < b1) {  // (wave-uniform)
@@ -569,11 +584,11 @@ __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, cons
         }
     } else {
         ChunkRows<MODE> R, Rn;
-        load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn);
+        load_chunk<MODE>(page_of(K, sh, shv, b0), lane, d, Rn, f32);
         for (int b = b0; b < b1; ++b) {
             double* P = page_of(K, sh, shv, b);
             R = Rn;
-            if (b + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn);
+            if (b + 1 < b1) load_chunk<MODE>(page_of(K, sh, shv, b + 1), lane, d, Rn, f32);
             bin_one_chunk<MODE>(D, R, P, lane, m - 64 * b < 64 ? m - 64 * b : 64, d, x, Wacc, dlist, pos0, flags, ndir);
         }
     }
@@ -587,16 +602,16 @@ __device__ __forceinline__ int bin_chunks(const KbDev& D, const KbState& K, cons
 // with the same bits as from this one wave.  Wseg: 256 doubles of LDS scratch (used beyond one segment).
 template <int MODE, int DEEP = 0>
 __device__ __forceinline__ int bin_pass(const KbDev& D, const KbState& K, const uint64_t* sh, int m, int d, const double* x,
-                                         double* W, double* Wseg, double* dlist, uint64_t shv) {
+                                         double* W, double* Wseg, double* dlist, uint64_t shv, bool f32 = false) {
     const int lane = threadIdx.x & 63;
     const int nch = (m + 63) >> 6;
-    if (nch <= KB_BIN_SEG) return bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, 0, nch, W, dlist, 0);
+    if (nch <= KB_BIN_SEG) return bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, 0, nch, W, dlist, 0, f32);
     int flags = 0, ndir = 0;
     for (int b0 = 0; b0 < nch; b0 += KB_BIN_SEG) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) Wseg[lane + 64 * k] = 0.0;
         const int b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
-        const int r = bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, b0, b1, Wseg, dlist, ndir);
+        const int r = bin_chunks<MODE, DEEP>(D, K, sh, shv, m, d, x, b0, b1, Wseg, dlist, ndir, f32);
         flags |= r & 3;
         ndir += r >> 8;
 #pragma unroll
@@ -1205,6 +1220,11 @@ __device__ int finish_update(const KbDev& D, const KbState& K, int dict, int err
         double* P = vec_page(K, sh, m >> 6);
         const int l = m & 63;
         if ((int)threadIdx.x < d - 1) P[threadIdx.x * KB_CH + l] = x[threadIdx.x];
+        if (d - 1 == 10 && (int)threadIdx.x < 10) {  // the float32 copy (KB_ROW_F32); exact for observations, flagged otherwise
+            const float xf = (float)x[threadIdx.x];
+            ((float*)(P + KB_ROW_F32 * KB_CH))[threadIdx.x * KB_CH + l] = xf;
+            if ((double)xf != x[threadIdx.x]) K.f32bad[dict] = 1;
+        }
         if (threadIdx.x == 0) {
             P[(d - 1) * KB_CH + l] = t_last;
             P[KB_ROW_CO * KB_CH + l] = (double)y;
@@ -2079,6 +2099,7 @@ __device__ __forceinline__ void select_bin_big_body(const SelArgs& A, BinBigLds&
     if (threadIdx.x < d - 1) x[threadIdx.x] = (double)A.state[(size_t)env * D.nv + D.off[s] + threadIdx.x];
     __syncthreads();
     const int nch = (m + 63) >> 6, nseg = (nch + KB_BIN_SEG - 1) / KB_BIN_SEG;
+    const bool f32 = KB_F32_ROWS && d - 1 == 10 && K.f32bad[dict] == 0;
     double* dlist = K.dlist + (size_t)task * (KB_DLIST * 3);
     int flags = 0, ndir = 0;
     for (int s0 = 0; s0 < nseg; s0 += KB_BINBIG_WAVES) {
@@ -2088,7 +2109,7 @@ __device__ __forceinline__ void select_bin_big_body(const SelArgs& A, BinBigLds&
 #pragma unroll
             for (int k = 0; k < 4; ++k) Ws[wv][lane + 64 * k] = 0.0;
             const int b0 = sg * KB_BIN_SEG, b1 = b0 + KB_BIN_SEG < nch ? b0 + KB_BIN_SEG : nch;
-            r = bin_chunks<0, KB_BIN_DEEP>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0);
+            r = bin_chunks<0, KB_BIN_DEEP>(D, K, sh, shv, m, d, x, b0, b1, Ws[wv], dls[wv], 0, f32);
         }
         if (lane == 0) res[wv] = r;
         __syncthreads();
@@ -2170,7 +2191,8 @@ __device__ __forceinline__ void select_bin_body(const SelArgs& A, int slot, BinL
     for (int k = 0; k < 4; ++k) W[lane + 64 * k] = 0.0;
     if (lane < d - 1) x[lane] = (double)A.state[(size_t)env * D.nv + D.off[s] + lane];
     bin_wave_sync<SOLO>();
-    const int direct = bin_pass<0, KB_BIN_DEEP>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv);
+    const int direct = bin_pass<0, KB_BIN_DEEP>(D, K, sh, m, d, x, W, Wseg, K.dlist + (size_t)task * (KB_DLIST * 3), shv,
+                                                KB_F32_ROWS && d - 1 == 10 && K.f32bad[dict] == 0);
 #ifdef KB_BIN_STAMPS
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     const unsigned long long st2 = __builtin_amdgcn_s_memtime();

@@ -116,7 +116,7 @@ def main():
         'step_workload_per_env_step': {'fading_samples': per(0), 'pf_iterations': per(2), 'ue_slots': per(3)},
         'kb_update_phase_ms': ph['update_ms'], 'kb_select_ms': ph['select_ms'],
         'per_step_ms': {k2: ph[k2 + '_launch_ms'] * ph['n_' + k2] / args.steps for k2 in ('matvec', 'rank1', 'finish', 'update_small', 'select_bin', 'select_gemm')},
-        'select_bin_GBs': (float(sizes.sum()) * 108.0 / (ph['select_bin_launch_ms'] * 1e-3) / 1e9) if ph['select_bin_launch_ms'] else None,
+        'select_bin_GBs': (float(sizes.sum()) * 68.0 / (ph['select_bin_launch_ms'] * 1e-3) / 1e9) if ph['select_bin_launch_ms'] else None,
         'kinv_streaming': {'heavy_matvec_kernel': roof('matvec', 'matvec_launch_ms', 'n_matvec'), 'heavy_rank1_kernel': roof('rank1', 'rank1_launch_ms', 'n_rank1')},
         'stamps_raw_w4_w7': [int(x) for x in agent._repair_raw()[4:8]],
         'direct_passes_per_step': (w1['direct_passes'] - w0['direct_passes']) / args.steps,
