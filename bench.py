@@ -789,7 +789,7 @@ def main():
         alg_bytes = b_fading + b_state + b_io
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
         roof = {
-            'bound': 'hbm', 'kernel': 'embb_step_kernel' if n_tasks < 61440 else
+            'bound': 'hbm', 'kernel': 'embb_step_kernel' if n_tasks < 49152 else
             'embb_step_kernel<8> + embb_step_kernel<16> side by side (the split step of large batches; kernel_ms spans both)',
             'achieved': achieved, 'peak': HBM_PEAK_GBS,
             'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,

@@ -616,9 +616,10 @@ extern "C" int rs_create(const rs_config* cfg, int device, rs_handle** out) {
     // The split step pays where the batch is several rounds of waves -- the launch is then bound by the instructions issued, and
     // eight like tasks per wave issue a sixth fewer than four -- and loses where every wave is resident at once and the launch ends
     // with its slowest wave, whose chain eight tasks in lockstep lengthen (round 5, 4096 / 8192 / 16384 / 65536 replicas: step
-    // kernel 1.08 -> 1.19-1.31 ms, 1.98 -> 1.95, 3.55 -> 2.96, 13.2 -> 11.5 with a head; profiles/r05_c_mixed.txt).  From 12,288
-    // replicas of five slices on: the lightest 7/8 of the ranking on the 8-lane instance.
-    if (h->group == 16 && h->n_tasks >= 61440) h->mixed_light = 224;
+    // kernel 1.08 -> 1.19-1.31 ms, 1.98 -> 1.95, 3.55 -> 2.96, 13.2 -> 11.5 with a head; profiles/r05_c_mixed.txt).  With round 6's
+    // kernel (profiles/r06_x_split_threshold.txt): 8192 replicas of five slices even, 10,240 replicas 5.29 -> 5.79 M env-steps/s.  From
+    // 49,152 tasks on: the lightest 7/8 of the ranking on the 8-lane instance.
+    if (h->group == 16 && h->n_tasks >= 49152) h->mixed_light = 224;
     if (const char* e = dev_env("RANSLICE_MIXED")) h->mixed = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_UE")) h->mixed_ue = atoi(e);
     if (const char* e = dev_env("RANSLICE_MIXED_LIGHT")) h->mixed_light = atoi(e);

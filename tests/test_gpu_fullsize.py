@@ -358,7 +358,7 @@ def _oracle_churn_script_run(args):
 
 
 def test_split_step_at_its_batch_size_vs_oracle(golden_dir):
-    """From 12,288 replicas of five slices on the production library deals the cost ranking out to TWO launches side by side: the
+    """From 49,152 tasks (9,831 replicas of five slices) on the production library deals the cost ranking out to TWO launches side by side: the
     lightest 7/8 of the tasks eight to a wave on the 8-lane instance, the rest (every task with eight UEs or more among them) on
     the 16-lane one; a task that outgrows eight lanes inside a step is replayed by the 32-lane instance (rs_api.hip, round 5).
     16,384 replicas of the high-churn configuration (slices of 0 to 15 UEs, NaN-column trace), the scripted loop replayed from a
