@@ -110,3 +110,31 @@ def test_short_reception_test_is_refused_for_slopes_outside_its_proof(golden_dir
     tests, exact, avail = env.rx_stats()
     assert not avail and exact == tests > 0
     env.close()
+
+
+def test_short_paths_step_aside_for_samples_beyond_their_bounds(golden_dir):
+    """The bands of both short paths were derived for samples of at most 1e3 in magnitude (rs_api.hip: upload_fading).  Traces scaled
+    beyond that load as before, the handle reports that the short reception test is off, and the results still equal the oracle's
+    (every estimate by the pairwise sum, every reception by the f64 probability)."""
+    from ranslice.vec_env import VecRanSlice
+    fading = [np.asarray(t) * 40.0 for t in _fading(golden_dir)]     # |samples| up to ~1,600
+    assert max(float(np.nanmax(np.abs(t))) for t in fading) > 1.0e3
+    n = 16
+    env = VecRanSlice(n_envs=n, cfg=_churn(make_config(0, n_envs=n)), fading=fading, seed=5)
+    env.reset()
+    oracles = []
+    for r in range(n):
+        o = po.OracleEnv(_churn(make_config(0)), fading)
+        o.set_seed(replica_seed(5, r))
+        o.reset()
+        oracles.append(o)
+    rng = np.random.default_rng(2)
+    for i in range(6):
+        acts = rng.multinomial(200, [1 / 5.0] * 5, size=n).astype(np.int32)
+        obs, rew, _, info = env.step(acts)
+        for r, o in enumerate(oracles):
+            out = o.step(acts[r])
+            assert obs[r].tobytes() == out['obs'].tobytes() and rew[r] == out['reward'], (i, r)
+    tests, exact, avail = env.rx_stats()
+    assert not avail and exact == tests
+    env.close()
