@@ -279,3 +279,33 @@ def test_committed_counter_summaries_are_of_the_current_round():
         assert abs(cal[name]['fetch_ratio'] * t['fetch_correction'] - 1.0) < 0.01, name     # every coalesced shape: counter x 2 = true bytes
     for name in ('write_4B_per_lane', 'write_8B_per_lane', 'write_16B_per_lane'):
         assert abs(cal[name]['write_ratio'] * t['write_correction'] - 1.0) < 0.01, name
+
+
+def test_rendezvous_file_is_private_and_replaces_stale_ones(tmp_path, monkeypatch):
+    """the rendezvous file carries the join token -- it lives in a directory only the user can enter, is created 0600 without
+    following links, and a stale file of a crashed launch (or a link somebody planted under its name) is removed, not reused."""
+    import stat
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import rank_group as rg
+    monkeypatch.delenv('RANSLICE_RDZV_FILE', raising=False)
+    monkeypatch.delenv('XDG_RUNTIME_DIR', raising=False)
+    monkeypatch.setenv('MASTER_PORT', '29777')
+    f = rg.default_rdzv_file()
+    d = os.path.dirname(f)
+    st = os.lstat(d)
+    assert d == os.path.join('/tmp', 'ranslice-%d' % os.getuid()) and stat.S_ISDIR(st.st_mode) and (st.st_mode & 0o077) == 0
+    assert os.path.basename(f) == 'rdzv_29777_%d' % os.getppid()
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path))
+    assert os.path.dirname(rg.default_rdzv_file()) == str(tmp_path)
+    target = tmp_path / 'somebody_elses_file'
+    target.write_text('{"port": 1, "token": "stale"}')
+    path = str(tmp_path / 'rdzv_x')
+    os.symlink(str(target), path)                        # a planted link under the rendezvous name
+    with pytest.raises(OSError):
+        rg._read_published(path)                         # never followed
+    rg._publish(path, {'port': 4242, 'token': 'fresh'})
+    assert not os.path.islink(path) and (os.lstat(path).st_mode & 0o777) == 0o600
+    assert rg._read_published(path) == {'port': 4242, 'token': 'fresh'}
+    assert target.read_text() == '{"port": 1, "token": "stale"}'     # the link's target was not written through
+    rg._publish(path, {'port': 4243, 'token': 'newer'})  # a stale regular file is replaced as well
+    assert rg._read_published(path)['port'] == 4243
