@@ -620,6 +620,18 @@ def test_checkpoint_and_resume(golden_dir, tmp_path):
         env3.load_state(blob_e)
     with pytest.raises(_lib.RanSliceError):
         ag3.load_state(blob_a)
+    # a blob of the format before round 6 ("KBSLICE4": its configuration hash covered the pool's size) is refused BY NAME, not as
+    # "another configuration" (ADVICE r5); a blob loaded into a roomier pool keeps its dictionaries and drops "pool exhausted"
+    old = blob_a.copy()
+    old[:8] = np.frombuffer((0x4b42534c49434534).to_bytes(8, 'little'), dtype=np.uint8)
+    with pytest.raises(_lib.RanSliceError) as e:
+        ag2.load_state(old)
+    assert 'older checkpoint format' in str(e.value)
+    big = VecKBRL(N, dims, n_prbs, capacity=512, pool_bytes=512 << 20)
+    big.reset(ia * 0 + 1, sf * 0 + 1)
+    big.load_state(blob_a)          # (the pool's size is not part of the configuration)
+    assert big.pool()['pool_full'] == 0
+    big.close()
     for h in (env2, ag2, env3, ag3):
         h.close()
     # ---- the evaluator: interrupted and resumed == uninterrupted
