@@ -133,7 +133,12 @@ def _oracle_script_chunk(args):
     return out
 
 
-@pytest.mark.parametrize('scenario,skip,tail', [(0, 0, 12), (0, 150, 4), (2, 60, 4)])
+# RANSLICE_SOAK_STEPS=k adds one more case: scenario 0 with k steps inside the oracle's loop (k = 3000: the stationary population of
+# the bench, ~6 minutes of oracle time on 16 cores; profiles/r06_ac_soak_every_replica.txt is such a run)
+_SOAK = [(0, int(os.environ['RANSLICE_SOAK_STEPS']), 4)] if os.environ.get('RANSLICE_SOAK_STEPS') else []
+
+
+@pytest.mark.parametrize('scenario,skip,tail', [(0, 0, 12), (0, 150, 4), (2, 60, 4)] + _SOAK)
 def test_every_replica_at_baseline_size_vs_oracle(scenario, skip, tail):
     """the bench path (device action script + resident step, 10,000-column traces, default order and instance)
     with EVERY one of the 4096 replicas followed by an oracle replica.  (0, 12): the first twelve steps, every output of every
